@@ -1,0 +1,460 @@
+// kbj_oracle_task.h — TEST INFRASTRUCTURE ONLY (CPU oracle). Never linked into the product library.
+//
+// Scalar restatement of the task layer of the reference: observations, command sampler, terminations,
+// resets, randomisers, actuators, push events and the reward stack. In-tree pieces follow train.py
+// line by line (cited per function); pieces that live in the un-vendored ksim fork
+// (b-vm/ksim@e88d8bc, requirements.lock:100) follow the definitions frozen in DESIGN.md "Spec decisions".
+// PARITY WITH THE JAX REFERENCE IS UNPINNED.
+#pragma once
+#include "kbj_oracle_physics.h"
+
+namespace kbjo {
+
+// ---- threefry2x32-20 counter RNG (the generator behind jax.random; restated from the Random123 paper) ----
+inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+inline void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
+  static const int rot[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+  uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+  for (int g = 0; g < 5; ++g) {
+    for (int r = 0; r < 4; ++r) { x0 += x1; x1 = rotl32(x1, rot[(g & 1) * 4 + r]); x1 ^= x0; }
+    x0 += ks[(g + 1) % 3]; x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  o0 = x0; o1 = x1;
+}
+struct Rng {
+  uint32_t seed, env;
+  void bits(int stream, uint32_t a, uint32_t b, uint32_t& o0, uint32_t& o1) const {
+    threefry2x32(seed ^ ((uint32_t)stream * 0x9E3779B9u), env, a, b, o0, o1);
+  }
+  // uniform in [0,1) with 24 bits: identical value in the fp32 and fp64 instantiations
+  double uniform(int stream, uint32_t a, uint32_t b) const { uint32_t x, y; bits(stream, a, b, x, y); return (x >> 8) * (1.0 / 16777216.0); }
+  double uniform(int stream, uint32_t a, uint32_t b, double lo, double hi) const { return lo + (hi - lo) * uniform(stream, a, b); }
+  template <class R> R normal(int stream, uint32_t a, uint32_t b) const {  // Box-Muller
+    uint32_t x, y; bits(stream, a, b, x, y);
+    R u1 = (R)(((x >> 8) + 1) * (1.0 / 16777216.0)), u2 = (R)((y >> 8) * (1.0 / 16777216.0));
+    return std::sqrt(-2 * std::log(u1)) * std::cos((R)6.283185307179586 * u2);
+  }
+};
+
+// ---- quaternion helpers restating xax (call sites train.py:264,276-282,317-329,419-451,688-697) ----
+template <class R> inline void quat_to_euler(const R* q, R* e) {
+  R w = q[0], x = q[1], y = q[2], z = q[3];
+  e[0] = std::atan2(2 * (w * x + y * z), 1 - 2 * (x * x + y * y));
+  R sp = 2 * (w * y - z * x);
+  sp = std::min<R>(1, std::max<R>(-1, sp));
+  e[1] = std::asin(sp);
+  e[2] = std::atan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z));
+}
+template <class R> inline void euler_to_quat(const R* e, R* q) {
+  R cr = std::cos(e[0] / 2), sr = std::sin(e[0] / 2), cp = std::cos(e[1] / 2), sp = std::sin(e[1] / 2), cy = std::cos(e[2] / 2), sy = std::sin(e[2] / 2);
+  q[0] = cr * cp * cy + sr * sp * sy; q[1] = sr * cp * cy - cr * sp * sy; q[2] = cr * sp * cy + sr * cp * sy; q[3] = cr * cp * sy - sr * sp * cy;
+}
+template <class R> inline void rotate_by_quat(const R* v, const R* q_in, bool inverse, R* o) {
+  R q[4] = {q_in[0], q_in[1], q_in[2], q_in[3]};
+  quat_norm(q);
+  if (inverse) { q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+  R mat[9]; quat_to_mat(q, mat); mat_vec(mat, v, o);
+}
+
+// ---- COMDistanceObservation (train.py:509-659) ----
+// Andrew monotone chain over the 8 contact slots (lexsort x then y, pop while cross <= 0), masked shoelace centroid
+// with mean-point fallback when |area| < 1e-12, distance to subtree_com[2].xy. With MJX's fixed-size contact
+// array every slot carries geom1 == floor and num_unique(geom2) == 4 >= 3, so the hull branch is always taken.
+template <class R> R com_distance(const R pts_in[NCON][3], const R* com) {
+  int order[NCON];
+  for (int i = 0; i < NCON; ++i) order[i] = i;
+  std::stable_sort(order, order + NCON, [&](int a, int b) {
+    if (pts_in[a][0] != pts_in[b][0]) return pts_in[a][0] < pts_in[b][0];
+    return pts_in[a][1] < pts_in[b][1];
+  });
+  R sp[NCON][2];
+  for (int i = 0; i < NCON; ++i) { sp[i][0] = pts_in[order[i]][0]; sp[i][1] = pts_in[order[i]][1]; }
+  auto cross = [&](int a, int b, int c) { return (sp[b][0] - sp[a][0]) * (sp[c][1] - sp[a][1]) - (sp[b][1] - sp[a][1]) * (sp[c][0] - sp[a][0]); };
+  auto build = [&](bool rev, int* stack) {
+    int ptr = 0;
+    for (int k = 0; k < NCON; ++k) {
+      int idx = rev ? NCON - 1 - k : k;
+      while (ptr >= 2 && cross(stack[ptr - 2], stack[ptr - 1], idx) <= 0) --ptr;
+      stack[ptr++] = idx;
+    }
+    return ptr;
+  };
+  int sl[NCON], su[NCON];
+  int nl = std::max(build(false, sl) - 1, 0), nu = std::max(build(true, su) - 1, 0);
+  R poly[2 * NCON][2];
+  int cnt = 0;
+  for (int i = 0; i < nl; ++i) { poly[cnt][0] = sp[sl[i]][0]; poly[cnt][1] = sp[sl[i]][1]; ++cnt; }
+  for (int i = 0; i < nu; ++i) { poly[cnt][0] = sp[su[i]][0]; poly[cnt][1] = sp[su[i]][1]; ++cnt; }
+  R area = 0, sx = 0, sy = 0, mx = 0, my = 0;
+  for (int i = 0; i < cnt; ++i) {
+    int j = (i + 1 < cnt) ? i + 1 : 0;
+    R cr = poly[i][0] * poly[j][1] - poly[j][0] * poly[i][1];
+    area += cr; sx += (poly[i][0] + poly[j][0]) * cr; sy += (poly[i][1] + poly[j][1]) * cr;
+    mx += poly[i][0]; my += poly[i][1];
+  }
+  area *= (R)0.5;
+  R cx, cy;
+  if (std::fabs(area) < (R)1e-12) { R c = (R)std::max(cnt, 1); cx = mx / c; cy = my / c; }
+  else { cx = sx / (6 * area); cy = sy / (6 * area); }
+  return std::sqrt((cx - com[0]) * (cx - com[0]) + (cy - com[1]) * (cy - com[1]));
+}
+
+// ---- the environment: one instance steps one env ----
+template <class R> struct Env {
+  const kbj_model* m;
+  const kbj_config* c;
+  Rng rng;
+  float* ep;   // KBJ_EP_SIZE
+  float* es;   // KBJ_ES_SIZE
+  Physics<R> phy;
+  Derived<R> d;
+  R qpos[NQ], qvel[NV], warm[NV];
+  R last_ctrl[NU];
+
+  void bind(const kbj_model* m_, const kbj_config* c_, uint32_t seed, int env_gid, float* ep_, float* es_) {
+    m = m_; c = c_; rng.seed = seed; rng.env = (uint32_t)env_gid; ep = ep_; es = es_;
+    phy.m = m; phy.dt = c->dt; phy.opt.iterations = c->solver_iterations; phy.opt.ls_iterations = c->ls_iterations; phy.opt.tolerance = c->solver_tolerance;
+  }
+  uint32_t& episode() { return *reinterpret_cast<uint32_t*>(es + KBJ_ES_EPISODE); }
+  uint32_t& stepctr() { return *reinterpret_cast<uint32_t*>(es + KBJ_ES_STEP); }
+  void load_state() {
+    for (int i = 0; i < NQ; ++i) qpos[i] = es[KBJ_ES_QPOS + i];
+    for (int i = 0; i < NV; ++i) { qvel[i] = es[KBJ_ES_QVEL + i]; warm[i] = es[KBJ_ES_WARM + i]; }
+    phy.p.load(ep);
+  }
+  void store_state() {
+    for (int i = 0; i < NQ; ++i) es[KBJ_ES_QPOS + i] = (float)qpos[i];
+    for (int i = 0; i < NV; ++i) { es[KBJ_ES_QVEL + i] = (float)qvel[i]; es[KBJ_ES_WARM + i] = (float)warm[i]; }
+  }
+
+  // physics randomisers + actuator / sensor per-episode draws (train.py:1097-1132,1158-1161,1191-1198,1780)
+  void randomize() {
+    uint32_t e = episode();
+    bool on = c->enable_randomizers != 0;
+    auto U = [&](uint32_t idx, double lo, double hi) { return on ? rng.uniform(KBJ_RNG_RANDOMIZE, e, idx, lo, hi) : 0.5 * (lo + hi); };
+    for (int b = 0; b < NB; ++b) {
+      double s = on ? U(140 + b, 1 - c->inertia_scale, 1 + c->inertia_scale) : 1.0;
+      ep[KBJ_EP_MASS + b] = (float)(m->body_mass[b] * s);
+      for (int k = 0; k < 3; ++k) {
+        ep[KBJ_EP_INERTIA + 3 * b + k] = (float)(m->body_inertia[b][k] * s);
+        ep[KBJ_EP_IPOS + 3 * b + k] = (float)(m->body_ipos[b][k] + (b && on ? U(60 + 3 * b + k, -c->com_jitter, c->com_jitter) : 0.0));
+      }
+    }
+    for (int d_ = 0; d_ < NV; ++d_) {
+      ep[KBJ_EP_FRICLOSS + d_] = (float)(m->dof_frictionloss[d_] * (on ? U(d_, c->fricloss_scale_lo, c->fricloss_scale_hi) : 1.0));
+      ep[KBJ_EP_ARMATURE + d_] = (float)(m->dof_armature[d_] * (on ? U(26 + d_, c->armature_scale_lo, c->armature_scale_hi) : 1.0));
+    }
+    for (int cp = 0; cp < NCAP; ++cp) {
+      ep[KBJ_EP_CAP_RAD + cp] = (float)(m->cap_radius[cp] * (on ? U(170 + cp, 1 - c->cap_radius_scale, 1 + c->cap_radius_scale) : 1.0));
+      ep[KBJ_EP_CAP_HALF + cp] = (float)(m->cap_halflen[cp] * (on ? U(174 + cp, 1 - c->cap_length_scale, 1 + c->cap_length_scale) : 1.0));
+      for (int k = 0; k < 3; ++k)
+        ep[KBJ_EP_CAP_POS + 3 * cp + k] = (float)(m->cap_pos[cp][k] + (on ? U(180 + 3 * cp + k, -c->cap_jitter[k], c->cap_jitter[k]) : 0.0));
+    }
+    // the capsules have priority 1 over the floor (robot.mjcf class "collision"), so MuJoCo takes the capsule's
+    // friction and the floor-friction randomiser (train.py:1112-1114) scales nothing; kept as a per-env field.
+    ep[KBJ_EP_MU] = m->contact_mu;
+    for (int u = 0; u < NU; ++u) {
+      ep[KBJ_EP_KP + u] = (float)(m->kp[u] * (on ? U(200 + u, 1.0 / c->kp_scale, c->kp_scale) : 1.0));
+      ep[KBJ_EP_KD + u] = (float)(m->kd[u] * (on ? U(220 + u, 1.0 / c->kd_scale, c->kd_scale) : 1.0));
+      ep[KBJ_EP_TAULIM + u] = (float)(m->tau_limit[u] * (on ? U(240 + u, c->torque_limit_scale_low, 1.0) : 1.0));
+      ep[KBJ_EP_ACTBIAS + u] = (float)(on ? U(260 + u, -c->action_bias_scale, c->action_bias_scale) : 0.0);
+      ep[KBJ_EP_JPBIAS + u] = (float)(c->enable_noise ? rng.uniform(KBJ_RNG_RANDOMIZE, e, 280 + u, -c->jpos_bias_range, c->jpos_bias_range) : 0.0);
+    }
+    for (int k = 0; k < 3; ++k) ep[KBJ_EP_PGBIAS + k] = (float)(c->enable_noise ? rng.uniform(KBJ_RNG_RANDOMIZE, e, 300 + k, -c->pg_bias, c->pg_bias) : 0.0);
+    ep[KBJ_EP_PGLAG] = (float)(c->enable_noise ? rng.uniform(KBJ_RNG_RANDOMIZE, e, 303, c->pg_lag_lo, c->pg_lag_hi) : 0.0);
+    double lat = rng.uniform(KBJ_RNG_RANDOMIZE, e, 304, c->latency_lo, c->latency_hi);
+    ep[KBJ_EP_LATENCY] = (float)std::floor(lat / c->dt + 0.5);
+    for (int k = KBJ_EP_MU + 1; k < KBJ_EP_SIZE; ++k) ep[k] = 0;
+  }
+
+  // UnifiedCommand.initial_command (train.py:724-766); `off` separates reset-time draws from switch draws
+  void sample_command(uint32_t a, uint32_t off, float* cmd) {
+    if (c->command_mode == 1) { for (int k = 0; k < KBJ_NCMD; ++k) cmd[k] = c->fixed_command[k]; return; }
+    auto U = [&](uint32_t idx, double lo, double hi) { return (float)rng.uniform(KBJ_RNG_COMMAND, a, off + idx, lo, hi); };
+    float vx = U(2, c->vx_lo, c->vx_hi), vy = U(3, c->vy_lo, c->vy_hi), wz = U(4, c->wz_lo, c->wz_hi);
+    float bh = U(5, c->bh_lo, c->bh_hi), rx = U(6, c->rx_lo, c->rx_hi), ry = U(7, c->ry_lo, c->ry_hi);
+    float arms[10];
+    for (int j = 0; j < 10; ++j) {
+      // uniform and bernoulli share one key in the reference (train.py:734-737): the same draw u decides both
+      double u = rng.uniform(KBJ_RNG_COMMAND, a, off + 8 + j);
+      double lo = m->dof_range[16 + j][0], hi = m->dof_range[16 + j][1];
+      arms[j] = u < 0.5 ? (float)(lo + (hi - lo) * u) : 0.0f;
+    }
+    uint32_t b0, b1; rng.bits(KBJ_RNG_COMMAND, a, off + 1, b0, b1);
+    int mode = (int)(b0 % 6u);
+    for (int k = 0; k < KBJ_NCMD; ++k) cmd[k] = 0;
+    switch (mode) {
+      case 0: cmd[0] = vx; break;
+      case 1: cmd[1] = vy; break;
+      case 2: cmd[2] = wz; break;
+      case 3: cmd[0] = vx; cmd[1] = vy; cmd[2] = wz; for (int j = 0; j < 10; ++j) cmd[6 + j] = arms[j]; break;
+      case 4: cmd[3] = bh; cmd[4] = rx; cmd[5] = ry; for (int j = 0; j < 10; ++j) cmd[6 + j] = arms[j]; break;
+      default: break;
+    }
+  }
+
+  // resets (train.py:1146-1153, 833-844) + per-episode re-initialisation
+  void reset() {
+    episode() += 1;
+    uint32_t e = episode();
+    randomize();
+    auto U = [&](uint32_t idx, double s) { return rng.uniform(KBJ_RNG_RESET, e, idx, -s, s); };
+    for (int k = 0; k < NQ; ++k) qpos[k] = m->qpos0[k];
+    for (int u = 0; u < NU; ++u) qpos[7 + u] = (R)(m->joint_bias[u] + U(u, c->reset_joint_pos_scale));
+    for (int i = 0; i < NV; ++i) { qvel[i] = 0; warm[i] = 0; }
+    for (int u = 0; u < NU; ++u) qvel[6 + u] = (R)U(20 + u, c->reset_joint_vel_scale);
+    qvel[0] = (R)U(40, c->reset_base_vel_xy_scale); qvel[1] = (R)U(41, c->reset_base_vel_xy_scale);
+    double yaw = U(42, 3.14159265358979323846);
+    qpos[3] = (R)std::cos(yaw / 2); qpos[4] = 0; qpos[5] = 0; qpos[6] = (R)std::sin(yaw / 2);
+    qpos[0] = (R)U(43, c->reset_xy_range); qpos[1] = (R)U(44, c->reset_xy_range);
+    for (int u = 0; u < NU; ++u) es[KBJ_ES_ACT_PREV + u] = m->joint_bias[u];
+    for (int k = 0; k < 6; ++k) es[KBJ_ES_PUSH + k] = 0;
+    es[KBJ_ES_PUSH_REM] = 0;
+    es[KBJ_ES_PUSH_NXT] = (float)std::floor(rng.uniform(KBJ_RNG_RANDOMIZE, e, 310, c->push_int_lo, c->push_int_hi) / c->ctrl_dt);
+    es[KBJ_ES_TIME] = 0;
+    sample_command(stepctr(), 32, es + KBJ_ES_CMD);
+    phy.p.load(ep);
+    R zero_ctrl[NU];
+    pd_torque(es + KBJ_ES_ACT_PREV, zero_ctrl);
+    phy.forward(qpos, qvel, zero_ctrl, nullptr, warm, d);  // derived quantities for the first observation
+    for (int u = 0; u < NU; ++u) last_ctrl[u] = zero_ctrl[u];
+    R pg[3]; projected_gravity(pg);
+    for (int k = 0; k < 3; ++k) es[KBJ_ES_PGLAG + k] = (float)pg[k];
+    store_state();
+  }
+
+  // PositionActuators (train.py:1097-1105): tau = kp (a + bias - q) - kd qdot, clipped to the randomised soft limit
+  void pd_torque(const float* action, R* tau) const {
+    for (int u = 0; u < NU; ++u) {
+      R t = phy.p.kp[u] * ((R)action[u] + phy.p.actbias[u] - qpos[7 + u]) - phy.p.kd[u] * qvel[6 + u];
+      tau[u] = std::min(std::max(t, -phy.p.taulim[u]), phy.p.taulim[u]);
+    }
+  }
+  void projected_gravity(R* pg) const {  // gravity direction in the imu frame
+    R g[3] = {0, 0, -1};
+    rotate_by_quat(g, d.imu_quat, true, pg);
+  }
+
+  // obs packing (train.py:1329-1433) from the derived data of the last forward pass
+  void write_obs(float* actor, float* critic, float* aux) {
+    uint32_t st = stepctr();
+    bool noise = c->enable_noise != 0;
+    R pg[3]; projected_gravity(pg);
+    R lag = phy.p.pglag, pgl[3], pgn[3];
+    for (int k = 0; k < 3; ++k) {
+      pgl[k] = lag * (R)es[KBJ_ES_PGLAG + k] + (1 - lag) * pg[k];
+      es[KBJ_ES_PGLAG + k] = (float)pgl[k];
+      pgn[k] = pgl[k] + phy.p.pgbias[k] + (noise ? (R)c->pg_noise_std * rng.normal<R>(KBJ_RNG_OBS_NOISE, st, 43 + k) : 0);
+    }
+    auto enc_pg = [](const R* g, float* o) {  // train.py:1338-1349
+      R roll = std::atan2(g[1], -g[2]), pitch = std::atan2(-g[0], std::sqrt(g[1] * g[1] + g[2] * g[2]));
+      R n = std::sqrt(g[0] * g[0] + g[1] * g[1] + g[2] * g[2]);
+      o[0] = (float)roll; o[1] = (float)pitch; o[2] = (float)(g[0] / n); o[3] = (float)(g[1] / n); o[4] = (float)(g[2] / n);
+    };
+    const float* cmd = es + KBJ_ES_CMD;
+    float zc = std::sqrt(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]) < 1e-3f ? 1.0f : 0.0f;
+    for (int u = 0; u < NU; ++u) {
+      R range = std::max((R)m->joint_bias[u] - (R)m->joint_lo[u], (R)m->joint_hi[u] - (R)m->joint_bias[u]);
+      R q = qpos[7 + u], v = qvel[6 + u];
+      R qn = q + phy.p.jpbias[u] + (noise ? (R)rng.uniform(KBJ_RNG_OBS_NOISE, st, u, -c->jpos_noise, c->jpos_noise) : 0);
+      R vn = v + (noise ? (R)rng.uniform(KBJ_RNG_OBS_NOISE, st, 20 + u, -c->jvel_noise, c->jvel_noise) : 0);
+      actor[u] = (float)((qn - (R)m->joint_bias[u]) / range); actor[20 + u] = (float)(vn / 10);
+      critic[u] = (float)((q - (R)m->joint_bias[u]) / range); critic[20 + u] = (float)(v / 10);
+    }
+    enc_pg(pgn, actor + 40); enc_pg(pg, critic + 40);
+    for (int k = 0; k < 3; ++k) {
+      actor[45 + k] = (float)(d.gyro[k] + (noise ? (R)c->gyro_noise_std * rng.normal<R>(KBJ_RNG_OBS_NOISE, st, 40 + k) : 0));
+      critic[45 + k] = (float)d.gyro[k];
+    }
+    actor[48] = zc; critic[48] = zc;
+    for (int k = 0; k < KBJ_NCMD; ++k) { actor[49 + k] = cmd[k]; critic[49 + k] = cmd[k]; }
+    for (int k = KBJ_NOBS_ACTOR; k < KBJ_LD_ACTOR; ++k) actor[k] = 0;
+    // privileged block (train.py:1417-1428)
+    critic[65] = (float)d.touch[0]; critic[66] = (float)d.touch[1];
+    {  // FeetPositionObservation (train.py:682-699)
+      int bb = m->base_body;
+      R e[3]; quat_to_euler(d.xquat[bb], e);
+      R ye[3] = {0, 0, e[2]}, yq[4]; euler_to_quat(ye, yq);
+      int feet[2] = {m->lfoot_body, m->rfoot_body};
+      for (int f = 0; f < 2; ++f) {
+        R rel[3] = {d.xpos[feet[f]][0] - d.xpos[bb][0], d.xpos[feet[f]][1] - d.xpos[bb][1], d.xpos[feet[f]][2] - d.xpos[bb][2]}, o[3];
+        rotate_by_quat(rel, yq, true, o);
+        for (int k = 0; k < 3; ++k) critic[67 + 3 * f + k] = (float)o[k];
+      }
+    }
+    for (int k = 0; k < 3; ++k) critic[73 + k] = (float)qpos[k];
+    for (int k = 0; k < 4; ++k) critic[76 + k] = (float)qpos[3 + k];
+    for (int b = 1; b < NB; ++b) for (int k = 0; k < 10; ++k) critic[80 + 10 * (b - 1) + k] = (float)d.cinert[b][k];
+    for (int b = 1; b < NB; ++b) for (int k = 0; k < 6; ++k) critic[310 + 6 * (b - 1) + k] = (float)d.cvel[b][k];
+    for (int k = 0; k < 3; ++k) { critic[448 + k] = (float)qvel[k]; critic[451 + k] = (float)qvel[3 + k]; }
+    for (int u = 0; u < NU; ++u) critic[454 + u] = (float)(d.qfrc_actuator[6 + u] / 4);
+    critic[474] = (float)d.xpos[1][2];  // BaseHeightObservation (train.py:706-707)
+    for (int k = KBJ_NOBS_CRITIC; k < KBJ_LD_CRITIC; ++k) critic[k] = 0;
+    // the pre-step observation fields the reward stack reads
+    aux[KBJ_AUX_TOUCH] = (float)d.touch[0]; aux[KBJ_AUX_TOUCH + 1] = (float)d.touch[1];
+    aux[KBJ_AUX_COMDIST] = (float)com_distance<R>(d.con_pos, d.subtree_com[2]);
+    for (int k = 0; k < KBJ_NCMD; ++k) aux[KBJ_AUX_CMD + k] = cmd[k];
+  }
+
+  // one control step: action latency/drop, push event, 5 physics substeps, termination, reset / command update,
+  // next observation. `aux_t` is the record of this step, `*_next` the rows of step t+1.
+  void step(const float* action, float* aux_t, float* actor_next, float* critic_next, float* aux_next) {
+    load_state();
+    uint32_t st = stepctr();
+    // the derived data of the previous forward pass is not persisted: observations were written at the end of the
+    // previous step, so nothing here needs it before the first substep recomputes it.
+    float a_eff[NU];
+    bool drop = rng.uniform(KBJ_RNG_DROP, st, 0) < c->drop_action_prob;
+    for (int u = 0; u < NU; ++u) a_eff[u] = drop ? es[KBJ_ES_ACT_PREV + u] : action[u];
+    // ForcePushEvent (train.py:1134-1144)
+    R push[6] = {0, 0, 0, 0, 0, 0};
+    bool pushing = false;
+    if (c->enable_pushes) {
+      if (es[KBJ_ES_PUSH_REM] > 0) { es[KBJ_ES_PUSH_REM] -= 1; pushing = true; }
+      else if (es[KBJ_ES_PUSH_NXT] <= 0) {
+        for (int k = 0; k < 3; ++k) {
+          es[KBJ_ES_PUSH + k] = (float)rng.uniform(KBJ_RNG_PUSH, st, k, -c->push_max_force, c->push_max_force);
+          es[KBJ_ES_PUSH + 3 + k] = (float)rng.uniform(KBJ_RNG_PUSH, st, 3 + k, -c->push_max_torque, c->push_max_torque);
+        }
+        es[KBJ_ES_PUSH_REM] = (float)std::floor(rng.uniform(KBJ_RNG_PUSH, st, 6, c->push_dur_lo, c->push_dur_hi) / c->ctrl_dt);
+        es[KBJ_ES_PUSH_NXT] = (float)std::floor(rng.uniform(KBJ_RNG_PUSH, st, 7, c->push_int_lo, c->push_int_hi) / c->ctrl_dt);
+        pushing = true;
+      } else es[KBJ_ES_PUSH_NXT] -= 1;
+      if (pushing) for (int k = 0; k < 6; ++k) push[k] = es[KBJ_ES_PUSH + k];
+    }
+    int lat = phy.p.latency;
+    for (int s = 0; s < c->substeps; ++s) {
+      const float* a = s >= lat ? a_eff : es + KBJ_ES_ACT_PREV;
+      pd_torque(a, last_ctrl);
+      phy.forward(qpos, qvel, last_ctrl, pushing ? push : nullptr, warm, d);
+      phy.integrate(qpos, qvel, d);
+      for (int i = 0; i < NV; ++i) warm[i] = d.qacc[i];
+    }
+    for (int u = 0; u < NU; ++u) es[KBJ_ES_ACT_PREV + u] = a_eff[u];
+    es[KBJ_ES_TIME] += 1;
+    stepctr() = st + 1;
+    // terminations (train.py:817-823, 1267-1268)
+    int bb = m->base_body, lf = m->lfoot_body, rf = m->rfoot_body;
+    R height = d.xpos[bb][2] - std::min(d.xpos[lf][2], d.xpos[rf][2]);
+    R zz = 1 - 2 * (qpos[4] * qpos[4] + qpos[5] * qpos[5]);  // world z component of the base z axis
+    int done = 0;
+    if (es[KBJ_ES_TIME] >= (float)c->max_episode_steps) done = 1;
+    if (height < (R)c->unhealthy_z || zz < std::cos((R)c->max_tilt_rad)) done = -1;
+    // reward inputs of this step (state after the step; derived fields from the last substep's forward pass)
+    for (int k = 0; k < 6; ++k) aux_t[KBJ_AUX_QVEL + k] = (float)qvel[k];
+    for (int k = 0; k < 4; ++k) { aux_t[KBJ_AUX_BQUAT + k] = (float)d.xquat[bb][k]; aux_t[KBJ_AUX_LFQUAT + k] = (float)d.xquat[lf][k]; aux_t[KBJ_AUX_RFQUAT + k] = (float)d.xquat[rf][k]; }
+    aux_t[KBJ_AUX_BASEZ] = (float)d.xpos[bb][2]; aux_t[KBJ_AUX_LFZ] = (float)d.xpos[lf][2]; aux_t[KBJ_AUX_RFZ] = (float)d.xpos[rf][2];
+    for (int j = 0; j < 10; ++j) aux_t[KBJ_AUX_ARMQ + j] = (float)qpos[17 + j];
+    for (int u = 0; u < NU; ++u) aux_t[KBJ_AUX_CTRL + u] = (float)last_ctrl[u];
+    aux_t[KBJ_AUX_DONE] = (float)done;
+    aux_t[KBJ_AUX_DONE + 1] = 0;
+    if (done) reset();
+    else {
+      // UnifiedCommand.__call__ (train.py:768-785)
+      if (c->command_mode == 0 && rng.uniform(KBJ_RNG_COMMAND, st + 1, 0) < c->switch_prob) sample_command(st + 1, 0, es + KBJ_ES_CMD);
+      store_state();
+    }
+    write_obs(actor_next, critic_next, aux_next);
+  }
+};
+
+// ---- reward stack (train.py:125-506; weights train.py:1225-1256) over one env's trajectory ----
+// aux: [T][stride] rows of KBJ_AUX_*; carry: KBJ_RC_*; out: reward[T], components[T][12] (unscaled terms)
+template <class R> void rewards_scan(const kbj_model* m, const kbj_config* c, const float* aux, size_t stride, int T, float* carry,
+                                     float* reward, size_t rstride, float* comps, size_t cstride) {
+  static const R scales[KBJ_NREW] = {(R)0.2, (R)0.1, (R)0.2, (R)0.2, (R)0.2, (R)0.1, (R)0.1, (R)1.5, (R)0.1, (R)0.05, (R)0.1, (R)0.1};
+  const R ctrl_dt = c->ctrl_dt;
+  for (int t = 0; t < T; ++t) {
+    const float* a = aux + (size_t)t * stride;
+    R r[KBJ_NREW];
+    const float* cmd = a + KBJ_AUX_CMD;
+    bool zc = std::sqrt((R)cmd[0] * cmd[0] + (R)cmd[1] * cmd[1] + (R)cmd[2] * cmd[2]) < (R)1e-3;
+    bool done = a[KBJ_AUX_DONE] != 0;
+    R bq[4] = {a[KBJ_AUX_BQUAT], a[KBJ_AUX_BQUAT + 1], a[KBJ_AUX_BQUAT + 2], a[KBJ_AUX_BQUAT + 3]}, be[3];
+    quat_to_euler(bq, be);
+    {  // linvel (train.py:274-292)
+      R ye[3] = {0, 0, be[2]}, yq[4], v[3] = {cmd[0], cmd[1], 0}, g[3];
+      euler_to_quat(ye, yq); rotate_by_quat(v, yq, false, g);
+      R ex = (R)a[KBJ_AUX_QVEL] - g[0], ey = (R)a[KBJ_AUX_QVEL + 1] - g[1], err = std::sqrt(ex * ex + ey * ey);
+      r[KBJ_REW_LINVEL] = std::exp(-(zc ? err : err * err) / (R)0.2);
+    }
+    r[KBJ_REW_ANGVEL] = std::exp(-std::fabs((R)a[KBJ_AUX_QVEL + 5] - (R)cmd[2]) / (R)0.2);  // train.py:301-306
+    {  // roll_pitch (train.py:316-334)
+      R e1[3] = {be[0], be[1], 0}, q1[4], e2[3] = {cmd[4], cmd[5], 0}, q2[4];
+      euler_to_quat(e1, q1); euler_to_quat(e2, q2);
+      R dt_ = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
+      r[KBJ_REW_ROLL_PITCH] = std::exp(-(1 - dt_ * dt_) / (zc ? (R)0.01 : (R)0.03));
+    }
+    {  // base_height (train.py:377-388)
+      R low = std::min((R)a[KBJ_AUX_LFZ] - (R)0.06, (R)a[KBJ_AUX_RFZ] - (R)0.06);
+      R h = (R)a[KBJ_AUX_BASEZ] - low;
+      r[KBJ_REW_BASE_HEIGHT] = std::exp(-std::fabs(h - ((R)cmd[3] + (R)0.80)) / (R)0.02);
+    }
+    {  // arm_pos (train.py:261-265); xax.get_norm(.,"l2") is the elementwise square
+      R e = 0;
+      for (int j = 0; j < 10; ++j) { R dq = (R)a[KBJ_AUX_ARMQ + j] - ((R)cmd[6 + j] + (R)m->joint_bias[10 + j]); e += dq * dq; }
+      r[KBJ_REW_ARM_POS] = std::exp(-e / (R)0.1);
+    }
+    bool cl = a[KBJ_AUX_TOUCH] > 0.1f, cr = a[KBJ_AUX_TOUCH + 1] > 0.1f;
+    {  // single_contact (train.py:138-154), grace period 2.0 s
+      R ts = (cl != cr) ? 0 : (R)carry[KBJ_RC_TSINGLE] + ctrl_dt;
+      if (zc) ts = 2.0;
+      carry[KBJ_RC_TSINGLE] = (float)ts;
+      r[KBJ_REW_SINGLE_CONTACT] = zc ? 1 : (ts < (R)2.0 ? 1 : 0);
+    }
+    r[KBJ_REW_NO_CONTACT] = zc ? 0 : ((cl || cr) ? 0 : 1);  // train.py:161-165
+    {  // feet_airtime (train.py:197-213)
+      bool con[2] = {cl, cr};
+      R rew = 0;
+      for (int f = 0; f < 2; ++f) {
+        R prev_air = carry[KBJ_RC_AIRTIME + f];
+        bool prev_con = carry[KBJ_RC_CONTACT + f] != 0;
+        bool first = con[f] && !prev_con && !done;
+        rew += (prev_air - (R)0.4) * (first ? 1 : 0);
+        carry[KBJ_RC_AIRTIME + f] = (con[f] || done) ? 0.0f : (float)(prev_air + ctrl_dt);
+        carry[KBJ_RC_CONTACT + f] = con[f] ? 1.0f : 0.0f;
+      }
+      r[KBJ_REW_FEET_AIRTIME] = zc ? 0 : rew;
+    }
+    {  // feet_orient (train.py:418-457)
+      R rpy = 0, rp = 0;
+      for (int f = 0; f < 2; ++f) {
+        const float* fq_ = a + (f ? KBJ_AUX_RFQUAT : KBJ_AUX_LFQUAT);
+        R fq[4] = {fq_[0], fq_[1], fq_[2], fq_[3]};
+        R te[3] = {f ? (R)1.5707963267948966 : (R)-1.5707963267948966, 0, be[2] - (R)3.141592653589793}, tq[4];
+        euler_to_quat(te, tq);
+        R d1 = tq[0] * fq[0] + tq[1] * fq[1] + tq[2] * fq[2] + tq[3] * fq[3];
+        rpy += 1 - d1 * d1;
+        R fe[3]; quat_to_euler(fq, fe); fe[2] = 0;
+        R fq0[4]; euler_to_quat(fe, fq0);
+        te[2] = 0; euler_to_quat(te, tq);
+        R d2 = tq[0] * fq0[0] + tq[1] * fq0[1] + tq[2] * fq0[2] + tq[3] * fq0[3];
+        rp += 1 - d2 * d2;
+      }
+      r[KBJ_REW_FEET_ORIENT] = std::exp(-(std::fabs((R)cmd[2]) > (R)1e-3 ? rp : rpy) / (R)0.02);
+    }
+    {  // com_distance (train.py:466-478)
+      R cd = a[KBJ_AUX_COMDIST];
+      r[KBJ_REW_COM_DISTANCE] = (cd >= 0 && zc) ? std::exp(-cd / (R)0.04) : 0;
+    }
+    {  // base_accel (train.py:487-494): velocity edge-padded at t = 0, difference zeroed after a done
+      R e = 0;
+      if (t > 0) {
+        const float* pa = aux + (size_t)(t - 1) * stride;
+        if (pa[KBJ_AUX_DONE] == 0) for (int k = 0; k < 6; ++k) e += std::fabs((R)a[KBJ_AUX_QVEL + k] - (R)pa[KBJ_AUX_QVEL + k]);
+      }
+      r[KBJ_REW_BASE_ACCEL] = std::exp(-e / (R)5.0);
+    }
+    {  // torque (train.py:503-506)
+      R s = 0;
+      for (int u = 0; u < NU; ++u) s += std::exp(-std::fabs((R)a[KBJ_AUX_CTRL + u]) / (R)5.0);
+      r[KBJ_REW_TORQUE] = zc ? s / NU : 1;
+    }
+    R tot = 0;
+    for (int k = 0; k < KBJ_NREW; ++k) { tot += scales[k] * r[k]; if (comps) comps[(size_t)t * cstride + k] = (float)r[k]; }
+    reward[(size_t)t * rstride] = (float)tot;
+  }
+}
+
+}  // namespace kbjo
