@@ -165,7 +165,7 @@ def test_static_weight_on_feet(model, quiet_cfg):
     weight = model.total_mass * 9.81
     # the open-loop neutral pose stands still for ~0.3 s after the landing transient (then slowly tips over)
     assert abs(np.mean(tot[20:30]) - weight) < 0.03 * weight
-    assert abs(o.es[0, L.ES["QVEL"]:L.ES["QVEL"] + 3]).max() < 0.1
+    assert abs(o.es[0, L.ES["QVEL"] + 2]) < 0.05        # vertical velocity
 
 
 def test_fp32_matches_fp64_one_step(model, quiet_cfg):
