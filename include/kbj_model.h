@@ -105,7 +105,8 @@ typedef struct kbj_config {
   int32_t enable_pushes;
   int32_t enable_noise;
   int32_t max_episode_steps; /* 12 s / 0.02 s = 600 */
-  int32_t reserved_i[5];
+  int32_t solver_newton;     /* 1 = Newton direction (default), 0 = Polak-Ribiere CG */
+  int32_t reserved_i[4];
   float dt;                  /* 0.004 */
   float ctrl_dt;             /* 0.02  */
   float solver_tolerance;    /* 1e-8 */

@@ -45,7 +45,7 @@ class Config(C.Structure):
         ("num_envs", i32), ("env_id_offset", i32), ("rollout_len", i32), ("substeps", i32),
         ("solver_iterations", i32), ("ls_iterations", i32), ("hidden_size", i32), ("depth", i32),
         ("batch_size", i32), ("num_passes", i32), ("command_mode", i32), ("enable_randomizers", i32),
-        ("enable_pushes", i32), ("enable_noise", i32), ("max_episode_steps", i32), ("reserved_i", i32 * 5),
+        ("enable_pushes", i32), ("enable_noise", i32), ("max_episode_steps", i32), ("solver_newton", i32), ("reserved_i", i32 * 4),
         ("dt", f32), ("ctrl_dt", f32), ("solver_tolerance", f32), ("latency_lo", f32), ("latency_hi", f32),
         ("drop_action_prob", f32), ("fixed_command", f32 * NCMD),
         ("vx_lo", f32), ("vx_hi", f32), ("vy_lo", f32), ("vy_hi", f32), ("wz_lo", f32), ("wz_hi", f32),
@@ -92,8 +92,9 @@ def default_config(**overrides) -> Config:
     c.solver_iterations, c.ls_iterations = 8, 8                                   # train.py:1777-1778
     c.hidden_size, c.depth, c.batch_size, c.num_passes = 256, 2, 512, 3           # train.py:1773,82-85,1764-1765
     c.command_mode, c.enable_randomizers, c.enable_pushes, c.enable_noise = 0, 1, 1, 1
+    c.solver_newton = 1
     c.max_episode_steps = 600                                                     # 12 s, train.py:1268
-    c.dt, c.ctrl_dt, c.solver_tolerance = 0.004, 0.02, 1e-8
+    c.dt, c.ctrl_dt, c.solver_tolerance = 0.004, 0.02, 1e-6   # fp32 gradient noise floor sits above MuJoCo's 1e-8
     c.latency_lo, c.latency_hi, c.drop_action_prob = 0.003, 0.01, 0.05            # train.py:1780-1781
     c.vx_lo, c.vx_hi, c.vy_lo, c.vy_hi, c.wz_lo, c.wz_hi = -0.5, 1.2, -0.5, 0.5, -1.0, 1.0   # train.py:1212-1214
     c.bh_lo, c.bh_hi, c.rx_lo, c.rx_hi, c.ry_lo, c.ry_hi = -0.25, 0.05, -0.25, 0.25, -0.25, 0.25

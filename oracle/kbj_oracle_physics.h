@@ -117,7 +117,7 @@ template <class R> struct Derived {
   int solver_iters;
 };
 
-struct SolverOpts { int iterations = 8, ls_iterations = 8; double tolerance = 1e-8; };
+struct SolverOpts { int iterations = 8, ls_iterations = 8; double tolerance = 1e-8; int newton = 1; };
 
 template <class R> struct Physics {
   const kbj_model* m;
@@ -464,7 +464,30 @@ template <class R> struct Physics {
       solve_M(d, grad, Mgrad);
       R gg = 0; for (int i = 0; i < NV; ++i) gg += grad[i] * grad[i];
       if (scale * std::sqrt(gg) < (R)opt.tolerance) break;
-      if (it == 0) { for (int i = 0; i < NV; ++i) search[i] = -Mgrad[i]; }
+      if (opt.newton) {
+        // Newton direction: H = M + sum over rows in their quadratic zone of D J^T J (dense Cholesky)
+        static thread_local R H[NV][NV], Lh[NV][NV];
+        for (int i = 0; i < NV; ++i) for (int j = 0; j < NV; ++j) H[i][j] = d.M[i][j];
+        for (int r = 0; r < NEFC; ++r) {
+          if (!d.efc_active[r]) continue;
+          bool quad = r < ROW_LIM ? std::fabs(jar[r]) < d.efc_R[r] * d.efc_floss[r] : jar[r] < 0;
+          if (!quad) continue;
+          for (int i = 0; i < NV; ++i) {
+            if (d.efc_J[r][i] == 0) continue;
+            R s = d.efc_D[r] * d.efc_J[r][i];
+            for (int j = 0; j < NV; ++j) H[i][j] += s * d.efc_J[r][j];
+          }
+        }
+        for (int i = 0; i < NV; ++i)
+          for (int j = 0; j <= i; ++j) {
+            R s = H[i][j];
+            for (int k = 0; k < j; ++k) s -= Lh[i][k] * Lh[j][k];
+            Lh[i][j] = (i == j) ? std::sqrt(s) : s / Lh[j][j];
+          }
+        R y[NV];
+        for (int i = 0; i < NV; ++i) { R s = -grad[i]; for (int k = 0; k < i; ++k) s -= Lh[i][k] * y[k]; y[i] = s / Lh[i][i]; }
+        for (int i = NV - 1; i >= 0; --i) { R s = y[i]; for (int k = i + 1; k < NV; ++k) s -= Lh[k][i] * search[k]; search[i] = s / Lh[i][i]; }
+      } else if (it == 0) { for (int i = 0; i < NV; ++i) search[i] = -Mgrad[i]; }
       else {
         R num = 0, den = 0;
         for (int i = 0; i < NV; ++i) { num += grad[i] * (Mgrad[i] - Mgrad_old[i]); den += grad_old[i] * Mgrad_old[i]; }

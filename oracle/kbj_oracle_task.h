@@ -114,7 +114,7 @@ template <class R> struct Env {
 
   void bind(const kbj_model* m_, const kbj_config* c_, uint32_t seed, int env_gid, float* ep_, float* es_) {
     m = m_; c = c_; rng.seed = seed; rng.env = (uint32_t)env_gid; ep = ep_; es = es_;
-    phy.m = m; phy.dt = c->dt; phy.opt.iterations = c->solver_iterations; phy.opt.ls_iterations = c->ls_iterations; phy.opt.tolerance = c->solver_tolerance;
+    phy.m = m; phy.dt = c->dt; phy.opt.iterations = c->solver_iterations; phy.opt.ls_iterations = c->ls_iterations; phy.opt.tolerance = c->solver_tolerance; phy.opt.newton = c->solver_newton;
   }
   uint32_t& episode() { return *reinterpret_cast<uint32_t*>(es + KBJ_ES_EPISODE); }
   uint32_t& stepctr() { return *reinterpret_cast<uint32_t*>(es + KBJ_ES_STEP); }
