@@ -1,0 +1,130 @@
+/* kbj.h — C ABI of the MI355X-native K-Bot joystick hot path (rollout + PPO update).
+ *
+ * The reference has no FFI: its boundary is ksim's Python Task API (a `ksim.PPOTask` subclass,
+ * train.py:1058) whose engine, rollout loop and PPO update run as jitted JAX programs. This
+ * library is what a ksim-style host would bind instead of those programs; every entry point
+ * cites the reference interface it replaces. The Python host layer
+ * (kbot-joystick_amd/host) binds it with ctypes and re-exposes the Task API names.
+ *
+ * Conventions
+ *  - All functions return 0 on success, <0 on error; kbj_last_error() gives the message.
+ *    No exceptions cross the ABI, no torch types appear in signatures.
+ *  - One kbj_ctx per (process, GPU). Not thread-safe; distinct contexts may be driven from
+ *    distinct host threads. Work is enqueued on the hipStream_t given to kbj_create and is
+ *    asynchronous unless stated otherwise.
+ *  - Pointers named *_d are DEVICE pointers owned by the caller (e.g. torch tensor data_ptr());
+ *    the library never frees caller memory. Pointers named *_h are host pointers.
+ *  - Trajectory arrays are time-major, row-major: [T][N][dim] with dims/strides from kbj_model.h.
+ *  - Multi-GPU: the library only produces/consumes flat fp32 buffers; the RCCL communicator is
+ *    owned by the host (torch.distributed).
+ */
+#ifndef KBJ_H
+#define KBJ_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "kbj_model.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kbj_ctx kbj_ctx;
+
+/* ---- lifetime ---------------------------------------------------------------------------- */
+/* replaces: HumanoidWalkingTask.launch(config) set-up — get_mujoco_model / metadata / mjx.put_model
+ * (train.py:1079-1089, 1760-1792). model_blob is a kbj_model produced by the spec compiler. */
+int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const kbj_config* cfg, int device, void* hip_stream);
+int kbj_destroy(kbj_ctx* ctx);
+const char* kbj_last_error(const kbj_ctx* ctx); /* ctx may be NULL: error of a failed kbj_create */
+int kbj_sizeof_model(void);
+int kbj_sizeof_config(void);
+int kbj_synchronize(kbj_ctx* ctx);
+
+/* ---- environment (physics + task), SURVEY §8 rows a1-a3, a14-a22 -------------------------- */
+/* replaces: ksim reset path — get_resets / get_physics_randomizers / initial commands and the first
+ * get_observations call (train.py:1107-1132, 1146-1204, 724-766). Writes observation row 0. */
+int kbj_env_reset_all(kbj_ctx* ctx, uint32_t seed, float* actor0_d, float* critic0_d, float* aux0_d);
+/* replaces: one ksim engine control step = action latency/drop + ctrl_dt/dt x (PositionActuators.get_ctrl,
+ * ForcePushEvent, mjx.step) + terminations + reset + command update + next observations
+ * (train.py:1091-1105, 1134-1144, 1155-1222, 1258-1269, 1775-1781).
+ * action_d [N][20]; aux_t_d [N][72] row of this step (completed); *_next_d rows of step t+1. */
+int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d, float* aux_next_d);
+/* state save/restore (checkpointing, tests): ep [N][KBJ_EP_SIZE], es [N][KBJ_ES_SIZE]; synchronous */
+int kbj_env_get_state(kbj_ctx* ctx, float* ep_h, float* es_h);
+int kbj_env_set_state(kbj_ctx* ctx, const float* ep_h, const float* es_h);
+
+/* ---- rewards, row a23 --------------------------------------------------------------------- */
+/* replaces: get_rewards() stack evaluated over the trajectory (train.py:125-506, 1224-1256).
+ * aux_d [T][N][72] -> reward_d [T][N] (sum of scale*term), comps_d [T][N][12] unscaled terms or NULL.
+ * The StatefulReward carries persist inside the context across calls. */
+int kbj_rewards(kbj_ctx* ctx, const float* aux_d, int T, float* reward_d, float* comps_d);
+
+/* ---- actor-critic, rows a4-a11 ------------------------------------------------------------- */
+/* Flat parameter vector layout (floats), equinox leaf order of Model(actor, critic)
+ * (train.py:847-1046; convert.py:44-46):
+ *   actor : input_proj.weight [H][65], input_proj.bias [H],
+ *           rnns[l].weight_ih [4H][H], rnns[l].weight_hh [4H][H], rnns[l].bias [4H]   (l = 0..depth-1)
+ *           output_proj.weight [40][H], output_proj.bias [40]
+ *   critic: input_proj.weight [H][475], input_proj.bias [H], rnns[l]..., output_proj.weight [1][H], output_proj.bias [1]
+ */
+size_t kbj_param_count(const kbj_config* cfg);
+size_t kbj_actor_param_count(const kbj_config* cfg);
+/* replaces: get_model(InitParams(key)) (train.py:1278-1327): U(+-1/sqrt(fan_in)) init from a threefry stream */
+int kbj_init_params(kbj_ctx* ctx, uint32_t seed, float* params_d);
+
+/* Model carry (train.py:1049-1055, 1526-1543), device arrays owned by the caller:
+ *   actor_hc_d / critic_hc_d [depth][2][N][H] (h then c per layer), lpf_d [N][20] */
+typedef struct kbj_carry {
+  float* actor_hc_d;
+  float* critic_hc_d;
+  float* lpf_d;
+} kbj_carry;
+
+/* replaces: sample_action() (train.py:1545-1572) for all envs at one control step, fused with what the
+ * on-policy get_ppo_variables() pass would recompute for this step (log-prob, value; train.py:1435-1508):
+ *   actor_obs_d [N][68], critic_obs_d [N][476] -> action_d [N][20], logp_d [N], value_d [N]; carry updated in place.
+ * step_index seeds the Gaussian draw (RNG stream KBJ_RNG_ACTION); argmax!=0 returns the mode (train.py:1564). */
+int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_d, const float* critic_obs_d, kbj_carry* carry,
+                    uint32_t seed, uint32_t step_index, int argmax, float* action_d, float* logp_d, float* value_d);
+/* carry <- initial carry where done (train.py:1502-1506): done_d [N] float (aux KBJ_AUX_DONE column, stride in floats) */
+int kbj_carry_reset(kbj_ctx* ctx, kbj_carry* carry, const float* done_d, int done_stride);
+
+/* ---- rollout, §3.2 ------------------------------------------------------------------------- */
+typedef struct kbj_traj {
+  int32_t T, N;
+  float* actor_obs_d;  /* [T+1][N][68]  row T = observation after the last step (row 0 of the next rollout) */
+  float* critic_obs_d; /* [T+1][N][476] */
+  float* aux_d;        /* [T+1][N][72]  */
+  float* action_d;     /* [T][N][20] */
+  float* logp_d;       /* [T][N] on-policy log-prob  */
+  float* value_d;      /* [T][N] on-policy value     */
+  float* reward_d;     /* [T][N] */
+  float* carry0_actor_hc_d;  /* [depth][2][N][H] carry at the start of the trajectory (BPTT initial state) */
+  float* carry0_critic_hc_d;
+  float* carry0_lpf_d;       /* [N][20] */
+} kbj_traj;
+/* replaces: ksim's jitted rollout scan (vmap over envs, scan over T). Copies observation row T to row 0,
+ * snapshots the carry, then T x (policy_step, env_step, carry_reset), then rewards. */
+int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t seed, uint32_t first_step_index, kbj_traj* traj);
+
+/* ---- PPO update, rows a9, a12, a13 ---------------------------------------------------------- */
+/* replaces: ksim GAE (gamma, lam: train.py:1769-1770). done from aux; adv_d/target_d [T][N] */
+int kbj_gae(kbj_ctx* ctx, const kbj_traj* traj, float* adv_d, float* target_d);
+/* replaces: the loss/grad of one minibatch: get_ppo_variables under grad (BPTT through T LSTM steps,
+ * train.py:1435-1524) + ksim's clipped PPO loss. env_idx_d [B] int32 env indices of the minibatch.
+ * grad_d [P] flat gradient (overwritten), metrics_d [8]: loss, policy, value, entropy, clipfrac, kl, adv_mean, adv_std */
+int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* traj, const int32_t* env_idx_d, int B, const float* adv_d,
+                 const float* target_d, float* grad_d, float* metrics_d);
+/* replaces: optax.adamw + global-norm clip (train.py:1059-1077). step is 1-based. grad_scale multiplies the
+ * gradient first (1/world_size after an all-reduce sum). */
+int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const float* grad_d, int64_t step, float grad_scale);
+
+/* per-launch timing of the dominant kernels, measured with HIP events on the context's stream (bench.py roofline) */
+int kbj_profile_begin(kbj_ctx* ctx);
+int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, float* nn_ms, int* nn_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KBJ_H */

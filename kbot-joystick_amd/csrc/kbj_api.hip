@@ -1,0 +1,119 @@
+// kbj_api.hip — context lifetime and the rollout driver of libkbj.so (C ABI in include/kbj.h).
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include "kbj_ctx.h"
+
+thread_local std::string kbj_global_error;
+
+namespace {
+
+// the HIP kernels are specialised on the kbot tree (kbj_env_core.h body_parent / dof_parent / dof_body)
+bool topology_ok(const kbj_model& m, std::string& why) {
+  if (m.magic != KBJ_MAGIC || m.version != KBJ_VERSION) { why = "bad magic/version"; return false; }
+  if (m.nbody != KBJ_NBODY || m.nq != KBJ_NQ || m.nv != KBJ_NV || m.nu != KBJ_NU || m.ncap != KBJ_NCAP) { why = "unexpected sizes"; return false; }
+  for (int b = 0; b < KBJ_NBODY; ++b) {
+    int par = b <= 1 ? 0 : (b == 2 ? 1 : ((b - 3) % 5 == 0 ? 2 : b - 1));
+    int num = b == 1 ? 6 : ((b >= 3 && b <= 22) ? 1 : 0);
+    int adr = b == 1 ? 0 : ((b >= 3 && b <= 22) ? b + 3 : -1);
+    if (m.body_parent[b] != par || m.body_dofnum[b] != num || m.body_dofadr[b] != adr) { why = "body tree differs from the kbot topology"; return false; }
+  }
+  for (int d = 0; d < KBJ_NV; ++d) {
+    int body = d < 6 ? 1 : d - 3;
+    int par = d == 0 ? -1 : (d < 6 ? d - 1 : ((d - 6) % 5 == 0 ? 5 : d - 1));
+    if (m.dof_body[d] != body || m.dof_parent[d] != par) { why = "dof tree differs from the kbot topology"; return false; }
+  }
+  const int cap_body[4] = {7, 7, 12, 12};
+  for (int c = 0; c < 4; ++c) if (m.cap_body[c] != cap_body[c]) { why = "collision capsules must sit on the foot bodies 7 and 12"; return false; }
+  if (m.base_body != 1 || m.torso_body != 2 || m.lfoot_body != 7 || m.rfoot_body != 12 || m.imu_body != 23) { why = "unexpected named body ids"; return false; }
+  return true;
+}
+
+}  // namespace
+
+int kbj_nn_create(kbj_ctx* ctx);   // kbj_nn.hip
+void kbj_nn_destroy(kbj_ctx* ctx);
+
+extern "C" {
+
+int kbj_sizeof_model(void) { return (int)sizeof(kbj_model); }
+int kbj_sizeof_config(void) { return (int)sizeof(kbj_config); }
+
+const char* kbj_last_error(const kbj_ctx* ctx) { return ctx ? ctx->error.c_str() : kbj_global_error.c_str(); }
+
+int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const kbj_config* cfg, int device, void* hip_stream) {
+  if (!out || !model_blob || !cfg) return kbj_fail(nullptr, "kbj_create: null argument");
+  *out = nullptr;
+  if (model_bytes != sizeof(kbj_model)) return kbj_fail(nullptr, "kbj_create: model blob has the wrong size");
+  kbj_ctx* ctx = new kbj_ctx();
+  std::memcpy(&ctx->model_h, model_blob, sizeof(kbj_model));
+  ctx->cfg_h = *cfg;
+  std::string why;
+  if (!topology_ok(ctx->model_h, why)) { delete ctx; return kbj_fail(nullptr, "kbj_create: " + why); }
+  if (cfg->num_envs <= 0 || cfg->substeps <= 0 || cfg->rollout_len <= 0) { delete ctx; return kbj_fail(nullptr, "kbj_create: bad config sizes"); }
+  if (cfg->solver_newton != 1) { delete ctx; return kbj_fail(nullptr, "kbj_create: only the Newton solver is implemented on the GPU (solver_newton = 1)"); }
+  if (cfg->hidden_size % 64 != 0 || cfg->depth != 2) { delete ctx; return kbj_fail(nullptr, "kbj_create: hidden_size must be a multiple of 64 and depth 2"); }
+  ctx->device = device;
+  ctx->stream = (hipStream_t)hip_stream;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) { delete ctx; return kbj_fail(nullptr, "kbj_create: no HIP device (this library has no CPU fallback)"); }
+  if (device < 0 || device >= ndev) { delete ctx; return kbj_fail(nullptr, "kbj_create: bad device index"); }
+  auto cleanup = [&](const std::string& msg) { kbj_destroy(ctx); return kbj_fail(nullptr, msg); };
+#define KBJ_TRY(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return cleanup(std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+  KBJ_TRY(hipSetDevice(device));
+  size_t N = cfg->num_envs;
+  KBJ_TRY(hipMalloc(&ctx->model_d, sizeof(kbj_model)));
+  KBJ_TRY(hipMalloc(&ctx->cfg_d, sizeof(kbj_config)));
+  KBJ_TRY(hipMemcpy(ctx->model_d, &ctx->model_h, sizeof(kbj_model), hipMemcpyHostToDevice));
+  KBJ_TRY(hipMemcpy(ctx->cfg_d, &ctx->cfg_h, sizeof(kbj_config), hipMemcpyHostToDevice));
+  KBJ_TRY(hipMalloc(&ctx->ep_d, N * KBJ_EP_SIZE * sizeof(float)));
+  KBJ_TRY(hipMalloc(&ctx->es_d, N * KBJ_ES_SIZE * sizeof(float)));
+  KBJ_TRY(hipMalloc(&ctx->rcarry_d, N * KBJ_RC_SIZE * sizeof(float)));
+  KBJ_TRY(hipMemset(ctx->ep_d, 0, N * KBJ_EP_SIZE * sizeof(float)));
+  KBJ_TRY(hipMemset(ctx->es_d, 0, N * KBJ_ES_SIZE * sizeof(float)));
+  KBJ_TRY(hipMemset(ctx->rcarry_d, 0, N * KBJ_RC_SIZE * sizeof(float)));
+  KBJ_TRY(hipEventCreate(&ctx->ev0));
+  KBJ_TRY(hipEventCreate(&ctx->ev1));
+#undef KBJ_TRY
+  if (kbj_nn_create(ctx) != 0) { std::string msg = ctx->error; kbj_destroy(ctx); return kbj_fail(nullptr, msg); }
+  *out = ctx;
+  return 0;
+}
+
+int kbj_destroy(kbj_ctx* ctx) {
+  if (!ctx) return 0;
+  hipSetDevice(ctx->device);
+  kbj_nn_destroy(ctx);
+  if (ctx->model_d) hipFree(ctx->model_d);
+  if (ctx->cfg_d) hipFree(ctx->cfg_d);
+  if (ctx->ep_d) hipFree(ctx->ep_d);
+  if (ctx->es_d) hipFree(ctx->es_d);
+  if (ctx->rcarry_d) hipFree(ctx->rcarry_d);
+  if (ctx->ev0) hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  delete ctx;
+  return 0;
+}
+
+int kbj_synchronize(kbj_ctx* ctx) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_synchronize: null ctx");
+  KBJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return 0;
+}
+
+int kbj_profile_begin(kbj_ctx* ctx) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_profile_begin: null ctx");
+  ctx->profiling = true; ctx->env_ms = ctx->nn_ms = 0; ctx->env_launches = ctx->nn_launches = 0;
+  return 0;
+}
+int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, float* nn_ms, int* nn_launches) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_profile_end: null ctx");
+  ctx->profiling = false;
+  if (env_step_ms) *env_step_ms = ctx->env_ms;
+  if (env_step_launches) *env_step_launches = ctx->env_launches;
+  if (nn_ms) *nn_ms = ctx->nn_ms;
+  if (nn_launches) *nn_launches = ctx->nn_launches;
+  return 0;
+}
+
+}  // extern "C"

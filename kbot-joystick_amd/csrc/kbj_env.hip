@@ -1,0 +1,216 @@
+// kbj_env.hip — HIP kernels + C-ABI entry points of the environment side of the hot path:
+// kbj_env_reset_all / kbj_env_step (one wavefront = one env, state in LDS; kbj_env_*.h) and kbj_rewards.
+#include <hip/hip_runtime.h>
+#include "kbj_env_task.h"
+#include "kbj_ctx.h"
+
+using namespace kbj;
+
+namespace {
+
+__device__ __forceinline__ PhysConst make_pc(const kbj_config& c) {
+  PhysConst pc;
+  pc.dt = c.dt; pc.tolerance = c.solver_tolerance; pc.iterations = c.solver_iterations; pc.ls_iterations = c.ls_iterations;
+  return pc;
+}
+
+// grid = N workgroups of one wavefront; env state rows are read/written lane-contiguously (coalesced)
+__global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, uint32_t seed,
+                                                       float* __restrict__ ep, float* __restrict__ es, float* actor0, float* critic0, float* aux0) {
+  __shared__ KbjShared S;
+  const int env = blockIdx.x;
+  PFOR(k, KBJ_ES_SIZE) S.es[k] = 0;
+  KBJ_SYNC();
+  Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
+  PhysConst pc = make_pc(*c);
+  task_reset(S, *m, *c, pc, rng);
+  task_write_obs(S, *m, *c, rng, actor0 + (size_t)env * KBJ_LD_ACTOR, critic0 + (size_t)env * KBJ_LD_CRITIC, aux0 + (size_t)env * KBJ_AUX_SIZE);
+  PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
+  PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
+}
+
+__global__ __launch_bounds__(64) void env_step_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, uint32_t seed,
+                                                      float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ action,
+                                                      float* aux_t, float* actor_next, float* critic_next, float* aux_next) {
+  __shared__ KbjShared S;
+  const int env = blockIdx.x;
+  PFOR(k, KBJ_EP_SIZE) S.ep[k] = ep[(size_t)env * KBJ_EP_SIZE + k];
+  PFOR(k, KBJ_ES_SIZE) S.es[k] = es[(size_t)env * KBJ_ES_SIZE + k];
+  KBJ_SYNC();
+  Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
+  PhysConst pc = make_pc(*c);
+  task_step(S, *m, *c, pc, rng, action + (size_t)env * KBJ_NU, aux_t + (size_t)env * KBJ_AUX_SIZE, actor_next + (size_t)env * KBJ_LD_ACTOR,
+            critic_next + (size_t)env * KBJ_LD_CRITIC, aux_next + (size_t)env * KBJ_AUX_SIZE);
+  if (S.done) PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
+  PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
+}
+
+// ---- reward stack (train.py:125-506, weights train.py:1225-1256): one thread scans one env's trajectory ----
+__global__ void rewards_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ aux, int T, int N,
+                               float* __restrict__ carry, float* __restrict__ reward, float* __restrict__ comps) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= N) return;
+  const float scales[KBJ_NREW] = {0.2f, 0.1f, 0.2f, 0.2f, 0.2f, 0.1f, 0.1f, 1.5f, 0.1f, 0.05f, 0.1f, 0.1f};
+  const float ctrl_dt = c->ctrl_dt;
+  float* rc = carry + (size_t)env * KBJ_RC_SIZE;
+  float tsingle = rc[KBJ_RC_TSINGLE], air[2] = {rc[KBJ_RC_AIRTIME], rc[KBJ_RC_AIRTIME + 1]};
+  bool pcon[2] = {rc[KBJ_RC_CONTACT] != 0, rc[KBJ_RC_CONTACT + 1] != 0};
+  float pq[6];
+  bool pdone = false;
+  for (int t = 0; t < T; ++t) {
+    const float* a = aux + ((size_t)t * N + env) * KBJ_AUX_SIZE;
+    float r[KBJ_NREW];
+    const float* cmd = a + KBJ_AUX_CMD;
+    bool zc = sqrtf(cmd[0] * cmd[0] + cmd[1] * cmd[1] + cmd[2] * cmd[2]) < 1e-3f;
+    bool done = a[KBJ_AUX_DONE] != 0;
+    float bq[4] = {a[KBJ_AUX_BQUAT], a[KBJ_AUX_BQUAT + 1], a[KBJ_AUX_BQUAT + 2], a[KBJ_AUX_BQUAT + 3]}, be[3];
+    quat_to_euler(bq, be);
+    {  // linvel (train.py:274-292)
+      float ye[3] = {0, 0, be[2]}, yq[4], v[3] = {cmd[0], cmd[1], 0}, g[3];
+      euler_to_quat(ye, yq); rotate_by_quat(v, yq, false, g);
+      float ex = a[KBJ_AUX_QVEL] - g[0], ey = a[KBJ_AUX_QVEL + 1] - g[1], err = sqrtf(ex * ex + ey * ey);
+      r[KBJ_REW_LINVEL] = expf(-(zc ? err : err * err) / 0.2f);
+    }
+    r[KBJ_REW_ANGVEL] = expf(-fabsf(a[KBJ_AUX_QVEL + 5] - cmd[2]) / 0.2f);  // train.py:301-306
+    {  // roll_pitch (train.py:316-334)
+      float e1[3] = {be[0], be[1], 0}, q1[4], e2[3] = {cmd[4], cmd[5], 0}, q2[4];
+      euler_to_quat(e1, q1); euler_to_quat(e2, q2);
+      float d_ = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
+      r[KBJ_REW_ROLL_PITCH] = expf(-(1 - d_ * d_) / (zc ? 0.01f : 0.03f));
+    }
+    {  // base_height (train.py:377-388)
+      float low = fminf(a[KBJ_AUX_LFZ] - 0.06f, a[KBJ_AUX_RFZ] - 0.06f);
+      float h = a[KBJ_AUX_BASEZ] - low;
+      r[KBJ_REW_BASE_HEIGHT] = expf(-fabsf(h - (cmd[3] + 0.80f)) / 0.02f);
+    }
+    {  // arm_pos (train.py:261-265)
+      float e = 0;
+      for (int j = 0; j < 10; ++j) { float dq = a[KBJ_AUX_ARMQ + j] - (cmd[6 + j] + m->joint_bias[10 + j]); e += dq * dq; }
+      r[KBJ_REW_ARM_POS] = expf(-e / 0.1f);
+    }
+    bool cl = a[KBJ_AUX_TOUCH] > 0.1f, cr = a[KBJ_AUX_TOUCH + 1] > 0.1f;
+    {  // single_contact (train.py:138-154), grace period 2.0 s
+      float ts = (cl != cr) ? 0.0f : tsingle + ctrl_dt;
+      if (zc) ts = 2.0f;
+      tsingle = ts;
+      r[KBJ_REW_SINGLE_CONTACT] = zc ? 1.0f : (ts < 2.0f ? 1.0f : 0.0f);
+    }
+    r[KBJ_REW_NO_CONTACT] = zc ? 0.0f : ((cl || cr) ? 0.0f : 1.0f);  // train.py:161-165
+    {  // feet_airtime (train.py:197-213)
+      bool con[2] = {cl, cr};
+      float rew = 0;
+      for (int f = 0; f < 2; ++f) {
+        bool first = con[f] && !pcon[f] && !done;
+        rew += (air[f] - 0.4f) * (first ? 1.0f : 0.0f);
+        air[f] = (con[f] || done) ? 0.0f : air[f] + ctrl_dt;
+        pcon[f] = con[f];
+      }
+      r[KBJ_REW_FEET_AIRTIME] = zc ? 0.0f : rew;
+    }
+    {  // feet_orient (train.py:418-457)
+      float rpy = 0, rp = 0;
+      for (int f = 0; f < 2; ++f) {
+        const float* fq_ = a + (f ? KBJ_AUX_RFQUAT : KBJ_AUX_LFQUAT);
+        float fq[4] = {fq_[0], fq_[1], fq_[2], fq_[3]};
+        float te[3] = {f ? 1.5707963267948966f : -1.5707963267948966f, 0, be[2] - 3.141592653589793f}, tq[4];
+        euler_to_quat(te, tq);
+        float d1 = tq[0] * fq[0] + tq[1] * fq[1] + tq[2] * fq[2] + tq[3] * fq[3];
+        rpy += 1 - d1 * d1;
+        float fe[3]; quat_to_euler(fq, fe); fe[2] = 0;
+        float fq0[4]; euler_to_quat(fe, fq0);
+        te[2] = 0; euler_to_quat(te, tq);
+        float d2 = tq[0] * fq0[0] + tq[1] * fq0[1] + tq[2] * fq0[2] + tq[3] * fq0[3];
+        rp += 1 - d2 * d2;
+      }
+      r[KBJ_REW_FEET_ORIENT] = expf(-(fabsf(cmd[2]) > 1e-3f ? rp : rpy) / 0.02f);
+    }
+    {  // com_distance (train.py:466-478)
+      float cd = a[KBJ_AUX_COMDIST];
+      r[KBJ_REW_COM_DISTANCE] = (cd >= 0 && zc) ? expf(-cd / 0.04f) : 0.0f;
+    }
+    {  // base_accel (train.py:487-494)
+      float e = 0;
+      if (t > 0 && !pdone) for (int k = 0; k < 6; ++k) e += fabsf(a[KBJ_AUX_QVEL + k] - pq[k]);
+      for (int k = 0; k < 6; ++k) pq[k] = a[KBJ_AUX_QVEL + k];
+      pdone = done;
+      r[KBJ_REW_BASE_ACCEL] = expf(-e / 5.0f);
+    }
+    {  // torque (train.py:503-506)
+      float s = 0;
+      for (int u = 0; u < KBJ_NU; ++u) s += expf(-fabsf(a[KBJ_AUX_CTRL + u]) / 5.0f);
+      r[KBJ_REW_TORQUE] = zc ? s / KBJ_NU : 1.0f;
+    }
+    float tot = 0;
+    for (int k = 0; k < KBJ_NREW; ++k) { tot += scales[k] * r[k]; if (comps) comps[((size_t)t * N + env) * KBJ_NREW + k] = r[k]; }
+    reward[(size_t)t * N + env] = tot;
+  }
+  rc[KBJ_RC_TSINGLE] = tsingle; rc[KBJ_RC_AIRTIME] = air[0]; rc[KBJ_RC_AIRTIME + 1] = air[1];
+  rc[KBJ_RC_CONTACT] = pcon[0] ? 1.0f : 0.0f; rc[KBJ_RC_CONTACT + 1] = pcon[1] ? 1.0f : 0.0f;
+}
+
+__global__ void init_reward_carry_kernel(float* carry, int N) {
+  int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= N) return;
+  float* rc = carry + (size_t)env * KBJ_RC_SIZE;
+  for (int k = 0; k < KBJ_RC_SIZE; ++k) rc[k] = 0;
+  rc[KBJ_RC_CONTACT] = 1.0f; rc[KBJ_RC_CONTACT + 1] = 1.0f;  // train.py:175-178 initial contact carry True
+}
+
+}  // namespace
+
+extern "C" {
+
+int kbj_env_reset_all(kbj_ctx* ctx, uint32_t seed, float* actor0_d, float* critic0_d, float* aux0_d) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_env_reset_all: null ctx");
+  if (!actor0_d || !critic0_d || !aux0_d) return kbj_fail(ctx, "kbj_env_reset_all: null observation pointer");
+  ctx->seed = seed;
+  int N = ctx->cfg_h.num_envs;
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(init_reward_carry_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, ctx->rcarry_d, N);
+  KBJ_CHECK_LAUNCH(ctx, "init_reward_carry_kernel");
+  hipLaunchKernelGGL(env_reset_kernel, dim3(N), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, seed, ctx->ep_d, ctx->es_d, actor0_d,
+                     critic0_d, aux0_d);
+  KBJ_CHECK_LAUNCH(ctx, "env_reset_kernel");
+  return 0;
+}
+
+int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_env_step: null ctx");
+  if (!action_d || !aux_t_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_step: null pointer");
+  int N = ctx->cfg_h.num_envs;
+  KbjTimed timed(ctx, false);
+  hipLaunchKernelGGL(env_step_kernel, dim3(N), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->seed, ctx->ep_d, ctx->es_d, action_d,
+                     aux_t_d, actor_next_d, critic_next_d, aux_next_d);
+  KBJ_CHECK_LAUNCH(ctx, "env_step_kernel");
+  return 0;
+}
+
+int kbj_env_get_state(kbj_ctx* ctx, float* ep_h, float* es_h) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_env_get_state: null ctx");
+  size_t N = ctx->cfg_h.num_envs;
+  KBJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ep_h) KBJ_HIP(ctx, hipMemcpy(ep_h, ctx->ep_d, N * KBJ_EP_SIZE * sizeof(float), hipMemcpyDeviceToHost));
+  if (es_h) KBJ_HIP(ctx, hipMemcpy(es_h, ctx->es_d, N * KBJ_ES_SIZE * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int kbj_env_set_state(kbj_ctx* ctx, const float* ep_h, const float* es_h) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_env_set_state: null ctx");
+  size_t N = ctx->cfg_h.num_envs;
+  KBJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ep_h) KBJ_HIP(ctx, hipMemcpy(ctx->ep_d, ep_h, N * KBJ_EP_SIZE * sizeof(float), hipMemcpyHostToDevice));
+  if (es_h) KBJ_HIP(ctx, hipMemcpy(ctx->es_d, es_h, N * KBJ_ES_SIZE * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+int kbj_rewards(kbj_ctx* ctx, const float* aux_d, int T, float* reward_d, float* comps_d) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_rewards: null ctx");
+  if (!aux_d || !reward_d || T <= 0) return kbj_fail(ctx, "kbj_rewards: bad arguments");
+  int N = ctx->cfg_h.num_envs;
+  hipLaunchKernelGGL(rewards_kernel, dim3((N + 63) / 64), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, aux_d, T, N, ctx->rcarry_d,
+                     reward_d, comps_d);
+  KBJ_CHECK_LAUNCH(ctx, "rewards_kernel");
+  return 0;
+}
+
+}  // extern "C"

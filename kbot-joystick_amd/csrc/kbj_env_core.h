@@ -1,0 +1,201 @@
+// kbj_env_core.h — the per-env control step of the K-Bot joystick task, one wavefront = one env.
+//
+// Hot-path rows a1-a3, a14-a22 of SURVEY.md §8: rigid-body step (restating what the reference gets from
+// mujoco-mjx via ksim's engine; configured at train.py:1775-1781), PD actuators (train.py:1091-1105),
+// observations (train.py:1155-1204, 509-707, 1329-1433), command (train.py:710-785), terminations
+// (train.py:788-823, 1258-1269), resets (train.py:826-844, 1146-1153), randomisers (train.py:1107-1132)
+// and push events (train.py:1134-1144).
+//
+// Execution model: a workgroup is ONE 64-lane wavefront and owns one environment. All per-body / per-dof /
+// per-constraint-row state of that env is staged in LDS (struct KbjShared, ~20 KB); the code is a sequence
+// of "phases": `PFOR(i, n)` spreads n independent work items over the 64 lanes, `KBJ_SYNC()` separates
+// phases that communicate through LDS, `wsum*()` are butterfly wave reductions. HBM traffic is only the
+// env's parameter/state rows at entry/exit and the observation rows, all lane-contiguous (coalesced).
+//
+// The same source compiles as a scalar host emulation (KBJ_EMU: 1 "lane", butterfly reductions replayed in
+// the same order) used by tests/ to debug the lane-parallel algorithm without a GPU. The emulation is test
+// infrastructure: the product library only ever launches the HIP kernel.
+#pragma once
+#include <stdint.h>
+#include <math.h>
+#include "kbj_model.h"
+
+#ifdef KBJ_EMU
+#define KBJ_DEV static inline
+#define KBJ_LANE 0
+#define KBJ_NLANE 1
+#define KBJ_SYNC() ((void)0)
+#else
+#define KBJ_DEV __device__ __forceinline__
+#define KBJ_LANE ((int)threadIdx.x)
+#define KBJ_NLANE 64
+#define KBJ_SYNC() __syncthreads()
+#endif
+#define PFOR(i, n) for (int i = KBJ_LANE; i < (n); i += KBJ_NLANE)
+
+namespace kbj {
+
+constexpr int NB = KBJ_NBODY, NQ = KBJ_NQ, NV = KBJ_NV, NU = KBJ_NU, NCON = KBJ_NCON;
+constexpr int NROW = 72, ROW_LIM = 20, ROW_CON = 40;  // frictionloss | limits | pyramidal contacts
+
+// ---- fixed kbot topology (validated against the model blob in kbj_create) ----
+KBJ_DEV int body_parent(int b) { return b <= 1 ? 0 : (b == 2 ? 1 : ((b - 3) % 5 == 0 ? 2 : b - 1)); }
+KBJ_DEV int dof_body(int d) { return d < 6 ? 1 : d - 3; }
+KBJ_DEV int dof_parent(int d) { return d == 0 ? -1 : (d < 6 ? d - 1 : ((d - 6) % 5 == 0 ? 5 : d - 1)); }
+
+struct KbjShared {
+  float ep[KBJ_EP_SIZE];
+  float es[KBJ_ES_SIZE];
+  float xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3], xaxis[NB][3];
+  float com[4];   // tree centre of mass (subtree_com[1]) and total mass
+  float com2[3];  // subtree_com[2] (everything but the base body)
+  float cinert[NB][10], crb[NB][10];
+  float cdof[NV][6], cdof_dot[NV][6], cvel[NB][6], cfrc[NB][6], cfrc_acc[NB][6];
+  float M[NV][27];
+  float A[4][12][12];  // chain-local blocks [ankle..hip | base 6], row 11 = right-hand side
+  float B[7][8];       // base block, row 6 = right-hand side
+  float qfrc_bias[NV], qfrc_act[NV], qfrc_app[NV], qfrc_smooth[NV], qacc_smooth[NV], qacc[NV], warm[NV];
+  float Ma[NV], grad[NV], search[NV], mv[NV], vec[NV];
+  float conpos[NCON][3], condist[NCON];
+  int conact[NCON];
+  float Jc[32][12];  // contact rows: columns 0..5 base dofs, 6..10 the leg's dofs hip..ankle
+  float D[NROW], R[NROW], aref[NROW], floss[NROW], jar[NROW], jv[NROW], force[NROW], lsign[NU];
+  int active[NROW], quad[NROW];
+  float ctrl[NU], push[6], act_eff[NU];
+  float gyro[3], imuquat[4], touch[2], pg[3];
+  float scal[8];
+  int iters, pushing, done;
+};
+
+// ---- small vector helpers ----
+KBJ_DEV void cross3(const float* a, const float* b, float* o) {
+  o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+KBJ_DEV void quat_mul(const float* a, const float* b, float* o) {
+  float w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  float x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  float y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  float z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  o[0] = w; o[1] = x; o[2] = y; o[3] = z;
+}
+KBJ_DEV void quat_norm(float* q) {
+  float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; ++k) q[k] /= n;
+}
+KBJ_DEV void quat_to_mat(const float* q, float* m) {
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  m[0] = 1 - 2 * (y * y + z * z); m[1] = 2 * (x * y - w * z); m[2] = 2 * (x * z + w * y);
+  m[3] = 2 * (x * y + w * z); m[4] = 1 - 2 * (x * x + z * z); m[5] = 2 * (y * z - w * x);
+  m[6] = 2 * (x * z - w * y); m[7] = 2 * (y * z + w * x); m[8] = 1 - 2 * (x * x + y * y);
+}
+KBJ_DEV void mat_vec(const float* m, const float* v, float* o) {
+  for (int i = 0; i < 3; ++i) o[i] = m[3 * i] * v[0] + m[3 * i + 1] * v[1] + m[3 * i + 2] * v[2];
+}
+KBJ_DEV void matT_vec(const float* m, const float* v, float* o) {
+  for (int i = 0; i < 3; ++i) o[i] = m[i] * v[0] + m[3 + i] * v[1] + m[6 + i] * v[2];
+}
+KBJ_DEV void inert_mul(const float* I, const float* v, float* o) {
+  o[0] = I[0] * v[0] + I[3] * v[1] + I[4] * v[2] - I[8] * v[4] + I[7] * v[5];
+  o[1] = I[3] * v[0] + I[1] * v[1] + I[5] * v[2] + I[8] * v[3] - I[6] * v[5];
+  o[2] = I[4] * v[0] + I[5] * v[1] + I[2] * v[2] - I[7] * v[3] + I[6] * v[4];
+  o[3] = I[8] * v[1] - I[7] * v[2] + I[9] * v[3];
+  o[4] = I[6] * v[2] - I[8] * v[0] + I[9] * v[4];
+  o[5] = I[7] * v[0] - I[6] * v[1] + I[9] * v[5];
+}
+KBJ_DEV void cross_motion(const float* vel, const float* v, float* o) {
+  float t1[3], t2[3];
+  cross3(vel, v, o); cross3(vel, v + 3, t1); cross3(vel + 3, v, t2);
+  for (int k = 0; k < 3; ++k) o[3 + k] = t1[k] + t2[k];
+}
+KBJ_DEV void cross_force(const float* vel, const float* f, float* o) {
+  float t1[3], t2[3];
+  cross3(vel, f, t1); cross3(vel + 3, f + 3, t2);
+  for (int k = 0; k < 3; ++k) o[k] = t1[k] + t2[k];
+  cross3(vel, f + 3, o + 3);
+}
+KBJ_DEV void quat_to_euler(const float* q, float* e) {  // xax.quat_to_euler
+  float w = q[0], x = q[1], y = q[2], z = q[3];
+  e[0] = atan2f(2 * (w * x + y * z), 1 - 2 * (x * x + y * y));
+  float sp = fminf(1.0f, fmaxf(-1.0f, 2 * (w * y - z * x)));
+  e[1] = asinf(sp);
+  e[2] = atan2f(2 * (w * z + x * y), 1 - 2 * (y * y + z * z));
+}
+KBJ_DEV void euler_to_quat(const float* e, float* q) {
+  float cr = cosf(e[0] / 2), sr = sinf(e[0] / 2), cp = cosf(e[1] / 2), sp = sinf(e[1] / 2), cy = cosf(e[2] / 2), sy = sinf(e[2] / 2);
+  q[0] = cr * cp * cy + sr * sp * sy; q[1] = sr * cp * cy - cr * sp * sy; q[2] = cr * sp * cy + sr * cp * sy; q[3] = cr * cp * sy - sr * sp * cy;
+}
+KBJ_DEV void rotate_by_quat(const float* v, const float* q_in, bool inverse, float* o) {
+  float q[4] = {q_in[0], q_in[1], q_in[2], q_in[3]}, mat[9];
+  quat_norm(q);
+  if (inverse) { q[1] = -q[1]; q[2] = -q[2]; q[3] = -q[3]; }
+  quat_to_mat(q, mat); mat_vec(mat, v, o);
+}
+
+// ---- wave reductions: xor butterfly, identical summation order on the GPU and in the emulation ----
+#ifdef KBJ_EMU
+template <class F> KBJ_DEV float wsum(int n, F f) {
+  float v[64];
+  for (int l = 0; l < 64; ++l) v[l] = l < n ? f(l) : 0.0f;
+  for (int msk = 32; msk >= 1; msk >>= 1) { float t[64]; for (int l = 0; l < 64; ++l) t[l] = v[l] + v[l ^ msk]; for (int l = 0; l < 64; ++l) v[l] = t[l]; }
+  return v[0];
+}
+template <class F> KBJ_DEV void wsum2(int n, F f, float& a, float& b) {
+  float va[64], vb[64];
+  for (int l = 0; l < 64; ++l) { va[l] = 0; vb[l] = 0; if (l < n) f(l, va[l], vb[l]); }
+  for (int msk = 32; msk >= 1; msk >>= 1) {
+    float ta[64], tb[64];
+    for (int l = 0; l < 64; ++l) { ta[l] = va[l] + va[l ^ msk]; tb[l] = vb[l] + vb[l ^ msk]; }
+    for (int l = 0; l < 64; ++l) { va[l] = ta[l]; vb[l] = tb[l]; }
+  }
+  a = va[0]; b = vb[0];
+}
+#else
+template <class F> KBJ_DEV float wsum(int n, F f) {
+  int l = KBJ_LANE;
+  float v = l < n ? f(l) : 0.0f;
+  for (int msk = 32; msk >= 1; msk >>= 1) v += __shfl_xor(v, msk, 64);
+  return v;
+}
+template <class F> KBJ_DEV void wsum2(int n, F f, float& a, float& b) {
+  int l = KBJ_LANE;
+  float va = 0, vb = 0;
+  if (l < n) f(l, va, vb);
+  for (int msk = 32; msk >= 1; msk >>= 1) { va += __shfl_xor(va, msk, 64); vb += __shfl_xor(vb, msk, 64); }
+  a = va; b = vb;
+}
+#endif
+
+// ---- threefry2x32-20 counter RNG (a25: the generator behind jax.random; Random123 KATs in tests) ----
+KBJ_DEV uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+KBJ_DEV void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
+  const int rot[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+  uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+#pragma unroll
+  for (int g = 0; g < 5; ++g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { x0 += x1; x1 = rotl32(x1, rot[(g & 1) * 4 + r]); x1 ^= x0; }
+    x0 += ks[(g + 1) % 3]; x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  o0 = x0; o1 = x1;
+}
+struct Rng { uint32_t seed, env; };
+KBJ_DEV void rng_bits(const Rng& r, int stream, uint32_t a, uint32_t b, uint32_t& o0, uint32_t& o1) {
+  threefry2x32(r.seed ^ ((uint32_t)stream * 0x9E3779B9u), r.env, a, b, o0, o1);
+}
+// uniform in [0,1) on 24 bits (exact in fp32)
+KBJ_DEV float rng_u01(const Rng& r, int stream, uint32_t a, uint32_t b) {
+  uint32_t x, y; rng_bits(r, stream, a, b, x, y);
+  return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+// lo + (hi - lo) u with one rounding (explicit fma so the oracle reproduces it bit for bit)
+KBJ_DEV float rng_uniform(const Rng& r, int stream, uint32_t a, uint32_t b, float lo, float hi) {
+  return fmaf(hi - lo, rng_u01(r, stream, a, b), lo);
+}
+KBJ_DEV float rng_normal(const Rng& r, int stream, uint32_t a, uint32_t b) {  // Box-Muller
+  uint32_t x, y; rng_bits(r, stream, a, b, x, y);
+  float u1 = (float)((x >> 8) + 1u) * (1.0f / 16777216.0f), u2 = (float)(y >> 8) * (1.0f / 16777216.0f);
+  return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+}
+
+}  // namespace kbj

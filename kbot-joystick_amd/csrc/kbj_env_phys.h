@@ -1,0 +1,623 @@
+// kbj_env_phys.h — rigid-body forward dynamics + soft-constraint Newton solve for one env per wavefront.
+//
+// the "MuJoCo-XLA physics step" (reference: mjx.step under ksim's engine, configured at
+// train.py:1775-1778). Pipeline per substep: kinematics -> tree com / cinert / cdof -> composite inertia ->
+// mass matrix -> velocities + bias forces (RNE) -> actuation -> plane-capsule contacts -> constraint rows ->
+// Newton solve with exact line search -> sensors -> semi-implicit Euler.
+//
+// Data layout: everything lives in KbjShared (LDS). Linear algebra exploits the kbot tree: four 5-dof limb
+// chains hang off the 6-dof base, so M and the Newton Hessian H = M + J^T D J are "arrow" matrices; each chain
+// is eliminated in its own 11x11 local block (5 chain dofs + 6 base dofs) in parallel, the four Schur
+// complements are summed into the 6x6 base block, and the right-hand side rides along as an extra row.
+#pragma once
+#include "kbj_env_core.h"
+
+namespace kbj {
+
+struct PhysConst {  // per-launch constants derived from kbj_config
+  float dt, tolerance;
+  int iterations, ls_iterations;
+};
+
+// ---- position stage ----------------------------------------------------------------------------------------
+KBJ_DEV void phys_kinematics(KbjShared& S, const kbj_model& m) {
+  const float* qpos = S.es + KBJ_ES_QPOS;
+  PFOR(w, 1) {
+    for (int k = 0; k < 3; ++k) { S.xpos[0][k] = 0; S.xipos[0][k] = 0; S.xaxis[0][k] = 0; S.xaxis[1][k] = 0; S.xaxis[2][k] = 0; S.xaxis[23][k] = 0; }
+    S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
+    quat_to_mat(S.xquat[0], S.xmat[0]);
+    float q[4] = {qpos[3], qpos[4], qpos[5], qpos[6]};
+    quat_norm(q);
+    for (int k = 0; k < 3; ++k) S.xpos[1][k] = qpos[k];
+    for (int k = 0; k < 4; ++k) S.xquat[1][k] = q[k];
+    quat_to_mat(q, S.xmat[1]);
+    float t[3];
+    mat_vec(S.xmat[1], S.ep + KBJ_EP_IPOS + 3, t);
+    for (int k = 0; k < 3; ++k) S.xipos[1][k] = S.xpos[1][k] + t[k];
+    // torso: welded to the base
+    mat_vec(S.xmat[1], m.body_pos[2], t);
+    for (int k = 0; k < 3; ++k) S.xpos[2][k] = S.xpos[1][k] + t[k];
+    float q2[4];
+    quat_mul(q, m.body_quat[2], q2);
+    quat_norm(q2);
+    for (int k = 0; k < 4; ++k) S.xquat[2][k] = q2[k];
+    quat_to_mat(q2, S.xmat[2]);
+    mat_vec(S.xmat[2], S.ep + KBJ_EP_IPOS + 6, t);
+    for (int k = 0; k < 3; ++k) S.xipos[2][k] = S.xpos[2][k] + t[k];
+  }
+  KBJ_SYNC();
+  PFOR(c, 5) {  // lanes 0..3 walk one limb each from the torso outwards, lane 4 places the imu body
+    float ppos[3], pquat[4], pmat[9];
+    for (int k = 0; k < 3; ++k) ppos[k] = S.xpos[2][k];
+    for (int k = 0; k < 4; ++k) pquat[k] = S.xquat[2][k];
+    for (int k = 0; k < 9; ++k) pmat[k] = S.xmat[2][k];
+    int nb = c < 4 ? 5 : 1;
+    for (int k5 = 0; k5 < nb; ++k5) {
+      int b = c < 4 ? 3 + 5 * c + k5 : 23;
+      float t[3], q[4];
+      mat_vec(pmat, m.body_pos[b], t);
+      for (int k = 0; k < 3; ++k) ppos[k] += t[k];
+      quat_mul(pquat, m.body_quat[b], q);
+      if (c < 4) {
+        float ang = qpos[7 + 5 * c + k5];
+        float s = sinf(ang / 2), co = cosf(ang / 2);
+        float jq[4] = {co, s * m.jnt_axis[b][0], s * m.jnt_axis[b][1], s * m.jnt_axis[b][2]}, q2[4];
+        quat_mul(q, jq, q2);
+        for (int k = 0; k < 4; ++k) q[k] = q2[k];
+      }
+      quat_norm(q);
+      for (int k = 0; k < 4; ++k) pquat[k] = q[k];
+      quat_to_mat(pquat, pmat);
+      for (int k = 0; k < 3; ++k) S.xpos[b][k] = ppos[k];
+      for (int k = 0; k < 4; ++k) S.xquat[b][k] = pquat[k];
+      for (int k = 0; k < 9; ++k) S.xmat[b][k] = pmat[k];
+      mat_vec(pmat, S.ep + KBJ_EP_IPOS + 3 * b, t);
+      for (int k = 0; k < 3; ++k) S.xipos[b][k] = ppos[k] + t[k];
+      if (c < 4) mat_vec(pmat, m.jnt_axis[b], S.xaxis[b]);
+    }
+  }
+  KBJ_SYNC();
+}
+
+KBJ_DEV void phys_com(KbjShared& S) {
+  const float* mass = S.ep + KBJ_EP_MASS;
+  PFOR(w, 3) {
+    float s2 = 0, m2 = 0;
+    for (int b = 2; b < NB; ++b) { s2 += mass[b] * S.xipos[b][w]; m2 += mass[b]; }
+    float s1 = s2 + mass[1] * S.xipos[1][w], m1 = m2 + mass[1];
+    S.com2[w] = s2 / m2;
+    S.com[w] = s1 / m1;
+    if (w == 0) S.com[3] = m1;
+  }
+  PFOR(w, NV * 27) (&S.M[0][0])[w] = 0;
+  KBJ_SYNC();
+  PFOR(b, NB) {
+    float* c = S.cinert[b];
+    if (b == 0) { for (int k = 0; k < 10; ++k) c[k] = 0; }
+    else {
+      const float* mat = S.xmat[b];
+      const float* in = S.ep + KBJ_EP_INERTIA + 3 * b;
+      float dif[3] = {S.xipos[b][0] - S.com[0], S.xipos[b][1] - S.com[1], S.xipos[b][2] - S.com[2]};
+      float ms = mass[b];
+      c[0] = mat[0] * mat[0] * in[0] + mat[1] * mat[1] * in[1] + mat[2] * mat[2] * in[2];
+      c[1] = mat[3] * mat[3] * in[0] + mat[4] * mat[4] * in[1] + mat[5] * mat[5] * in[2];
+      c[2] = mat[6] * mat[6] * in[0] + mat[7] * mat[7] * in[1] + mat[8] * mat[8] * in[2];
+      c[3] = mat[0] * mat[3] * in[0] + mat[1] * mat[4] * in[1] + mat[2] * mat[5] * in[2];
+      c[4] = mat[0] * mat[6] * in[0] + mat[1] * mat[7] * in[1] + mat[2] * mat[8] * in[2];
+      c[5] = mat[3] * mat[6] * in[0] + mat[4] * mat[7] * in[1] + mat[5] * mat[8] * in[2];
+      c[0] += ms * (dif[1] * dif[1] + dif[2] * dif[2]);
+      c[1] += ms * (dif[0] * dif[0] + dif[2] * dif[2]);
+      c[2] += ms * (dif[0] * dif[0] + dif[1] * dif[1]);
+      c[3] -= ms * dif[0] * dif[1];
+      c[4] -= ms * dif[0] * dif[2];
+      c[5] -= ms * dif[1] * dif[2];
+      c[6] = ms * dif[0]; c[7] = ms * dif[1]; c[8] = ms * dif[2]; c[9] = ms;
+    }
+  }
+  PFOR(d, NV) {
+    float* cd = S.cdof[d];
+    int b = dof_body(d);
+    float off[3] = {S.com[0] - S.xpos[b][0], S.com[1] - S.xpos[b][1], S.com[2] - S.xpos[b][2]};
+    if (d < 3) { for (int k = 0; k < 6; ++k) cd[k] = 0; cd[3 + d] = 1; }
+    else if (d < 6) {
+      int i = d - 3;
+      float ax[3] = {S.xmat[1][i], S.xmat[1][3 + i], S.xmat[1][6 + i]};
+      for (int k = 0; k < 3; ++k) cd[k] = ax[k];
+      cross3(ax, off, cd + 3);
+    } else {
+      for (int k = 0; k < 3; ++k) cd[k] = S.xaxis[b][k];
+      cross3(S.xaxis[b], off, cd + 3);
+    }
+  }
+  KBJ_SYNC();
+}
+
+// sum of a per-body quantity over the subtree of body b (fixed kbot tree)
+template <int W> KBJ_DEV float subtree_sum(const float (*q)[W], int b, int k) {
+  float s = 0;
+  if (b == 1 || b == 2) { for (int bb = b; bb < NB; ++bb) s += q[bb][k]; }
+  else if (b == 23) s = q[23][k];
+  else if (b >= 3) { int last = 3 + 5 * ((b - 3) / 5) + 4; for (int bb = b; bb <= last; ++bb) s += q[bb][k]; }
+  return s;
+}
+
+KBJ_DEV void phys_crb_mass(KbjShared& S) {
+  PFOR(w, NB * 10) { int b = w / 10, k = w % 10; S.crb[b][k] = subtree_sum<10>(S.cinert, b, k); }
+  KBJ_SYNC();
+  PFOR(i, NV) {
+    float buf[6];
+    inert_mul(S.crb[dof_body(i)], S.cdof[i], buf);
+    for (int j = i; j >= 0; j = dof_parent(j)) {
+      float s = 0;
+      for (int k = 0; k < 6; ++k) s += S.cdof[j][k] * buf[k];
+      if (j == i) s += S.ep[KBJ_EP_ARMATURE + i];
+      S.M[i][j] = s;
+      S.M[j][i] = s;
+    }
+  }
+  KBJ_SYNC();
+}
+
+// ---- contacts + velocity stage -------------------------------------------------------------------------------
+KBJ_DEV void phys_collide_vel(KbjShared& S, const kbj_model& m) {
+  const float* qvel = S.es + KBJ_ES_QVEL;
+  PFOR(ci, NCON) {  // capsule end ci%2 of capsule ci/2 against the plane z = 0
+    int c = ci / 2, b = c < 2 ? 7 : 12;
+    float t[3], ax[3];
+    mat_vec(S.xmat[b], S.ep + KBJ_EP_CAP_POS + 3 * c, t);
+    mat_vec(S.xmat[b], m.cap_axis[c], ax);
+    float sgn = (ci & 1) ? 1.0f : -1.0f, hl = S.ep[KBJ_EP_CAP_HALF + c], rad = S.ep[KBJ_EP_CAP_RAD + c];
+    float end[3];
+    for (int k = 0; k < 3; ++k) end[k] = S.xpos[b][k] + t[k] + sgn * hl * ax[k];
+    float dist = end[2] - rad;
+    S.condist[ci] = dist;
+    S.conpos[ci][0] = end[0]; S.conpos[ci][1] = end[1]; S.conpos[ci][2] = end[2] - (rad + dist / 2);
+    S.conact[ci] = dist < 0;
+  }
+  PFOR(c, 5) {  // limb walkers: spatial velocity, cdof_dot, acceleration bias and body forces (RNE forward pass)
+    float v[6] = {0, 0, 0, 0, 0, 0}, a[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
+    float cdd[6], Ia[6], Iv[6], x[6];
+    // base body: 3 translations (cdof_dot = 0) then 3 rotations sharing the pre-rotation velocity
+    for (int i = 0; i < 3; ++i) for (int k = 0; k < 6; ++k) v[k] += S.cdof[i][k] * qvel[i];
+    float vb[6];
+    for (int k = 0; k < 6; ++k) vb[k] = v[k];
+    for (int i = 3; i < 6; ++i) {
+      cross_motion(vb, S.cdof[i], cdd);
+      for (int k = 0; k < 6; ++k) { v[k] += S.cdof[i][k] * qvel[i]; a[k] += cdd[k] * qvel[i]; }
+      if (c == 0) for (int k = 0; k < 6; ++k) S.cdof_dot[i][k] = cdd[k];
+    }
+    if (c == 0) {
+      for (int i = 0; i < 3; ++i) for (int k = 0; k < 6; ++k) S.cdof_dot[i][k] = 0;
+      for (int b = 0; b < 3; ++b) {
+        if (b == 0) { for (int k = 0; k < 6; ++k) { S.cvel[0][k] = 0; S.cfrc[0][k] = 0; } continue; }
+        for (int k = 0; k < 6; ++k) S.cvel[b][k] = v[k];
+        inert_mul(S.cinert[b], a, Ia); inert_mul(S.cinert[b], v, Iv); cross_force(v, Iv, x);
+        for (int k = 0; k < 6; ++k) S.cfrc[b][k] = Ia[k] + x[k];
+      }
+    }
+    int nb = c < 4 ? 5 : 1;
+    for (int k5 = 0; k5 < nb; ++k5) {
+      int b = c < 4 ? 3 + 5 * c + k5 : 23;
+      if (c < 4) {
+        int d = b + 3;
+        cross_motion(v, S.cdof[d], cdd);
+        for (int k = 0; k < 6; ++k) { S.cdof_dot[d][k] = cdd[k]; v[k] += S.cdof[d][k] * qvel[d]; a[k] += cdd[k] * qvel[d]; }
+      }
+      for (int k = 0; k < 6; ++k) S.cvel[b][k] = v[k];
+      inert_mul(S.cinert[b], a, Ia); inert_mul(S.cinert[b], v, Iv); cross_force(v, Iv, x);
+      for (int k = 0; k < 6; ++k) S.cfrc[b][k] = Ia[k] + x[k];
+    }
+  }
+  KBJ_SYNC();
+  PFOR(w, NB * 6) { int b = w / 6, k = w % 6; S.cfrc_acc[b][k] = subtree_sum<6>(S.cfrc, b, k); }
+  KBJ_SYNC();
+}
+
+KBJ_DEV void phys_smooth_forces(KbjShared& S, const kbj_model& m) {
+  PFOR(i, NV) {
+    float s = 0;
+    for (int k = 0; k < 6; ++k) s += S.cdof[i][k] * S.cfrc_acc[dof_body(i)][k];
+    S.qfrc_bias[i] = s;
+    float act = 0, app = 0;
+    if (i >= 6) act = fminf(fmaxf(S.ctrl[i - 6], m.act_range[i - 6][0]), m.act_range[i - 6][1]);
+    else if (S.pushing) {
+      if (i < 3) app = S.push[i];
+      else {
+        float arm[3] = {S.xipos[1][0] - S.xpos[1][0], S.xipos[1][1] - S.xpos[1][1], S.xipos[1][2] - S.xpos[1][2]}, t[3], tq[3], loc[3];
+        cross3(arm, S.push, t);
+        for (int k = 0; k < 3; ++k) tq[k] = S.push[3 + k] + t[k];
+        matT_vec(S.xmat[1], tq, loc);
+        app = loc[i - 3];
+      }
+    }
+    S.qfrc_act[i] = act; S.qfrc_app[i] = app;
+    S.qfrc_smooth[i] = act + app - s;
+  }
+  KBJ_SYNC();
+}
+
+// ---- arrow-matrix Cholesky with the right-hand side carried as an extra row ------------------------------------
+// G = M (+ J^T D J over rows in their quadratic zone when `hess`); solves G x = rhs, result in S.vec.
+// local index li of chain c: li 0..4 <-> dof 10+5c-li (ankle first), li 5..10 <-> base dof li-5.
+KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
+  PFOR(w, 4 * 12 * 11) {
+    int c = w / 132, i = (w % 132) / 11, j = w % 11;
+    if (i < 11 && j > i) continue;
+    float v;
+    if (i == 11) v = j < 5 ? rhs[10 + 5 * c - j] : 0.0f;
+    else {
+      int di = i < 5 ? 10 + 5 * c - i : i - 5, dj = j < 5 ? 10 + 5 * c - j : j - 5;
+      v = (i >= 5 && j >= 5) ? 0.0f : S.M[di][dj];
+      if (hess) {
+        if (c < 2) {  // legs: contact rows of this leg
+          int ci_ = i < 5 ? 10 - i : i - 5, cj_ = j < 5 ? 10 - j : j - 5;
+          for (int r = 16 * c; r < 16 * c + 16; ++r)
+            if (S.quad[ROW_CON + r]) v += S.D[ROW_CON + r] * S.Jc[r][ci_] * S.Jc[r][cj_];
+        }
+        if (i == j && i < 5) {
+          int u = di - 6;
+          if (S.quad[u]) v += S.D[u];
+          if (S.quad[ROW_LIM + u]) v += S.D[ROW_LIM + u];
+        }
+      }
+    }
+    S.A[c][i][j] = v;
+  }
+  KBJ_SYNC();
+  for (int p = 0; p < 5; ++p) {
+    PFOR(c, 4) S.A[c][p][p] = sqrtf(S.A[c][p][p]);
+    KBJ_SYNC();
+    PFOR(w, 4 * 11) { int c = w / 11, i = p + 1 + w % 11; if (i <= 11) S.A[c][i][p] /= S.A[c][p][p]; }
+    KBJ_SYNC();
+    PFOR(w, 4 * 121) {
+      int c = w / 121, e = w % 121, i = p + 1 + e / 11, j = p + 1 + e % 11;
+      if (i <= 11 && j <= 10 && j <= i) S.A[c][i][j] -= S.A[c][i][p] * S.A[c][j][p];
+    }
+    KBJ_SYNC();
+  }
+  PFOR(w, 7 * 6) {
+    int i = w / 6, j = w % 6;
+    if (i < 6 && j > i) continue;
+    float v = i < 6 ? S.M[i][j] : rhs[j];
+    int ai = i < 6 ? 5 + i : 11;
+    for (int c = 0; c < 4; ++c) v += S.A[c][ai][5 + j];
+    S.B[i][j] = v;
+  }
+  KBJ_SYNC();
+  for (int p = 0; p < 6; ++p) {
+    PFOR(w, 1) S.B[p][p] = sqrtf(S.B[p][p]);
+    KBJ_SYNC();
+    PFOR(w, 6) { int i = p + 1 + w; if (i <= 6) S.B[i][p] /= S.B[p][p]; }
+    KBJ_SYNC();
+    PFOR(w, 36) { int i = p + 1 + w / 6, j = p + 1 + w % 6; if (i <= 6 && j <= 5 && j <= i) S.B[i][j] -= S.B[i][p] * S.B[j][p]; }
+    KBJ_SYNC();
+  }
+  PFOR(w, 1) {
+    float x[6];
+    for (int p = 5; p >= 0; --p) {
+      float s = S.B[6][p];
+      for (int i = p + 1; i < 6; ++i) s -= S.B[i][p] * x[i];
+      x[p] = s / S.B[p][p];
+      S.vec[p] = x[p];
+    }
+  }
+  KBJ_SYNC();
+  PFOR(c, 4) {
+    float x[5];
+    for (int p = 4; p >= 0; --p) {
+      float s = S.A[c][11][p];
+      for (int i = p + 1; i < 5; ++i) s -= S.A[c][i][p] * x[i];
+      for (int i = 5; i < 11; ++i) s -= S.A[c][i][p] * S.vec[i - 5];
+      x[p] = s / S.A[c][p][p];
+      S.vec[10 + 5 * c - p] = x[p];
+    }
+  }
+  KBJ_SYNC();
+}
+
+// y = M v using the tree sparsity
+KBJ_DEV float mul_M_row(const KbjShared& S, int i, const float* v) {
+  float s = 0;
+  if (i < 6) { for (int j = 0; j < NV; ++j) s += S.M[i][j] * v[j]; }
+  else {
+    for (int j = 0; j < 6; ++j) s += S.M[i][j] * v[j];
+    int c0 = 6 + 5 * ((i - 6) / 5);
+    for (int j = c0; j < c0 + 5; ++j) s += S.M[i][j] * v[j];
+  }
+  return s;
+}
+
+// ---- constraint rows -------------------------------------------------------------------------------------------
+KBJ_DEV float impedance(float dist, const float* solimp) {
+  float dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f), dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
+  float width = fmaxf(solimp[2], 1e-15f), mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f), power = fmaxf(solimp[4], 1.0f);
+  float x = fabsf(dist) / width;
+  if (x >= 1) return dmax;
+  if (x <= 0) return dmin;
+  float y;
+  if (power == 1.0f) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
+  else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
+  return dmin + y * (dmax - dmin);
+}
+KBJ_DEV void kbi(const float* solref, const float* solimp, float dist, float dt, float& k, float& b, float& imp) {
+  float dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
+  float tc = fmaxf(solref[0], 2 * dt), dr = solref[1];
+  k = 1 / (dmax * dmax * tc * tc * dr * dr);
+  b = 2 / (dmax * tc);
+  imp = impedance(dist, solimp);
+}
+
+KBJ_DEV void phys_make_constraints(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
+  const float* qpos = S.es + KBJ_ES_QPOS;
+  const float* qvel = S.es + KBJ_ES_QVEL;
+  PFOR(u, NU) {
+    int dof = 6 + u;
+    float k, b, imp;
+    kbi(m.fric_solref, m.fric_solimp, 0.0f, pc.dt, k, b, imp);
+    float fl = S.ep[KBJ_EP_FRICLOSS + dof];
+    float Rr = fmaxf(1e-15f, (1 - imp) / imp * m.dof_invweight0[dof]);
+    S.R[u] = Rr; S.D[u] = 1 / Rr; S.aref[u] = -b * qvel[dof]; S.floss[u] = fl; S.active[u] = fl > 0;
+    float q = qpos[7 + u];
+    float dlo = q - m.dof_range[dof][0], dhi = m.dof_range[dof][1] - q;
+    float pos = fminf(dlo, dhi), sgn = dlo < dhi ? 1.0f : -1.0f;
+    int r = ROW_LIM + u;
+    S.lsign[u] = sgn; S.floss[r] = 0;
+    if (pos < 0) {
+      kbi(m.limit_solref, m.limit_solimp, pos, pc.dt, k, b, imp);
+      float Rl = fmaxf(1e-15f, (1 - imp) / imp * m.dof_invweight0[dof]);
+      S.R[r] = Rl; S.D[r] = 1 / Rl; S.aref[r] = -b * sgn * qvel[dof] - k * imp * pos; S.active[r] = 1;
+    } else { S.R[r] = 0; S.D[r] = 0; S.aref[r] = 0; S.active[r] = 0; }
+  }
+  PFOR(r, 32) {
+    int ci = r / 4, e = r % 4, leg = ci / 4, row = ROW_CON + r;
+    S.floss[row] = 0;
+    if (!S.conact[ci]) {
+      S.active[row] = 0; S.D[row] = 0; S.R[row] = 0; S.aref[row] = 0;
+      for (int k = 0; k < 12; ++k) S.Jc[r][k] = 0;
+      continue;
+    }
+    float off[3] = {S.conpos[ci][0] - S.com[0], S.conpos[ci][1] - S.com[1], S.conpos[ci][2] - S.com[2]};
+    float mu = S.ep[KBJ_EP_MU];
+    int ax = e / 2;
+    float sg = (e & 1) ? -mu : mu, vel = 0;
+    for (int k = 0; k < 11; ++k) {
+      int dk = k < 6 ? k : 6 + 5 * leg + (k - 6);
+      float t[3];
+      cross3(S.cdof[dk], off, t);
+      float jn = S.cdof[dk][5] + t[2], jt = S.cdof[dk][3 + ax] + t[ax];
+      float j = jn + sg * jt;
+      S.Jc[r][k] = j;
+      vel += j * qvel[dk];
+    }
+    S.Jc[r][11] = 0;
+    float k_, b_, imp;
+    kbi(m.contact_solref, m.contact_solimp, S.condist[ci], pc.dt, k_, b_, imp);
+    float tran = m.body_invweight0[leg ? 12 : 7][0];
+    float invw = (tran + mu * mu * tran) * 2 * mu * mu;
+    float Rc = fmaxf(1e-15f, (1 - imp) / imp * invw);
+    S.R[row] = Rc; S.D[row] = 1 / Rc; S.aref[row] = -b_ * vel - k_ * imp * S.condist[ci]; S.active[row] = 1;
+  }
+  KBJ_SYNC();
+}
+
+// residual of every row for a candidate acceleration q: jar = J q - aref
+KBJ_DEV void rows_residual(KbjShared& S, const float* q) {
+  PFOR(i, NV) S.Ma[i] = mul_M_row(S, i, q);
+  PFOR(r, NROW) {
+    float x = 0;
+    if (S.active[r]) {
+      if (r < ROW_LIM) x = q[6 + r];
+      else if (r < ROW_CON) x = S.lsign[r - ROW_LIM] * q[6 + r - ROW_LIM];
+      else {
+        int rr = r - ROW_CON, leg = rr / 16;
+        for (int k = 0; k < 6; ++k) x += S.Jc[rr][k] * q[k];
+        for (int k = 6; k < 11; ++k) x += S.Jc[rr][k] * q[6 + 5 * leg + (k - 6)];
+      }
+      x -= S.aref[r];
+    }
+    S.jar[r] = x;
+  }
+  KBJ_SYNC();
+}
+
+// per-lane cost / derivative contributions: lane l < 20 owns friction+limit rows of joint l, lanes 32..63 one contact row
+KBJ_DEV float row_cost(const KbjShared& S, int r, float x) {
+  if (!S.active[r]) return 0.0f;
+  float D = S.D[r];
+  if (r < ROW_LIM) {
+    float f = S.floss[r], Rr = S.R[r];
+    if (x <= -Rr * f) return f * (-0.5f * Rr * f - x);
+    if (x >= Rr * f) return f * (-0.5f * Rr * f + x);
+    return 0.5f * D * x * x;
+  }
+  return x < 0 ? 0.5f * D * x * x : 0.0f;
+}
+KBJ_DEV void row_deriv(const KbjShared& S, int r, float a, float& d1, float& d2) {
+  if (!S.active[r]) return;
+  float jv = S.jv[r], x = S.jar[r] + a * jv, D = S.D[r];
+  if (r < ROW_LIM) {
+    float f = S.floss[r], Rr = S.R[r];
+    if (x <= -Rr * f) d1 -= f * jv;
+    else if (x >= Rr * f) d1 += f * jv;
+    else { d1 += D * x * jv; d2 += D * jv * jv; }
+  } else if (x < 0) { d1 += D * x * jv; d2 += D * jv * jv; }
+}
+KBJ_DEV float total_cost(const KbjShared& S, const float* q) {
+  return wsum(64, [&](int l) {
+    float c = 0;
+    if (l < NV) c += 0.5f * (S.Ma[l] - S.qfrc_smooth[l]) * (q[l] - S.qacc_smooth[l]);
+    if (l < NU) c += row_cost(S, l, S.jar[l]) + row_cost(S, ROW_LIM + l, S.jar[ROW_LIM + l]);
+    if (l >= 32) c += row_cost(S, ROW_CON + l - 32, S.jar[ROW_CON + l - 32]);
+    return c;
+  });
+}
+
+KBJ_DEV void rows_force(KbjShared& S) {
+  PFOR(r, NROW) {
+    float f = 0;
+    int quad = 0;
+    if (S.active[r]) {
+      float x = S.jar[r], D = S.D[r];
+      if (r < ROW_LIM) {
+        float fl = S.floss[r], Rr = S.R[r];
+        if (x <= -Rr * fl) f = fl;
+        else if (x >= Rr * fl) f = -fl;
+        else { f = -D * x; quad = 1; }
+      } else if (x < 0) { f = -D * x; quad = 1; }
+    }
+    S.force[r] = f; S.quad[r] = quad;
+  }
+  KBJ_SYNC();
+}
+
+// Newton iterations on the convex constraint cost with an exact (safeguarded Newton) line search
+KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
+  arrow_solve(S, S.qfrc_smooth, false);
+  PFOR(i, NV) S.qacc_smooth[i] = S.vec[i];
+  KBJ_SYNC();
+  // warm-start selection: the cheaper of the previous step's acceleration and the unconstrained one
+  rows_residual(S, S.qacc_smooth);
+  float cs = total_cost(S, S.qacc_smooth);
+  KBJ_SYNC();
+  rows_residual(S, S.warm);
+  float cw = total_cost(S, S.warm);
+  KBJ_SYNC();
+  bool use_warm = cw < cs;
+  PFOR(i, NV) S.qacc[i] = use_warm ? S.warm[i] : S.qacc_smooth[i];
+  KBJ_SYNC();
+  if (!use_warm) rows_residual(S, S.qacc);
+  float scale = 1.0f / (m.meaninertia * NV);
+  int iters = 0;
+  for (int it = 0; it < pc.iterations; ++it) {
+    rows_force(S);
+    PFOR(i, NV) {
+      float g = S.Ma[i] - S.qfrc_smooth[i];
+      if (i < 6) { for (int r = 0; r < 32; ++r) g -= S.Jc[r][i] * S.force[ROW_CON + r]; }
+      else {
+        int u = i - 6;
+        g -= S.force[u] + S.lsign[u] * S.force[ROW_LIM + u];
+        if (i < 16) { int leg = u / 5, col = 6 + u % 5; for (int r = 16 * leg; r < 16 * leg + 16; ++r) g -= S.Jc[r][col] * S.force[ROW_CON + r]; }
+      }
+      S.grad[i] = g;
+      S.mv[i] = -g;  // right-hand side of the Newton system
+    }
+    KBJ_SYNC();
+    float gg = wsum(NV, [&](int l) { return S.grad[l] * S.grad[l]; });
+    if (scale * sqrtf(gg) < pc.tolerance) break;
+    arrow_solve(S, S.mv, true);
+    PFOR(i, NV) S.search[i] = S.vec[i];
+    KBJ_SYNC();
+    PFOR(i, NV) S.mv[i] = mul_M_row(S, i, S.search);
+    PFOR(r, NROW) {
+      float x = 0;
+      if (S.active[r]) {
+        if (r < ROW_LIM) x = S.search[6 + r];
+        else if (r < ROW_CON) x = S.lsign[r - ROW_LIM] * S.search[6 + r - ROW_LIM];
+        else {
+          int rr = r - ROW_CON, leg = rr / 16;
+          for (int k = 0; k < 6; ++k) x += S.Jc[rr][k] * S.search[k];
+          for (int k = 6; k < 11; ++k) x += S.Jc[rr][k] * S.search[6 + 5 * leg + (k - 6)];
+        }
+      }
+      S.jv[r] = x;
+    }
+    KBJ_SYNC();
+    float g1, g2;
+    wsum2(NV, [&](int l, float& a, float& b) { a = S.search[l] * (S.Ma[l] - S.qfrc_smooth[l]); b = S.search[l] * S.mv[l]; }, g1, g2);
+    auto eval = [&](float a, float& d1, float& d2) {
+      wsum2(64, [&](int l, float& x1, float& x2) {
+        if (l < NU) { row_deriv(S, l, a, x1, x2); row_deriv(S, ROW_LIM + l, a, x1, x2); }
+        if (l >= 32) row_deriv(S, ROW_CON + l - 32, a, x1, x2);
+      }, d1, d2);
+      d1 += g1 + a * g2; d2 += g2;
+    };
+    float d1, d2, alpha = 0;
+    eval(0.0f, d1, d2);
+    if (d1 < 0 && d2 > 0) {
+      float lo = 0, hi = 0;
+      bool hi_valid = false;
+      float a = -d1 / d2;
+      for (int ls = 0; ls < pc.ls_iterations; ++ls) {
+        eval(a, d1, d2);
+        if (d1 < 0) lo = a; else { hi = a; hi_valid = true; }
+        float an = a - d1 / d2;
+        if (an <= lo || (hi_valid && an >= hi)) an = hi_valid ? 0.5f * (lo + hi) : 2 * a;
+        a = an;
+      }
+      alpha = a;
+    }
+    PFOR(i, NV) { S.qacc[i] += alpha * S.search[i]; S.Ma[i] += alpha * S.mv[i]; }
+    PFOR(r, NROW) S.jar[r] += alpha * S.jv[r];
+    KBJ_SYNC();
+    iters = it + 1;
+    if (alpha == 0) break;
+  }
+  rows_force(S);
+  S.iters = iters;
+}
+
+KBJ_DEV void phys_sensors(KbjShared& S, const kbj_model& m) {
+  PFOR(w, 3) {
+    if (w == 0) {
+      float iq[4], sm[9];
+      quat_mul(S.xquat[23], m.imu_quat, iq);
+      for (int k = 0; k < 4; ++k) S.imuquat[k] = iq[k];
+      quat_to_mat(iq, sm);
+      matT_vec(sm, S.cvel[23], S.gyro);
+      float g[3] = {0, 0, -1};
+      rotate_by_quat(g, iq, true, S.pg);
+    } else {
+      int foot = w - 1, body = foot ? 12 : 7;
+      float tot = 0;
+      for (int ci = 4 * foot; ci < 4 * foot + 4; ++ci) {
+        if (!S.conact[ci]) continue;
+        float rel[3] = {S.conpos[ci][0] - S.xpos[body][0], S.conpos[ci][1] - S.xpos[body][1], S.conpos[ci][2] - S.xpos[body][2]}, loc[3];
+        matT_vec(S.xmat[body], rel, loc);
+        bool inside = true;
+        for (int k = 0; k < 3; ++k) inside = inside && fabsf(loc[k] - m.site_pos[foot][k]) <= m.site_size[foot][k];
+        if (!inside) continue;
+        for (int e = 0; e < 4; ++e) tot += S.force[ROW_CON + 4 * ci + e];
+      }
+      S.touch[foot] = tot;
+    }
+  }
+  KBJ_SYNC();
+}
+
+// full forward pass on the state in S.es with torques S.ctrl and (if S.pushing) wrench S.push
+KBJ_DEV void phys_forward(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
+  phys_kinematics(S, m);
+  phys_com(S);
+  phys_crb_mass(S);
+  phys_collide_vel(S, m);
+  phys_smooth_forces(S, m);
+  phys_make_constraints(S, m, pc);
+  phys_solve(S, m, pc);
+  phys_sensors(S, m);
+}
+
+// semi-implicit Euler; also refreshes the warm start
+KBJ_DEV void phys_integrate(KbjShared& S, const PhysConst& pc) {
+  float* qpos = S.es + KBJ_ES_QPOS;
+  float* qvel = S.es + KBJ_ES_QVEL;
+  PFOR(i, NV) { qvel[i] += pc.dt * S.qacc[i]; S.warm[i] = S.qacc[i]; }
+  KBJ_SYNC();
+  PFOR(i, NV) {
+    if (i < 3) qpos[i] += pc.dt * qvel[i];
+    else if (i == 3) {
+      float w[3] = {qvel[3], qvel[4], qvel[5]};
+      float nrm = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), ang = nrm * pc.dt;
+      if (ang > 0) {
+        float s = sinf(ang / 2) / nrm;
+        float dq[4] = {cosf(ang / 2), s * w[0], s * w[1], s * w[2]}, q[4];
+        quat_mul(qpos + 3, dq, q);
+        quat_norm(q);
+        for (int k = 0; k < 4; ++k) qpos[3 + k] = q[k];
+      }
+    } else if (i >= 6) qpos[1 + i] += pc.dt * qvel[i];
+  }
+  KBJ_SYNC();
+}
+
+}  // namespace kbj

@@ -1,0 +1,192 @@
+"""ctypes binding of libkbj.so (C ABI: include/kbj.h).
+
+This is the only place the product touches native code. There is NO fallback: if the HIP library is
+missing or a call fails, a KbjError is raised. torch is used only as the owner of device memory and
+streams (tensor.data_ptr(), torch.cuda.current_stream()).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+from ..spec import layout as L
+
+_CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libkbj.so")
+
+
+class KbjError(RuntimeError):
+    pass
+
+
+class Carry(C.Structure):
+    _fields_ = [("actor_hc_d", C.c_void_p), ("critic_hc_d", C.c_void_p), ("lpf_d", C.c_void_p)]
+
+
+class Traj(C.Structure):
+    _fields_ = [("T", C.c_int32), ("N", C.c_int32),
+                ("actor_obs_d", C.c_void_p), ("critic_obs_d", C.c_void_p), ("aux_d", C.c_void_p),
+                ("action_d", C.c_void_p), ("logp_d", C.c_void_p), ("value_d", C.c_void_p), ("reward_d", C.c_void_p),
+                ("carry0_actor_hc_d", C.c_void_p), ("carry0_critic_hc_d", C.c_void_p), ("carry0_lpf_d", C.c_void_p)]
+
+
+_vp, _i, _u32, _f, _sz = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t
+_cfgp = C.POINTER(L.Config)
+
+# every symbol include/kbj.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "kbj_create": (_i, [C.POINTER(_vp), _vp, _sz, _cfgp, _i, _vp]),
+    "kbj_destroy": (_i, [_vp]),
+    "kbj_last_error": (C.c_char_p, [_vp]),
+    "kbj_sizeof_model": (_i, []),
+    "kbj_sizeof_config": (_i, []),
+    "kbj_synchronize": (_i, [_vp]),
+    "kbj_env_reset_all": (_i, [_vp, _u32, _vp, _vp, _vp]),
+    "kbj_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "kbj_env_get_state": (_i, [_vp, _vp, _vp]),
+    "kbj_env_set_state": (_i, [_vp, _vp, _vp]),
+    "kbj_rewards": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "kbj_param_count": (_sz, [_cfgp]),
+    "kbj_actor_param_count": (_sz, [_cfgp]),
+    "kbj_init_params": (_i, [_vp, _u32, _vp]),
+    "kbj_policy_step": (_i, [_vp, _vp, _vp, _vp, C.POINTER(Carry), _u32, _u32, _i, _vp, _vp, _vp]),
+    "kbj_carry_reset": (_i, [_vp, C.POINTER(Carry), _vp, _i]),
+    "kbj_rollout": (_i, [_vp, _vp, C.POINTER(Carry), _u32, _u32, C.POINTER(Traj)]),
+    "kbj_gae": (_i, [_vp, C.POINTER(Traj), _vp, _vp]),
+    "kbj_ppo_grad": (_i, [_vp, _vp, C.POINTER(Traj), _vp, _i, _vp, _vp, _vp, _vp]),
+    "kbj_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _f]),
+    "kbj_profile_begin": (_i, [_vp]),
+    "kbj_profile_end": (_i, [_vp, C.POINTER(_f), C.POINTER(_i), C.POINTER(_f), C.POINTER(_i)]),
+}
+
+
+def build_library(force: bool = False) -> str:
+    """Compile libkbj.so for gfx950 with hipcc (works without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", _CSRC, "-s", "clean"])
+    subprocess.check_call(["make", "-C", _CSRC, "-s", "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise KbjError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
+                           "There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError here means the library does not match include/kbj.h
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def _ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (must be contiguous)."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        if not t.is_contiguous():
+            raise KbjError("tensor passed to libkbj must be contiguous")
+        return t.data_ptr()
+    return t.ctypes.data
+
+
+class Context:
+    """RAII wrapper of kbj_ctx."""
+
+    def __init__(self, model: L.Model, config: L.Config, device: int = 0, stream: int | None = None):
+        self.lib = load_library()
+        if self.lib.kbj_sizeof_model() != C.sizeof(L.Model) or self.lib.kbj_sizeof_config() != C.sizeof(L.Config):
+            raise KbjError("struct layout mismatch between spec/layout.py and libkbj.so")
+        self.model, self.config = model, config
+        self._h = _vp()
+        blob = C.string_at(C.addressof(model), C.sizeof(model))
+        rc = self.lib.kbj_create(C.byref(self._h), blob, len(blob), C.byref(config), device, stream)
+        if rc != 0:
+            raise KbjError(self.lib.kbj_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self.lib.kbj_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def call(self, name: str, *args):
+        rc = getattr(self.lib, name)(self._h, *args)
+        if rc != 0:
+            raise KbjError(f"{name}: {self.lib.kbj_last_error(self._h).decode()}")
+
+    # ---- thin typed helpers ----
+    def synchronize(self):
+        self.call("kbj_synchronize")
+
+    def env_reset_all(self, seed, actor0, critic0, aux0):
+        self.call("kbj_env_reset_all", seed, _ptr(actor0), _ptr(critic0), _ptr(aux0))
+
+    def env_step(self, action, aux_t, actor_next, critic_next, aux_next):
+        self.call("kbj_env_step", _ptr(action), _ptr(aux_t), _ptr(actor_next), _ptr(critic_next), _ptr(aux_next))
+
+    def env_get_state(self):
+        import numpy as np
+        N = self.config.num_envs
+        ep = np.zeros((N, L.EP["SIZE"]), np.float32)
+        es = np.zeros((N, L.ES["SIZE"]), np.float32)
+        self.call("kbj_env_get_state", _ptr(ep), _ptr(es))
+        return ep, es
+
+    def env_set_state(self, ep, es):
+        import numpy as np
+        ep = None if ep is None else np.ascontiguousarray(ep, np.float32)
+        es = None if es is None else np.ascontiguousarray(es, np.float32)
+        self.call("kbj_env_set_state", _ptr(ep), _ptr(es))
+
+    def rewards(self, aux, T, reward, comps=None):
+        self.call("kbj_rewards", _ptr(aux), T, _ptr(reward), _ptr(comps))
+
+    def param_count(self) -> int:
+        return int(self.lib.kbj_param_count(C.byref(self.config)))
+
+    def actor_param_count(self) -> int:
+        return int(self.lib.kbj_actor_param_count(C.byref(self.config)))
+
+    def init_params(self, seed, params):
+        self.call("kbj_init_params", seed, _ptr(params))
+
+    def policy_step(self, params, actor_obs, critic_obs, carry: Carry, seed, step_index, argmax, action, logp, value):
+        self.call("kbj_policy_step", _ptr(params), _ptr(actor_obs), _ptr(critic_obs), C.byref(carry), seed, step_index,
+                  int(argmax), _ptr(action), _ptr(logp), _ptr(value))
+
+    def carry_reset(self, carry: Carry, done, stride):
+        self.call("kbj_carry_reset", C.byref(carry), _ptr(done), stride)
+
+    def rollout(self, params, carry: Carry, seed, first_step_index, traj: Traj):
+        self.call("kbj_rollout", _ptr(params), C.byref(carry), seed, first_step_index, C.byref(traj))
+
+    def gae(self, traj: Traj, adv, target):
+        self.call("kbj_gae", C.byref(traj), _ptr(adv), _ptr(target))
+
+    def ppo_grad(self, params, traj: Traj, env_idx, B, adv, target, grad, metrics):
+        self.call("kbj_ppo_grad", _ptr(params), C.byref(traj), _ptr(env_idx), B, _ptr(adv), _ptr(target), _ptr(grad),
+                  _ptr(metrics))
+
+    def adamw_step(self, params, m, v, grad, step, grad_scale=1.0):
+        self.call("kbj_adamw_step", _ptr(params), _ptr(m), _ptr(v), _ptr(grad), step, grad_scale)
+
+    def profile_begin(self):
+        self.call("kbj_profile_begin")
+
+    def profile_end(self):
+        a, b, c, d = _f(), _i(), _f(), _i()
+        self.call("kbj_profile_end", C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+        return dict(env_step_ms=a.value, env_step_launches=b.value, nn_ms=c.value, nn_launches=d.value)

@@ -30,6 +30,9 @@ struct Rng {
   // uniform in [0,1) with 24 bits: identical value in the fp32 and fp64 instantiations
   double uniform(int stream, uint32_t a, uint32_t b) const { uint32_t x, y; bits(stream, a, b, x, y); return (x >> 8) * (1.0 / 16777216.0); }
   double uniform(int stream, uint32_t a, uint32_t b, double lo, double hi) const { return lo + (hi - lo) * uniform(stream, a, b); }
+  // fp32 draw with a single rounding, lo + (hi - lo) u as one fma: every value that is stored in the fp32 state
+  // records or decides a branch is drawn this way in BOTH precisions, so fp32/fp64/HIP agree bit for bit on them
+  float uf(int stream, uint32_t a, uint32_t b, float lo, float hi) const { return std::fmaf(hi - lo, (float)uniform(stream, a, b), lo); }
   template <class R> R normal(int stream, uint32_t a, uint32_t b) const {  // Box-Muller
     uint32_t x, y; bits(stream, a, b, x, y);
     R u1 = (R)(((x >> 8) + 1) * (1.0 / 16777216.0)), u2 = (R)((y >> 8) * (1.0 / 16777216.0));
@@ -131,55 +134,55 @@ template <class R> struct Env {
   // physics randomisers + actuator / sensor per-episode draws (train.py:1097-1132,1158-1161,1191-1198,1780)
   void randomize() {
     uint32_t e = episode();
-    bool on = c->enable_randomizers != 0;
-    auto U = [&](uint32_t idx, double lo, double hi) { return on ? rng.uniform(KBJ_RNG_RANDOMIZE, e, idx, lo, hi) : 0.5 * (lo + hi); };
+    bool on = c->enable_randomizers != 0, noise = c->enable_noise != 0;
+    auto U = [&](uint32_t idx, float lo, float hi) { return rng.uf(KBJ_RNG_RANDOMIZE, e, idx, lo, hi); };
     for (int b = 0; b < NB; ++b) {
-      double s = on ? U(140 + b, 1 - c->inertia_scale, 1 + c->inertia_scale) : 1.0;
-      ep[KBJ_EP_MASS + b] = (float)(m->body_mass[b] * s);
+      float s = on ? U(140 + b, 1 - c->inertia_scale, 1 + c->inertia_scale) : 1.0f;
+      ep[KBJ_EP_MASS + b] = m->body_mass[b] * s;
       for (int k = 0; k < 3; ++k) {
-        ep[KBJ_EP_INERTIA + 3 * b + k] = (float)(m->body_inertia[b][k] * s);
-        ep[KBJ_EP_IPOS + 3 * b + k] = (float)(m->body_ipos[b][k] + (b && on ? U(60 + 3 * b + k, -c->com_jitter, c->com_jitter) : 0.0));
+        ep[KBJ_EP_INERTIA + 3 * b + k] = m->body_inertia[b][k] * s;
+        ep[KBJ_EP_IPOS + 3 * b + k] = m->body_ipos[b][k] + ((b && on) ? U(60 + 3 * b + k, -c->com_jitter, c->com_jitter) : 0.0f);
       }
     }
     for (int d_ = 0; d_ < NV; ++d_) {
-      ep[KBJ_EP_FRICLOSS + d_] = (float)(m->dof_frictionloss[d_] * (on ? U(d_, c->fricloss_scale_lo, c->fricloss_scale_hi) : 1.0));
-      ep[KBJ_EP_ARMATURE + d_] = (float)(m->dof_armature[d_] * (on ? U(26 + d_, c->armature_scale_lo, c->armature_scale_hi) : 1.0));
+      ep[KBJ_EP_FRICLOSS + d_] = m->dof_frictionloss[d_] * (on ? U(d_, c->fricloss_scale_lo, c->fricloss_scale_hi) : 1.0f);
+      ep[KBJ_EP_ARMATURE + d_] = m->dof_armature[d_] * (on ? U(26 + d_, c->armature_scale_lo, c->armature_scale_hi) : 1.0f);
     }
     for (int cp = 0; cp < NCAP; ++cp) {
-      ep[KBJ_EP_CAP_RAD + cp] = (float)(m->cap_radius[cp] * (on ? U(170 + cp, 1 - c->cap_radius_scale, 1 + c->cap_radius_scale) : 1.0));
-      ep[KBJ_EP_CAP_HALF + cp] = (float)(m->cap_halflen[cp] * (on ? U(174 + cp, 1 - c->cap_length_scale, 1 + c->cap_length_scale) : 1.0));
+      ep[KBJ_EP_CAP_RAD + cp] = m->cap_radius[cp] * (on ? U(170 + cp, 1 - c->cap_radius_scale, 1 + c->cap_radius_scale) : 1.0f);
+      ep[KBJ_EP_CAP_HALF + cp] = m->cap_halflen[cp] * (on ? U(174 + cp, 1 - c->cap_length_scale, 1 + c->cap_length_scale) : 1.0f);
       for (int k = 0; k < 3; ++k)
-        ep[KBJ_EP_CAP_POS + 3 * cp + k] = (float)(m->cap_pos[cp][k] + (on ? U(180 + 3 * cp + k, -c->cap_jitter[k], c->cap_jitter[k]) : 0.0));
+        ep[KBJ_EP_CAP_POS + 3 * cp + k] = m->cap_pos[cp][k] + (on ? U(180 + 3 * cp + k, -c->cap_jitter[k], c->cap_jitter[k]) : 0.0f);
     }
     // the capsules have priority 1 over the floor (robot.mjcf class "collision"), so MuJoCo takes the capsule's
     // friction and the floor-friction randomiser (train.py:1112-1114) scales nothing; kept as a per-env field.
     ep[KBJ_EP_MU] = m->contact_mu;
     for (int u = 0; u < NU; ++u) {
-      ep[KBJ_EP_KP + u] = (float)(m->kp[u] * (on ? U(200 + u, 1.0 / c->kp_scale, c->kp_scale) : 1.0));
-      ep[KBJ_EP_KD + u] = (float)(m->kd[u] * (on ? U(220 + u, 1.0 / c->kd_scale, c->kd_scale) : 1.0));
-      ep[KBJ_EP_TAULIM + u] = (float)(m->tau_limit[u] * (on ? U(240 + u, c->torque_limit_scale_low, 1.0) : 1.0));
-      ep[KBJ_EP_ACTBIAS + u] = (float)(on ? U(260 + u, -c->action_bias_scale, c->action_bias_scale) : 0.0);
-      ep[KBJ_EP_JPBIAS + u] = (float)(c->enable_noise ? rng.uniform(KBJ_RNG_RANDOMIZE, e, 280 + u, -c->jpos_bias_range, c->jpos_bias_range) : 0.0);
+      ep[KBJ_EP_KP + u] = m->kp[u] * (on ? U(200 + u, 1.0f / c->kp_scale, c->kp_scale) : 1.0f);
+      ep[KBJ_EP_KD + u] = m->kd[u] * (on ? U(220 + u, 1.0f / c->kd_scale, c->kd_scale) : 1.0f);
+      ep[KBJ_EP_TAULIM + u] = m->tau_limit[u] * (on ? U(240 + u, c->torque_limit_scale_low, 1.0f) : 1.0f);
+      ep[KBJ_EP_ACTBIAS + u] = on ? U(260 + u, -c->action_bias_scale, c->action_bias_scale) : 0.0f;
+      ep[KBJ_EP_JPBIAS + u] = noise ? U(280 + u, -c->jpos_bias_range, c->jpos_bias_range) : 0.0f;
     }
-    for (int k = 0; k < 3; ++k) ep[KBJ_EP_PGBIAS + k] = (float)(c->enable_noise ? rng.uniform(KBJ_RNG_RANDOMIZE, e, 300 + k, -c->pg_bias, c->pg_bias) : 0.0);
-    ep[KBJ_EP_PGLAG] = (float)(c->enable_noise ? rng.uniform(KBJ_RNG_RANDOMIZE, e, 303, c->pg_lag_lo, c->pg_lag_hi) : 0.0);
-    double lat = rng.uniform(KBJ_RNG_RANDOMIZE, e, 304, c->latency_lo, c->latency_hi);
-    ep[KBJ_EP_LATENCY] = (float)std::floor(lat / c->dt + 0.5);
+    for (int k = 0; k < 3; ++k) ep[KBJ_EP_PGBIAS + k] = noise ? U(300 + k, -c->pg_bias, c->pg_bias) : 0.0f;
+    ep[KBJ_EP_PGLAG] = noise ? U(303, c->pg_lag_lo, c->pg_lag_hi) : 0.0f;
+    float lat = U(304, c->latency_lo, c->latency_hi);
+    ep[KBJ_EP_LATENCY] = std::floor(lat / c->dt + 0.5f);
     for (int k = KBJ_EP_MU + 1; k < KBJ_EP_SIZE; ++k) ep[k] = 0;
   }
 
   // UnifiedCommand.initial_command (train.py:724-766); `off` separates reset-time draws from switch draws
   void sample_command(uint32_t a, uint32_t off, float* cmd) {
     if (c->command_mode == 1) { for (int k = 0; k < KBJ_NCMD; ++k) cmd[k] = c->fixed_command[k]; return; }
-    auto U = [&](uint32_t idx, double lo, double hi) { return (float)rng.uniform(KBJ_RNG_COMMAND, a, off + idx, lo, hi); };
+    auto U = [&](uint32_t idx, float lo, float hi) { return rng.uf(KBJ_RNG_COMMAND, a, off + idx, lo, hi); };
     float vx = U(2, c->vx_lo, c->vx_hi), vy = U(3, c->vy_lo, c->vy_hi), wz = U(4, c->wz_lo, c->wz_hi);
     float bh = U(5, c->bh_lo, c->bh_hi), rx = U(6, c->rx_lo, c->rx_hi), ry = U(7, c->ry_lo, c->ry_hi);
     float arms[10];
     for (int j = 0; j < 10; ++j) {
       // uniform and bernoulli share one key in the reference (train.py:734-737): the same draw u decides both
-      double u = rng.uniform(KBJ_RNG_COMMAND, a, off + 8 + j);
-      double lo = m->dof_range[16 + j][0], hi = m->dof_range[16 + j][1];
-      arms[j] = u < 0.5 ? (float)(lo + (hi - lo) * u) : 0.0f;
+      float u = (float)rng.uniform(KBJ_RNG_COMMAND, a, off + 8 + j);
+      float lo = m->dof_range[16 + j][0], hi = m->dof_range[16 + j][1];
+      arms[j] = u < 0.5f ? std::fmaf(hi - lo, u, lo) : 0.0f;
     }
     uint32_t b0, b1; rng.bits(KBJ_RNG_COMMAND, a, off + 1, b0, b1);
     int mode = (int)(b0 % 6u);
@@ -199,19 +202,19 @@ template <class R> struct Env {
     episode() += 1;
     uint32_t e = episode();
     randomize();
-    auto U = [&](uint32_t idx, double s) { return rng.uniform(KBJ_RNG_RESET, e, idx, -s, s); };
+    auto U = [&](uint32_t idx, float s) { return rng.uf(KBJ_RNG_RESET, e, idx, -s, s); };
     for (int k = 0; k < NQ; ++k) qpos[k] = m->qpos0[k];
-    for (int u = 0; u < NU; ++u) qpos[7 + u] = (R)(m->joint_bias[u] + U(u, c->reset_joint_pos_scale));
+    for (int u = 0; u < NU; ++u) qpos[7 + u] = (R)(float)(m->joint_bias[u] + U(u, c->reset_joint_pos_scale));
     for (int i = 0; i < NV; ++i) { qvel[i] = 0; warm[i] = 0; }
     for (int u = 0; u < NU; ++u) qvel[6 + u] = (R)U(20 + u, c->reset_joint_vel_scale);
     qvel[0] = (R)U(40, c->reset_base_vel_xy_scale); qvel[1] = (R)U(41, c->reset_base_vel_xy_scale);
-    double yaw = U(42, 3.14159265358979323846);
+    float yaw = U(42, 3.14159265358979323846f);
     qpos[3] = (R)std::cos(yaw / 2); qpos[4] = 0; qpos[5] = 0; qpos[6] = (R)std::sin(yaw / 2);
     qpos[0] = (R)U(43, c->reset_xy_range); qpos[1] = (R)U(44, c->reset_xy_range);
     for (int u = 0; u < NU; ++u) es[KBJ_ES_ACT_PREV + u] = m->joint_bias[u];
     for (int k = 0; k < 6; ++k) es[KBJ_ES_PUSH + k] = 0;
     es[KBJ_ES_PUSH_REM] = 0;
-    es[KBJ_ES_PUSH_NXT] = (float)std::floor(rng.uniform(KBJ_RNG_RANDOMIZE, e, 310, c->push_int_lo, c->push_int_hi) / c->ctrl_dt);
+    es[KBJ_ES_PUSH_NXT] = std::floor(rng.uf(KBJ_RNG_RANDOMIZE, e, 310, c->push_int_lo, c->push_int_hi) / c->ctrl_dt);
     es[KBJ_ES_TIME] = 0;
     sample_command(stepctr(), 32, es + KBJ_ES_CMD);
     phy.p.load(ep);
@@ -257,8 +260,8 @@ template <class R> struct Env {
     for (int u = 0; u < NU; ++u) {
       R range = std::max((R)m->joint_bias[u] - (R)m->joint_lo[u], (R)m->joint_hi[u] - (R)m->joint_bias[u]);
       R q = qpos[7 + u], v = qvel[6 + u];
-      R qn = q + phy.p.jpbias[u] + (noise ? (R)rng.uniform(KBJ_RNG_OBS_NOISE, st, u, -c->jpos_noise, c->jpos_noise) : 0);
-      R vn = v + (noise ? (R)rng.uniform(KBJ_RNG_OBS_NOISE, st, 20 + u, -c->jvel_noise, c->jvel_noise) : 0);
+      R qn = q + phy.p.jpbias[u] + (noise ? (R)rng.uf(KBJ_RNG_OBS_NOISE, st, u, -c->jpos_noise, c->jpos_noise) : 0);
+      R vn = v + (noise ? (R)rng.uf(KBJ_RNG_OBS_NOISE, st, 20 + u, -c->jvel_noise, c->jvel_noise) : 0);
       actor[u] = (float)((qn - (R)m->joint_bias[u]) / range); actor[20 + u] = (float)(vn / 10);
       critic[u] = (float)((q - (R)m->joint_bias[u]) / range); critic[20 + u] = (float)(v / 10);
     }
@@ -314,11 +317,11 @@ template <class R> struct Env {
       if (es[KBJ_ES_PUSH_REM] > 0) { es[KBJ_ES_PUSH_REM] -= 1; pushing = true; }
       else if (es[KBJ_ES_PUSH_NXT] <= 0) {
         for (int k = 0; k < 3; ++k) {
-          es[KBJ_ES_PUSH + k] = (float)rng.uniform(KBJ_RNG_PUSH, st, k, -c->push_max_force, c->push_max_force);
-          es[KBJ_ES_PUSH + 3 + k] = (float)rng.uniform(KBJ_RNG_PUSH, st, 3 + k, -c->push_max_torque, c->push_max_torque);
+          es[KBJ_ES_PUSH + k] = rng.uf(KBJ_RNG_PUSH, st, k, -c->push_max_force, c->push_max_force);
+          es[KBJ_ES_PUSH + 3 + k] = rng.uf(KBJ_RNG_PUSH, st, 3 + k, -c->push_max_torque, c->push_max_torque);
         }
-        es[KBJ_ES_PUSH_REM] = (float)std::floor(rng.uniform(KBJ_RNG_PUSH, st, 6, c->push_dur_lo, c->push_dur_hi) / c->ctrl_dt);
-        es[KBJ_ES_PUSH_NXT] = (float)std::floor(rng.uniform(KBJ_RNG_PUSH, st, 7, c->push_int_lo, c->push_int_hi) / c->ctrl_dt);
+        es[KBJ_ES_PUSH_REM] = std::floor(rng.uf(KBJ_RNG_PUSH, st, 6, c->push_dur_lo, c->push_dur_hi) / c->ctrl_dt);
+        es[KBJ_ES_PUSH_NXT] = std::floor(rng.uf(KBJ_RNG_PUSH, st, 7, c->push_int_lo, c->push_int_hi) / c->ctrl_dt);
         pushing = true;
       } else es[KBJ_ES_PUSH_NXT] -= 1;
       if (pushing) for (int k = 0; k < 6; ++k) push[k] = es[KBJ_ES_PUSH + k];

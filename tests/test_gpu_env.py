@@ -1,0 +1,155 @@
+"""GPU parity tests of the env kernels (kbj_env_reset_all / kbj_env_step / kbj_rewards) through the C ABI,
+against the CPU oracle on identical seeds. Run with `pytest -m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+from kbot_joystick_amd.spec import compiler, layout as L
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(model, cfg):
+    import torch
+    from kbot_joystick_amd.host import binding as B
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return B.Context(model, cfg, device=0, stream=torch.cuda.current_stream().cuda_stream), torch
+
+
+def _obs(torch, N):
+    dev = "cuda:0"
+    return (torch.zeros(N, L.LD_ACTOR, device=dev), torch.zeros(N, L.LD_CRITIC, device=dev), torch.zeros(N, L.AUX["SIZE"], device=dev))
+
+
+@pytest.mark.parametrize("which", ["kbot-headless", "kbot"])
+def test_reset_matches_oracle(which):
+    from oracle import oracle as O
+    m = compiler.load_model(which)
+    N = 64
+    cfg = L.default_config(num_envs=N)
+    ctx, torch = _ctx(m, cfg)
+    a, c, x = _obs(torch, N)
+    ctx.env_reset_all(5, a, c, x)
+    ctx.synchronize()
+    ep, es = ctx.env_get_state()
+    o = O.Oracle(m, cfg, seed=5, precision="f32")
+    a0, c0, x0 = o.reset_all()
+    assert np.array_equal(o.ep, ep)
+    assert np.array_equal(o.es[:, 0:27], es[:, 0:27])
+    assert np.abs(o.es[:, 28:54] - es[:, 28:54]).max() == 0
+    assert np.array_equal(o.es[:, 80:125], es[:, 80:125])
+    assert np.array_equal(o.es[:, 128:130].view(np.uint32), es[:, 128:130].view(np.uint32))
+    assert np.abs(a0 - a.cpu().numpy()).max() < 1e-4
+    assert (np.abs(c0 - c.cpu().numpy()) / (1 + np.abs(c0))).max() < 1e-3
+    assert np.abs(x0 - x.cpu().numpy()).max() < 1e-4
+    ctx.close()
+
+
+def test_teacher_forced_steps_match_oracle(model):
+    from oracle import oracle as O
+    N = 128
+    cfg = L.default_config(num_envs=N)
+    ctx, torch = _ctx(model, cfg)
+    a, c, x = _obs(torch, N)
+    a2, c2, x2 = _obs(torch, N)
+    ctx.env_reset_all(11, a, c, x)
+    o = O.Oracle(model, cfg, seed=11, precision="f32")
+    a0, c0, x0 = o.reset_all()
+    rng = np.random.default_rng(0)
+    errs = {k: [] for k in H.TOL}
+    ndone = 0
+    for t in range(30):
+        act = H.random_actions(model, rng, N)
+        ctx.env_set_state(o.ep, o.es)                                # teacher forcing
+        aux_t = torch.from_numpy(x0.copy()).cuda()
+        auxo = x0.copy()
+        a0, c0, x0 = o.step(act, auxo)
+        ctx.env_step(torch.from_numpy(act).cuda(), aux_t, a2, c2, x2)
+        ctx.synchronize()
+        ep, es = ctx.env_get_state()
+        auxe = aux_t.cpu().numpy()
+        assert np.array_equal(auxo[:, L.AUX["DONE"]], auxe[:, L.AUX["DONE"]])
+        ndone += int((auxo[:, L.AUX["DONE"]] != 0).sum())
+        assert np.array_equal(o.es[:, 122:125], es[:, 122:125])
+        assert np.array_equal(o.es[:, 128:130].view(np.uint32), es[:, 128:130].view(np.uint32))
+        assert np.array_equal(o.es[:, 100:116], es[:, 100:116])
+        assert np.array_equal(o.ep, ep)
+        for k, v in H.state_errors(o.es, es).items():
+            errs[k].append(v)
+        assert np.median(np.abs(a0 - a2.cpu().numpy()).max(1)) < 1e-4
+        assert np.median((np.abs(c0 - c2.cpu().numpy()) / (1 + np.abs(c0))).max(1)) < 1e-3
+    assert ndone > 0
+    H.check_error_distribution(errs, label="hip vs oracle ")
+    ctx.close()
+
+
+def test_free_running_rollout_statistics(model):
+    """Without teacher forcing trajectories diverge chaotically, but episode statistics must agree."""
+    from oracle import oracle as O
+    N = 256
+    cfg = L.default_config(num_envs=N)
+    ctx, torch = _ctx(model, cfg)
+    a, c, x = _obs(torch, N)
+    a2, c2, x2 = _obs(torch, N)
+    ctx.env_reset_all(3, a, c, x)
+    o = O.Oracle(model, cfg, seed=3, precision="f32")
+    a0, c0, x0 = o.reset_all()
+    rng = np.random.default_rng(1)
+    T = 60
+    aux_g = torch.zeros(T + 1, N, L.AUX["SIZE"], device="cuda:0")
+    aux_g[0] = x
+    aux_o = np.zeros((T + 1, N, L.AUX["SIZE"]), np.float32)
+    aux_o[0] = x0
+    for t in range(T):
+        act = H.random_actions(model, rng, N, 0.1)
+        a0, c0, nx = o.step(act, aux_o[t])
+        aux_o[t + 1] = nx
+        ctx.env_step(torch.from_numpy(act).cuda(), aux_g[t], a2, c2, aux_g[t + 1])
+    ctx.synchronize()
+    g = aux_g.cpu().numpy()
+    # first steps agree closely, later only statistically
+    assert np.abs(g[0] - aux_o[0]).max() < 1e-4
+    assert np.median(np.abs(g[3, :, 0:6] - aux_o[3, :, 0:6])) < 1e-3
+    done_g, done_o = (g[:T, :, 70] != 0).mean(), (aux_o[:T, :, 70] != 0).mean()
+    assert abs(done_g - done_o) < 0.3 * max(done_o, 1e-3) + 2e-3
+    assert abs(g[:T, :, 51:53].mean() - aux_o[:T, :, 51:53].mean()) < 0.1 * aux_o[:T, :, 51:53].mean()
+    # rewards kernel on the oracle's trajectory: bit-for-bit same inputs -> tight tolerance
+    rew = torch.zeros(T, N, device="cuda:0")
+    comps = torch.zeros(T, N, L.NREW, device="cuda:0")
+    ctx.rewards(torch.from_numpy(aux_o[:T].copy()).cuda(), T, rew, comps)
+    ctx.synchronize()
+    r_o, c_o = o.rewards(aux_o[:T])
+    assert np.abs(comps.cpu().numpy() - c_o).max() < 2e-4
+    assert np.abs(rew.cpu().numpy() - r_o).max() < 2e-4
+    ctx.close()
+
+
+def test_full_size_properties(model):
+    """BASELINE config size (8192 envs): invariants that do not need the oracle."""
+    N = 8192
+    cfg = L.default_config(num_envs=N)
+    ctx, torch = _ctx(model, cfg)
+    a, c, x = _obs(torch, N)
+    a2, c2, x2 = _obs(torch, N)
+    ctx.env_reset_all(1, a, c, x)
+    act = torch.from_numpy(np.tile(np.array(model.joint_bias, np.float32), (N, 1))).cuda()
+    for t in range(5):
+        ctx.env_step(act, x, a2, c2, x2)
+        x, x2 = x2, x
+    ctx.synchronize()
+    ep, es = ctx.env_get_state()
+    assert np.isfinite(es[:, :125]).all() and np.isfinite(a2.cpu().numpy()).all() and np.isfinite(c2.cpu().numpy()).all()
+    assert np.abs(np.linalg.norm(es[:, 3:7], axis=1) - 1).max() < 1e-5
+    assert (es[:, 129].view(np.uint32) == 5).all()
+    # determinism: same seed, same actions -> identical bits
+    ctx2, _ = _ctx(model, cfg)
+    b, d, y = _obs(torch, N)
+    b2, d2, y2 = _obs(torch, N)
+    ctx2.env_reset_all(1, b, d, y)
+    for t in range(5):
+        ctx2.env_step(act, y, b2, d2, y2)
+        y, y2 = y2, y
+    ctx2.synchronize()
+    ep2, es2 = ctx2.env_get_state()
+    assert np.array_equal(es.view(np.uint32), es2.view(np.uint32))
+    ctx.close(); ctx2.close()
