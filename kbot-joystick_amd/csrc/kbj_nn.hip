@@ -1,18 +1,368 @@
-// kbj_nn.hip — actor-critic kernels (entry points stubbed until the MFMA path lands later this round;
-// every stub fails loudly, nothing falls back to the CPU)
+// kbj_nn.hip — LSTM actor-critic + PPO update on the GPU (C ABI: kbj_policy_step, kbj_rollout, kbj_gae, kbj_ppo_grad,
+// kbj_adamw_step, kbj_init_params). SURVEY.md §8 rows a4-a13. All matrix products run on the fp32 matrix cores
+// (kbj_gemm.h); activations needed by back-propagation-through-time are stashed in HBM (sized for 288 GB).
 #include <hip/hip_runtime.h>
+#include <vector>
+#include <cmath>
 #include "kbj_ctx.h"
-int kbj_nn_create(kbj_ctx*) { return 0; }
-void kbj_nn_destroy(kbj_ctx*) {}
-#define NI(ctx, name) return kbj_fail(ctx, name ": not implemented yet")
-extern "C" {
-size_t kbj_param_count(const kbj_config*) { return 0; }
-size_t kbj_actor_param_count(const kbj_config*) { return 0; }
-int kbj_init_params(kbj_ctx* c, uint32_t, float*) { NI(c, "kbj_init_params"); }
-int kbj_policy_step(kbj_ctx* c, const float*, const float*, const float*, kbj_carry*, uint32_t, uint32_t, int, float*, float*, float*) { NI(c, "kbj_policy_step"); }
-int kbj_carry_reset(kbj_ctx* c, kbj_carry*, const float*, int) { NI(c, "kbj_carry_reset"); }
-int kbj_rollout(kbj_ctx* c, const float*, kbj_carry*, uint32_t, uint32_t, kbj_traj*) { NI(c, "kbj_rollout"); }
-int kbj_gae(kbj_ctx* c, const kbj_traj*, float*, float*) { NI(c, "kbj_gae"); }
-int kbj_ppo_grad(kbj_ctx* c, const float*, const kbj_traj*, const int32_t*, int, const float*, const float*, float*, float*) { NI(c, "kbj_ppo_grad"); }
-int kbj_adamw_step(kbj_ctx* c, float*, float*, float*, const float*, int64_t, float) { NI(c, "kbj_adamw_step"); }
+#include "kbj_gemm.h"
+#include "kbj_nn_kernels.h"
+
+using namespace kbj;
+
+namespace {
+
+struct NetOff {  // float offsets into the flat parameter vector (kbj.h layout = equinox leaf order)
+  size_t w_in, b_in, w_ih[2], w_hh[2], b[2], w_out, b_out;
+  int nin, nout, ld_obs;
+};
+
+struct TrainBufs {  // per net, minibatch-sized
+  float *obs, *X0, *G[2], *Hm[2], *Hout[2], *Cm[2], *TanhC[2], *Out, *dOut, *dHa, *dHb, *dG, *dhm, *dcm[2];
+};
+
+struct NnWs {
+  int H = 0, N = 0, B = 0, T = 0;
+  NetOff net[2];
+  size_t nparams = 0, nactor = 0;
+  // rollout scratch
+  float *rX[2] = {nullptr, nullptr}, *rG[2] = {nullptr, nullptr}, *rOut[2] = {nullptr, nullptr};
+  float* joint_bias_d = nullptr;
+  // training
+  TrainBufs tb[2];
+  float *keep = nullptr, *act = nullptr, *logp_old = nullptr, *val_old = nullptr, *adv = nullptr, *target = nullptr;
+  float *y = nullptr, *sd = nullptr, *logp = nullptr, *ent = nullptr, *value = nullptr, *dlogp = nullptr, *dvalue = nullptr, *lpf0 = nullptr;
+  double* stats = nullptr;  // [0..1] adv stats, [2..9] metric accumulators, [10] grad sumsq
+  std::vector<void*> allocs;
+};
+
+NnWs* ws_of(kbj_ctx* ctx) { return reinterpret_cast<NnWs*>(ctx->nn_ws); }
+
+void layout_params(NnWs& w, int H) {
+  size_t off = 0;
+  for (int n = 0; n < 2; ++n) {
+    NetOff& o = w.net[n];
+    o.nin = n == 0 ? KBJ_NOBS_ACTOR : KBJ_NOBS_CRITIC;
+    o.ld_obs = n == 0 ? KBJ_LD_ACTOR : KBJ_LD_CRITIC;
+    o.nout = n == 0 ? 2 * KBJ_NU : 1;
+    o.w_in = off; off += (size_t)H * o.nin;
+    o.b_in = off; off += H;
+    for (int l = 0; l < 2; ++l) {
+      o.w_ih[l] = off; off += (size_t)4 * H * H;
+      o.w_hh[l] = off; off += (size_t)4 * H * H;
+      o.b[l] = off; off += (size_t)4 * H;
+    }
+    o.w_out = off; off += (size_t)o.nout * H;
+    o.b_out = off; off += o.nout;
+    if (n == 0) w.nactor = off;
+  }
+  w.nparams = off;
 }
+
+template <class T> int dalloc(kbj_ctx* ctx, NnWs& w, T** p, size_t count) {
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, count * sizeof(T));
+  if (e != hipSuccess) return kbj_fail(ctx, std::string("hipMalloc (nn workspace): ") + hipGetErrorString(e));
+  w.allocs.push_back(q);
+  *p = reinterpret_cast<T*>(q);
+  return 0;
+}
+
+inline dim3 g1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
+
+// y = x W^T + b  (x [M][K] lda, W [N][K])
+void linear_fwd(hipStream_t s, const float* x, int lda, const float* W, int ldw, const float* bias, float* y, int ldy, int M, int N, int K, int beta) {
+  GemmArgs g{x, W, y, bias, M, N, K, lda, ldw, ldy, beta, 1, nullptr};
+  gemm_launch<true, true>(s, g);
+}
+// dx = dy W   (dy [M][K=nout] , W [K][N])
+void linear_bwd_input(hipStream_t s, const float* dy, int lddy, const float* W, int ldw, float* dx, int lddx, int M, int N, int K, int beta) {
+  GemmArgs g{dy, W, dx, nullptr, M, N, K, lddy, ldw, lddx, beta, 1, nullptr};
+  gemm_launch<true, false>(s, g);
+}
+// dW[Nout][Nin] += dy^T x  (dy [R][Nout], x [R][Nin]); split-K over the R samples with atomics (dW pre-zeroed by the caller)
+void linear_bwd_weight(hipStream_t s, const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, int Nout, int Nin, int R) {
+  int tiles = ((Nout + 63) / 64) * ((Nin + 63) / 64);
+  int sk = std::max(1, std::min(64, 512 / std::max(1, tiles)));
+  sk = std::min(sk, (R + 255) / 256);
+  GemmArgs g{dy, x, dW, nullptr, Nout, Nin, R, lddy, ldx, lddw, 1, sk < 2 ? 2 : sk, nullptr};  // always the atomic path: accumulates into dW
+  gemm_launch<false, false>(s, g);
+}
+
+}  // namespace
+
+int kbj_nn_create(kbj_ctx* ctx) {
+  NnWs* w = new NnWs();
+  ctx->nn_ws = w;
+  const kbj_config& c = ctx->cfg_h;
+  w->H = c.hidden_size; w->N = c.num_envs; w->B = c.batch_size; w->T = c.rollout_len;
+  if (w->B <= 0 || w->B > w->N) return kbj_fail(ctx, "kbj_create: batch_size must be in [1, num_envs]");
+  layout_params(*w, w->H);
+  size_t N = w->N, H = w->H, B = w->B, T = w->T;
+  for (int n = 0; n < 2; ++n) {
+    if (dalloc(ctx, *w, &w->rX[n], N * H)) return -1;
+    if (dalloc(ctx, *w, &w->rG[n], N * 4 * H)) return -1;
+    if (dalloc(ctx, *w, &w->rOut[n], N * 40)) return -1;
+  }
+  if (dalloc(ctx, *w, &w->joint_bias_d, KBJ_NU)) return -1;
+  if (hipMemcpy(w->joint_bias_d, ctx->model_h.joint_bias, KBJ_NU * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return kbj_fail(ctx, "hipMemcpy joint_bias");
+  size_t R = T * B;
+  for (int n = 0; n < 2; ++n) {
+    TrainBufs& t = w->tb[n];
+    if (dalloc(ctx, *w, &t.obs, R * w->net[n].ld_obs)) return -1;
+    if (dalloc(ctx, *w, &t.X0, R * H)) return -1;
+    for (int l = 0; l < 2; ++l) {
+      if (dalloc(ctx, *w, &t.G[l], R * 4 * H)) return -1;
+      if (dalloc(ctx, *w, &t.Hm[l], (T + 1) * B * H)) return -1;
+      if (dalloc(ctx, *w, &t.Hout[l], R * H)) return -1;
+      if (dalloc(ctx, *w, &t.Cm[l], (T + 1) * B * H)) return -1;
+      if (dalloc(ctx, *w, &t.TanhC[l], R * H)) return -1;
+      if (dalloc(ctx, *w, &t.dcm[l], B * H)) return -1;
+    }
+    if (dalloc(ctx, *w, &t.Out, R * 40)) return -1;
+    if (dalloc(ctx, *w, &t.dOut, R * 40)) return -1;
+    if (dalloc(ctx, *w, &t.dHa, R * H)) return -1;
+    if (dalloc(ctx, *w, &t.dHb, R * H)) return -1;
+    if (dalloc(ctx, *w, &t.dG, R * 4 * H)) return -1;
+    if (dalloc(ctx, *w, &t.dhm, B * H)) return -1;
+  }
+  float** small[] = {&w->keep, &w->logp_old, &w->val_old, &w->adv, &w->target, &w->logp, &w->ent, &w->value, &w->dlogp, &w->dvalue};
+  for (float** p : small) if (dalloc(ctx, *w, p, R)) return -1;
+  if (dalloc(ctx, *w, &w->act, R * KBJ_NU)) return -1;
+  if (dalloc(ctx, *w, &w->y, R * KBJ_NU)) return -1;
+  if (dalloc(ctx, *w, &w->sd, R * KBJ_NU)) return -1;
+  if (dalloc(ctx, *w, &w->lpf0, B * KBJ_NU)) return -1;
+  if (dalloc(ctx, *w, &w->stats, 16)) return -1;
+  return 0;
+}
+
+void kbj_nn_destroy(kbj_ctx* ctx) {
+  NnWs* w = ws_of(ctx);
+  if (!w) return;
+  for (void* p : w->allocs) hipFree(p);
+  delete w;
+  ctx->nn_ws = nullptr;
+}
+
+extern "C" {
+
+size_t kbj_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size); return w.nparams; }
+size_t kbj_actor_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size); return w.nactor; }
+
+int kbj_init_params(kbj_ctx* ctx, uint32_t seed, float* params_d) {
+  if (!ctx || !params_d) return kbj_fail(ctx, "kbj_init_params: null argument");
+  NnWs& w = *ws_of(ctx);
+  int H = w.H;
+  uint32_t leaf = 0;
+  auto fill = [&](size_t off, size_t n, int fan_in) {
+    hipLaunchKernelGGL(init_uniform_kernel, g1(n), dim3(256), 0, ctx->stream, params_d + off, n, 1.0f / std::sqrt((float)fan_in), seed, leaf++);
+  };
+  for (int n = 0; n < 2; ++n) {
+    const NetOff& o = w.net[n];
+    fill(o.w_in, (size_t)H * o.nin, o.nin); fill(o.b_in, H, o.nin);
+    for (int l = 0; l < 2; ++l) { fill(o.w_ih[l], (size_t)4 * H * H, H); fill(o.w_hh[l], (size_t)4 * H * H, H); fill(o.b[l], (size_t)4 * H, H); }
+    fill(o.w_out, (size_t)o.nout * H, H); fill(o.b_out, o.nout, H);
+  }
+  KBJ_CHECK_LAUNCH(ctx, "init_uniform_kernel");
+  return 0;
+}
+
+int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_d, const float* critic_obs_d, kbj_carry* carry, uint32_t seed,
+                    uint32_t step_index, int argmax, float* action_d, float* logp_d, float* value_d) {
+  if (!ctx || !params_d || !actor_obs_d || !critic_obs_d || !carry || !action_d || !logp_d || !value_d) return kbj_fail(ctx, "kbj_policy_step: null argument");
+  NnWs& w = *ws_of(ctx);
+  const kbj_config& c = ctx->cfg_h;
+  hipStream_t s = ctx->stream;
+  int N = w.N, H = w.H;
+  KbjTimed timed(ctx, true);
+  const float* obs[2] = {actor_obs_d, critic_obs_d};
+  float* hc[2] = {carry->actor_hc_d, carry->critic_hc_d};
+  for (int n = 0; n < 2; ++n) {
+    const NetOff& o = w.net[n];
+    linear_fwd(s, obs[n], o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, w.rX[n], H, N, H, o.nin, 0);
+    const float* x = w.rX[n];
+    for (int l = 0; l < 2; ++l) {
+      float* h = hc[n] + (size_t)(2 * l) * N * H;
+      float* cc = hc[n] + (size_t)(2 * l + 1) * N * H;
+      linear_fwd(s, x, H, params_d + o.w_ih[l], H, params_d + o.b[l], w.rG[n], 4 * H, N, 4 * H, H, 0);
+      linear_fwd(s, h, H, params_d + o.w_hh[l], H, nullptr, w.rG[n], 4 * H, N, 4 * H, H, 1);
+      CellFwdArgs2 ca;
+      ca.a[0] = CellFwdArgs{w.rG[n], cc, h, cc, nullptr, nullptr, nullptr, nullptr, N, H};
+      hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((N * H + 255) / 256, 1), dim3(256), 0, s, ca);
+      x = h;
+    }
+    linear_fwd(s, x, H, params_d + o.w_out, H, params_d + o.b_out, w.rOut[n], 40, N, o.nout, H, 0);
+  }
+  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
+  hipLaunchKernelGGL(actor_head_sample_kernel, g1(N, 64), dim3(64), 0, s, w.rOut[0], actor_obs_d, carry->lpf_d, w.joint_bias_d, hp, seed,
+                     (uint32_t)c.env_id_offset, step_index, argmax, N, action_d, logp_d);
+  hipLaunchKernelGGL(critic_value_kernel, g1(N), dim3(256), 0, s, w.rOut[1], 40, N, value_d);
+  KBJ_CHECK_LAUNCH(ctx, "kbj_policy_step");
+  return 0;
+}
+
+int kbj_carry_reset(kbj_ctx* ctx, kbj_carry* carry, const float* done_d, int done_stride) {
+  if (!ctx || !carry || !done_d) return kbj_fail(ctx, "kbj_carry_reset: null argument");
+  NnWs& w = *ws_of(ctx);
+  size_t n = (size_t)4 * w.N * w.H;
+  hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, ctx->stream, carry->actor_hc_d, 4, w.N, w.H, carry->lpf_d, done_d, done_stride);
+  hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, ctx->stream, carry->critic_hc_d, 4, w.N, w.H, (float*)nullptr, done_d, done_stride);
+  KBJ_CHECK_LAUNCH(ctx, "carry_reset_kernel");
+  return 0;
+}
+
+int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t seed, uint32_t first_step_index, kbj_traj* tr) {
+  if (!ctx || !params_d || !carry || !tr) return kbj_fail(ctx, "kbj_rollout: null argument");
+  NnWs& w = *ws_of(ctx);
+  int N = w.N, H = w.H, T = tr->T;
+  if (tr->N != N || T <= 0) return kbj_fail(ctx, "kbj_rollout: trajectory shape does not match the context");
+  hipStream_t s = ctx->stream;
+  size_t la = KBJ_LD_ACTOR, lc = KBJ_LD_CRITIC, lx = KBJ_AUX_SIZE;
+  // observation row T of the previous rollout is row 0 of this one
+  KBJ_HIP(ctx, hipMemcpyAsync(tr->actor_obs_d, tr->actor_obs_d + (size_t)T * N * la, N * la * sizeof(float), hipMemcpyDeviceToDevice, s));
+  KBJ_HIP(ctx, hipMemcpyAsync(tr->critic_obs_d, tr->critic_obs_d + (size_t)T * N * lc, N * lc * sizeof(float), hipMemcpyDeviceToDevice, s));
+  KBJ_HIP(ctx, hipMemcpyAsync(tr->aux_d, tr->aux_d + (size_t)T * N * lx, N * lx * sizeof(float), hipMemcpyDeviceToDevice, s));
+  size_t hcb = (size_t)4 * N * H * sizeof(float);
+  KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_actor_hc_d, carry->actor_hc_d, hcb, hipMemcpyDeviceToDevice, s));
+  KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_critic_hc_d, carry->critic_hc_d, hcb, hipMemcpyDeviceToDevice, s));
+  KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_lpf_d, carry->lpf_d, (size_t)N * KBJ_NU * sizeof(float), hipMemcpyDeviceToDevice, s));
+  for (int t = 0; t < T; ++t) {
+    int rc = kbj_policy_step(ctx, params_d, tr->actor_obs_d + (size_t)t * N * la, tr->critic_obs_d + (size_t)t * N * lc, carry, seed,
+                             first_step_index + (uint32_t)t, 0, tr->action_d + (size_t)t * N * KBJ_NU, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N);
+    if (rc) return rc;
+    rc = kbj_env_step(ctx, tr->action_d + (size_t)t * N * KBJ_NU, tr->aux_d + (size_t)t * N * lx, tr->actor_obs_d + (size_t)(t + 1) * N * la,
+                      tr->critic_obs_d + (size_t)(t + 1) * N * lc, tr->aux_d + (size_t)(t + 1) * N * lx);
+    if (rc) return rc;
+    rc = kbj_carry_reset(ctx, carry, tr->aux_d + (size_t)t * N * lx + KBJ_AUX_DONE, KBJ_AUX_SIZE);
+    if (rc) return rc;
+  }
+  return kbj_rewards(ctx, tr->aux_d, T, tr->reward_d, nullptr);
+}
+
+int kbj_gae(kbj_ctx* ctx, const kbj_traj* tr, float* adv_d, float* target_d) {
+  if (!ctx || !tr || !adv_d || !target_d) return kbj_fail(ctx, "kbj_gae: null argument");
+  const kbj_config& c = ctx->cfg_h;
+  hipLaunchKernelGGL(gae_kernel, g1(tr->N, 64), dim3(64), 0, ctx->stream, tr->value_d, tr->reward_d, tr->aux_d, tr->T, tr->N, c.gamma, c.lam, adv_d, target_d);
+  KBJ_CHECK_LAUNCH(ctx, "gae_kernel");
+  return 0;
+}
+
+int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const int32_t* env_idx_d, int B, const float* adv_d, const float* target_d,
+                 float* grad_d, float* metrics_d) {
+  if (!ctx || !params_d || !tr || !env_idx_d || !adv_d || !target_d || !grad_d || !metrics_d) return kbj_fail(ctx, "kbj_ppo_grad: null argument");
+  NnWs& w = *ws_of(ctx);
+  const kbj_config& c = ctx->cfg_h;
+  if (B != w.B) return kbj_fail(ctx, "kbj_ppo_grad: B must equal config.batch_size");
+  int T = tr->T, N = tr->N, H = w.H;
+  if (T != w.T || N != w.N) return kbj_fail(ctx, "kbj_ppo_grad: trajectory shape does not match the context");
+  hipStream_t s = ctx->stream;
+  const int R = T * B;
+  KbjTimed timed(ctx, true);
+  const int* idx = env_idx_d;
+  // ---- gather the minibatch ----
+  auto gather = [&](const float* src, int wdt, int lds, float* dst, int ldd) {
+    hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)R * wdt), dim3(256), 0, s, src, idx, T, N, B, wdt, lds, ldd, dst);
+  };
+  gather(tr->actor_obs_d, KBJ_LD_ACTOR, KBJ_LD_ACTOR, w.tb[0].obs, KBJ_LD_ACTOR);
+  gather(tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);
+  gather(tr->action_d, KBJ_NU, KBJ_NU, w.act, KBJ_NU);
+  gather(tr->logp_d, 1, 1, w.logp_old, 1);
+  gather(tr->value_d, 1, 1, w.val_old, 1);
+  gather(adv_d, 1, 1, w.adv, 1);
+  gather(target_d, 1, 1, w.target, 1);
+  hipLaunchKernelGGL(gather_keep_kernel, g1(R), dim3(256), 0, s, tr->aux_d, idx, T, N, B, w.keep);
+  const float* carry0[2] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d};
+  for (int n = 0; n < 2; ++n)
+    for (int l = 0; l < 2; ++l) {  // carry at the start of the trajectory: T = 1 gather of [N][H] planes
+      hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * H), dim3(256), 0, s, carry0[n] + (size_t)(2 * l) * N * H, idx, 1, N, B, H, H, H, w.tb[n].Hm[l]);
+      hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * H), dim3(256), 0, s, carry0[n] + (size_t)(2 * l + 1) * N * H, idx, 1, N, B, H, H, H, w.tb[n].Cm[l]);
+    }
+  hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * KBJ_NU), dim3(256), 0, s, tr->carry0_lpf_d, idx, 1, N, B, KBJ_NU, KBJ_NU, KBJ_NU, w.lpf0);
+  // ---- forward through time ----
+  for (int n = 0; n < 2; ++n) {
+    const NetOff& o = w.net[n];
+    TrainBufs& t = w.tb[n];
+    linear_fwd(s, t.obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, t.X0, H, R, H, o.nin, 0);
+    const float* xin = t.X0;
+    for (int l = 0; l < 2; ++l) {
+      linear_fwd(s, xin, H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
+      for (int tt = 0; tt < T; ++tt) {
+        float* G = t.G[l] + (size_t)tt * B * 4 * H;
+        linear_fwd(s, t.Hm[l] + (size_t)tt * B * H, H, params_d + o.w_hh[l], H, nullptr, G, 4 * H, B, 4 * H, H, 1);
+        CellFwdArgs2 ca;
+        ca.a[0] = CellFwdArgs{G, t.Cm[l] + (size_t)tt * B * H, t.Hout[l] + (size_t)tt * B * H, t.dhm /*scratch c_out*/, t.Hm[l] + (size_t)(tt + 1) * B * H,
+                              t.Cm[l] + (size_t)(tt + 1) * B * H, t.TanhC[l] + (size_t)tt * B * H, w.keep + (size_t)tt * B, B, H};
+        hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((B * H + 255) / 256, 1), dim3(256), 0, s, ca);
+      }
+      xin = t.Hout[l];
+    }
+    linear_fwd(s, xin, H, params_d + o.w_out, H, params_d + o.b_out, t.Out, 40, R, o.nout, H, 0);
+  }
+  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
+  hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[0].Out, w.tb[0].obs, w.keep, w.lpf0, w.joint_bias_d, hp, T, B, w.y, w.sd);
+  hipLaunchKernelGGL(gaussian_logp_kernel, g1(R), dim3(256), 0, s, w.y, w.sd, w.act, R, w.logp, w.ent);
+  hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, s, w.tb[1].Out, 40, R, w.value);
+  // ---- loss ----
+  KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), s));
+  PpoParams pp{c.clip_param, c.value_clip, c.value_loss_coef, c.entropy_coef, c.log_ratio_clip, c.adv_eps};
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(256), 0, s, w.adv, R, w.stats);
+  hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, s, w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
+                     w.stats + 2);
+  hipLaunchKernelGGL(ppo_metrics_kernel, dim3(1), dim3(1), 0, s, w.stats + 2, w.stats, pp, R, metrics_d);
+  // ---- backward ----
+  KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), s));
+  KBJ_HIP(ctx, hipMemsetAsync(w.tb[0].dOut, 0, (size_t)R * 40 * sizeof(float), s));
+  KBJ_HIP(ctx, hipMemsetAsync(w.tb[1].dOut, 0, (size_t)R * 40 * sizeof(float), s));
+  hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[0].Out, w.y, w.sd, w.act, w.keep, w.dlogp,
+                     -c.entropy_coef / (float)R, hp, T, B, w.tb[0].dOut);
+  KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[1].dOut, 40 * sizeof(float), w.dvalue, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, s));
+  for (int n = 0; n < 2; ++n) {
+    const NetOff& o = w.net[n];
+    TrainBufs& t = w.tb[n];
+    // output projection
+    linear_bwd_weight(s, t.dOut, 40, t.Hout[1], H, grad_d + o.w_out, H, o.nout, H, R);
+    hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 64), dim3(256), 0, s, t.dOut, R, o.nout, 40, grad_d + o.b_out);
+    linear_bwd_input(s, t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
+    float* dh_above = t.dHa;
+    float* dx_out = t.dHb;
+    for (int l = 1; l >= 0; --l) {
+      for (int tt = T - 1; tt >= 0; --tt) {
+        bool last = tt == T - 1;
+        CellBwdArgs2 cb;
+        cb.a[0] = CellBwdArgs{t.G[l] + (size_t)tt * B * 4 * H, t.TanhC[l] + (size_t)tt * B * H, t.Cm[l] + (size_t)tt * B * H, dh_above + (size_t)tt * B * H,
+                              last ? nullptr : t.dhm, last ? nullptr : t.dcm[tt & 1 ? 0 : 1], w.keep + (size_t)tt * B, t.dG + (size_t)tt * B * 4 * H,
+                              t.dcm[tt & 1], B, H};
+        hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((B * H + 255) / 256, 1), dim3(256), 0, s, cb);
+        if (tt > 0) linear_bwd_input(s, t.dG + (size_t)tt * B * 4 * H, 4 * H, params_d + o.w_hh[l], H, t.dhm, H, B, H, 4 * H, 0);
+      }
+      const float* xin = l == 0 ? t.X0 : t.Hout[0];
+      linear_bwd_weight(s, t.dG, 4 * H, t.Hm[l], H, grad_d + o.w_hh[l], H, 4 * H, H, R);
+      linear_bwd_weight(s, t.dG, 4 * H, xin, H, grad_d + o.w_ih[l], H, 4 * H, H, R);
+      hipLaunchKernelGGL(colsum_kernel, dim3((4 * H + 63) / 64, 64), dim3(256), 0, s, t.dG, R, 4 * H, 4 * H, grad_d + o.b[l]);
+      linear_bwd_input(s, t.dG, 4 * H, params_d + o.w_ih[l], H, dx_out, H, R, H, 4 * H, 0);
+      std::swap(dh_above, dx_out);
+    }
+    // input projection (dh_above now holds dX0)
+    linear_bwd_weight(s, dh_above, H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
+    hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, 64), dim3(256), 0, s, dh_above, R, H, H, grad_d + o.b_in);
+  }
+  KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_grad");
+  return 0;
+}
+
+int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const float* grad_d, int64_t step, float grad_scale) {
+  if (!ctx || !params_d || !m_d || !v_d || !grad_d || step < 1) return kbj_fail(ctx, "kbj_adamw_step: bad argument");
+  NnWs& w = *ws_of(ctx);
+  const kbj_config& c = ctx->cfg_h;
+  hipStream_t s = ctx->stream;
+  double* sumsq = w.stats + 10;
+  KBJ_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double), s));
+  hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, s, grad_d, w.nparams, grad_scale, sumsq);
+  AdamParams ap{c.learning_rate, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay, c.max_grad_norm,
+                (float)(1.0 - std::pow((double)c.adam_b1, (double)step)), (float)(1.0 - std::pow((double)c.adam_b2, (double)step)), grad_scale};
+  hipLaunchKernelGGL(adamw_kernel, g1(w.nparams), dim3(256), 0, s, params_d, m_d, v_d, grad_d, w.nparams, sumsq, ap);
+  KBJ_CHECK_LAUNCH(ctx, "adamw_kernel");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,316 @@
+// kbj_nn_kernels.h — element-wise / scan kernels of the LSTM actor-critic and the PPO update (device code).
+// GEMMs live in kbj_gemm.h. Reference semantics: Actor/Critic forward train.py:913-941, 993-1004; equinox
+// LSTMCell (gate order i,f,g,o, single bias); distrax diagonal Gaussian; carry reset on done train.py:1502-1506.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kbj_model.h"
+
+namespace kbj {
+
+constexpr float kLog2Pi = 1.8378770664093453f;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
+
+// ---- LSTM cell, forward ----------------------------------------------------------------------------------------
+// G [M][4H] pre-activations (bias included) -> overwritten with the gate activations (i,f,g,o);
+// c_prev [M][H]; writes h_out, c_out (may alias c_prev) and, when given, the masked copies consumed by the next
+// time step (h*keep, c*keep with keep[m] = 1 - done) and tanh(c) for the backward pass.
+struct CellFwdArgs {
+  float* G; const float* c_prev; float* h_out; float* c_out; float* hm_next; float* cm_next; float* tanhc; const float* keep;
+  int M, H;
+};
+struct CellFwdArgs2 { CellFwdArgs a[2]; };
+__global__ void lstm_cell_fwd_kernel(CellFwdArgs2 args) {
+  const CellFwdArgs& a = args.a[blockIdx.y];
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.M * a.H) return;
+  int m = idx / a.H, u = idx - m * a.H;
+  float* g = a.G + (size_t)m * 4 * a.H;
+  float i = sigmoidf_(g[u]), f = sigmoidf_(g[a.H + u]), gg = tanhf(g[2 * a.H + u]), o = sigmoidf_(g[3 * a.H + u]);
+  float c = f * a.c_prev[idx] + i * gg;
+  float tc = tanhf(c), h = o * tc;
+  g[u] = i; g[a.H + u] = f; g[2 * a.H + u] = gg; g[3 * a.H + u] = o;
+  a.h_out[idx] = h;
+  a.c_out[idx] = c;
+  if (a.hm_next) { float k = a.keep[m]; a.hm_next[idx] = h * k; a.cm_next[idx] = c * k; a.tanhc[idx] = tc; }
+}
+
+// ---- LSTM cell, backward (one time step) -------------------------------------------------------------------------
+// inputs: dh_above [M][H] (grad wrt the layer output h_t), dhm_next / dcm_next [M][H] (grads wrt the masked carries
+// h_t*keep_t, c_t*keep_t consumed by step t+1; null at the last step), activations Gact, tanhc, cm_prev = masked c_{t-1}.
+// outputs: dG [M][4H] (grad wrt pre-activations), dcm_prev [M][H] (grad wrt masked c_{t-1}).
+struct CellBwdArgs {
+  const float* Gact; const float* tanhc; const float* cm_prev; const float* dh_above; const float* dhm_next; const float* dcm_next;
+  const float* keep; float* dG; float* dcm_prev; int M, H;
+};
+struct CellBwdArgs2 { CellBwdArgs a[2]; };
+__global__ void lstm_cell_bwd_kernel(CellBwdArgs2 args) {
+  const CellBwdArgs& a = args.a[blockIdx.y];
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= a.M * a.H) return;
+  int m = idx / a.H, u = idx - m * a.H;
+  const float* g = a.Gact + (size_t)m * 4 * a.H;
+  float i = g[u], f = g[a.H + u], gg = g[2 * a.H + u], o = g[3 * a.H + u], tc = a.tanhc[idx];
+  float k = a.keep[m];
+  float dh = a.dh_above[idx] + (a.dhm_next ? k * a.dhm_next[idx] : 0.0f);
+  float dc = (a.dcm_next ? k * a.dcm_next[idx] : 0.0f) + dh * o * (1 - tc * tc);
+  float* dg = a.dG + (size_t)m * 4 * a.H;
+  dg[u] = dc * gg * i * (1 - i);
+  dg[a.H + u] = dc * a.cm_prev[idx] * f * (1 - f);
+  dg[2 * a.H + u] = dc * i * (1 - gg * gg);
+  dg[3 * a.H + u] = dh * tc * o * (1 - o);
+  a.dcm_prev[idx] = dc * f;
+}
+
+// ---- threefry (same generator as the env kernels; RNG stream KBJ_RNG_ACTION / KBJ_RNG_INIT) ---------------------
+__device__ __forceinline__ uint32_t nn_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ void nn_threefry(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
+  const int rot[8] = {13, 15, 26, 6, 17, 29, 16, 24};
+  uint32_t ks[3] = {k0, k1, k0 ^ k1 ^ 0x1BD11BDAu};
+  uint32_t x0 = c0 + ks[0], x1 = c1 + ks[1];
+#pragma unroll
+  for (int g = 0; g < 5; ++g) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { x0 += x1; x1 = nn_rotl32(x1, rot[(g & 1) * 4 + r]); x1 ^= x0; }
+    x0 += ks[(g + 1) % 3]; x1 += ks[(g + 2) % 3] + (uint32_t)(g + 1);
+  }
+  o0 = x0; o1 = x1;
+}
+
+// ---- actor head at rollout time (train.py:924-941, 1545-1572): one thread per env ---------------------------------
+struct HeadParams { float min_std, max_std, var_scale, alpha; };
+__global__ void actor_head_sample_kernel(const float* __restrict__ out /*[N][40]*/, const float* __restrict__ obs /*[N][68]*/,
+                                         float* __restrict__ lpf /*[N][20]*/, const float* __restrict__ joint_bias, HeadParams hp, uint32_t seed,
+                                         uint32_t env_off, uint32_t step, int argmax, int N, float* __restrict__ action, float* __restrict__ logp) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float lp = 0;
+  for (int j = 0; j < KBJ_NU; ++j) {
+    float mean = out[n * 40 + j] + joint_bias[j] + (j >= 10 ? obs[(size_t)n * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
+    float sd = fminf((softplusf_(out[n * 40 + KBJ_NU + j]) + hp.min_std) * hp.var_scale, hp.max_std);
+    float y0 = lpf[n * KBJ_NU + j];
+    float y = y0 + hp.alpha * (mean - y0);
+    lpf[n * KBJ_NU + j] = y;
+    float a = y;
+    if (!argmax) {
+      uint32_t b0, b1;
+      nn_threefry(seed ^ ((uint32_t)KBJ_RNG_ACTION * 0x9E3779B9u), env_off + (uint32_t)n, step, (uint32_t)j, b0, b1);
+      float u1 = (float)((b0 >> 8) + 1u) * (1.0f / 16777216.0f), u2 = (float)(b1 >> 8) * (1.0f / 16777216.0f);
+      a = y + sd * (sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2));
+    }
+    action[n * KBJ_NU + j] = a;
+    float z = (a - y) / sd;
+    lp += -0.5f * z * z - logf(sd) - 0.5f * kLog2Pi;
+  }
+  logp[n] = lp;
+}
+
+// value_d[n] = out[n][0]
+__global__ void critic_value_kernel(const float* __restrict__ out, int ld, int N, float* __restrict__ value) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N) value[n] = out[(size_t)n * ld];
+}
+
+// carry <- carry * (done == 0) (train.py:1502-1506): hc [depth*2][N][H], lpf [N][20]
+__global__ void carry_reset_kernel(float* __restrict__ hc, int planes, int N, int H, float* __restrict__ lpf, const float* __restrict__ done, int stride) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  int per = N * H;
+  if (idx < planes * per) {
+    int n = (idx % per) / H;
+    if (done[(size_t)n * stride] != 0) hc[idx] = 0;
+  }
+  if (lpf && idx < N * KBJ_NU) { int n = idx / KBJ_NU; if (done[(size_t)n * stride] != 0) lpf[idx] = 0; }
+}
+
+// ---- minibatch gathers ---------------------------------------------------------------------------------------------
+// dst[t][b][0:w] = src[t][idx[b]][0:w]
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int* __restrict__ idx, int T, int N, int B, int w, int ld_src, int ld_dst, float* __restrict__ dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)T * B * w;
+  if (i >= total) return;
+  int k = i % w;
+  size_t r = i / w;
+  int b = r % B, t = r / B;
+  dst[r * ld_dst + k] = src[((size_t)t * N + idx[b]) * ld_src + k];
+}
+// keep[t][b] = 1 - (aux[t][idx[b]][DONE] != 0)
+__global__ void gather_keep_kernel(const float* __restrict__ aux, const int* __restrict__ idx, int T, int N, int B, float* __restrict__ keep) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= T * B) return;
+  int b = i % B, t = i / B;
+  keep[i] = aux[((size_t)t * N + idx[b]) * KBJ_AUX_SIZE + KBJ_AUX_DONE] != 0 ? 0.0f : 1.0f;
+}
+
+// ---- actor head over a minibatch trajectory: per (b, j) thread scans time (low-pass filter recursion) --------------
+// out [T][B][40], obs [T][B][68], act [T][B][20], keep [T][B], lpf0 [B][20] -> y [T][B][20] (filtered mean), std [T][B][20]
+__global__ void actor_head_train_fwd_kernel(const float* __restrict__ out, const float* __restrict__ obs, const float* __restrict__ keep,
+                                            const float* __restrict__ lpf0, const float* __restrict__ joint_bias, HeadParams hp, int T, int B,
+                                            float* __restrict__ y, float* __restrict__ sd) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * KBJ_NU) return;
+  int b = i / KBJ_NU, j = i % KBJ_NU;
+  float state = lpf0[i];
+  for (int t = 0; t < T; ++t) {
+    size_t r = (size_t)t * B + b;
+    float mean = out[r * 40 + j] + joint_bias[j] + (j >= 10 ? obs[r * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
+    float yy = state + hp.alpha * (mean - state);
+    y[r * KBJ_NU + j] = yy;
+    sd[r * KBJ_NU + j] = fminf((softplusf_(out[r * 40 + KBJ_NU + j]) + hp.min_std) * hp.var_scale, hp.max_std);
+    state = yy * keep[r];
+  }
+}
+// logp[r] / entropy[r] from y, sd, act (one thread per (t,b))
+__global__ void gaussian_logp_kernel(const float* __restrict__ y, const float* __restrict__ sd, const float* __restrict__ act, int R,
+                                     float* __restrict__ logp, float* __restrict__ ent) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float lp = 0, en = 0;
+  for (int j = 0; j < KBJ_NU; ++j) {
+    float s = sd[(size_t)r * KBJ_NU + j], z = (act[(size_t)r * KBJ_NU + j] - y[(size_t)r * KBJ_NU + j]) / s;
+    lp += -0.5f * z * z - logf(s) - 0.5f * kLog2Pi;
+    en += 0.5f + 0.5f * kLog2Pi + logf(s);
+  }
+  logp[r] = lp; ent[r] = en;
+}
+
+// ---- PPO loss (restated ksim defaults): statistics pass then per-sample gradient coefficients ------------
+// stats[0..1] = sum(adv), sum(adv^2) over the minibatch (double accumulation by one block)
+__global__ void adv_stats_kernel(const float* __restrict__ adv, int R, double* __restrict__ stats) {
+  __shared__ double s1[256], s2[256];
+  double a = 0, b = 0;
+  for (int i = threadIdx.x; i < R; i += 256) { double v = adv[i]; a += v; b += v * v; }
+  s1[threadIdx.x] = a; s2[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; } __syncthreads(); }
+  if (threadIdx.x == 0) { stats[0] = s1[0]; stats[1] = s2[0]; }
+}
+struct PpoParams { float clip, vclip, vcoef, ecoef, lrclip, adv_eps; };
+// per sample: coefficients dL/dlogp, dL/dvalue, dL/dentropy(const) and metric partial sums (atomics into metrics_acc[8] doubles)
+__global__ void ppo_loss_kernel(const float* __restrict__ logp, const float* __restrict__ value, const float* __restrict__ ent,
+                                const float* __restrict__ logp_old, const float* __restrict__ value_old, const float* __restrict__ adv,
+                                const float* __restrict__ target, const double* __restrict__ stats, PpoParams pp, int R,
+                                float* __restrict__ dlogp, float* __restrict__ dvalue, double* __restrict__ macc) {
+  __shared__ double red[6][256];
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  double m[6] = {0, 0, 0, 0, 0, 0};
+  if (r < R) {
+    float mean = (float)(stats[0] / R);
+    float var = fmaxf((float)(stats[1] / R) - mean * mean, 0.0f);
+    float a = (adv[r] - mean) / (sqrtf(var) + pp.adv_eps);
+    float d = logp[r] - logp_old[r];
+    float dcl = fminf(fmaxf(d, -pp.lrclip), pp.lrclip);
+    float ratio = expf(dcl);
+    float rc = fminf(fmaxf(ratio, 1 - pp.clip), 1 + pp.clip);
+    float s1 = ratio * a, s2 = rc * a;
+    bool unclipped = s1 <= s2;
+    float surr = unclipped ? s1 : s2;
+    float inv = 1.0f / R;
+    dlogp[r] = (unclipped && fabsf(d) < pp.lrclip) ? -inv * a * ratio : 0.0f;
+    float v = value[r], vo = value_old[r], tg = target[r];
+    float dv = v - vo, dvc = fminf(fmaxf(dv, -pp.vclip), pp.vclip), vcl = vo + dvc;
+    float e1 = (v - tg) * (v - tg), e2 = (vcl - tg) * (vcl - tg);
+    float gv = e1 >= e2 ? (v - tg) : ((fabsf(dv) < pp.vclip) ? (vcl - tg) : 0.0f);
+    dvalue[r] = pp.vcoef * inv * gv;
+    m[0] = -surr; m[1] = 0.5f * fmaxf(e1, e2); m[2] = ent[r]; m[3] = fabsf(ratio - 1) > pp.clip ? 1.0 : 0.0; m[4] = -d; m[5] = 0;
+  }
+  for (int k = 0; k < 6; ++k) red[k][threadIdx.x] = m[k];
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) for (int k = 0; k < 5; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) for (int k = 0; k < 5; ++k) atomicAdd(&macc[k], red[k][0]);
+}
+// metrics[8] = loss, policy, value, entropy, clipfrac, kl, adv_mean, adv_std
+__global__ void ppo_metrics_kernel(const double* __restrict__ macc, const double* __restrict__ stats, PpoParams pp, int R, float* __restrict__ metrics) {
+  double pol = macc[0] / R, vl = macc[1] / R, en = macc[2] / R;
+  double mean = stats[0] / R, var = stats[1] / R - mean * mean;
+  metrics[0] = (float)(pol + pp.vcoef * vl - pp.ecoef * en);
+  metrics[1] = (float)pol; metrics[2] = (float)vl; metrics[3] = (float)en; metrics[4] = (float)(macc[3] / R); metrics[5] = (float)(macc[4] / R);
+  metrics[6] = (float)mean; metrics[7] = (float)sqrt(var > 0 ? var : 0);
+}
+
+// actor head backward: per (b, j) thread, reverse scan through the low-pass recursion.
+// dL/dlogp [T][B] and the constant entropy coefficient -> dOut [T][B][40]
+__global__ void actor_head_train_bwd_kernel(const float* __restrict__ out, const float* __restrict__ y, const float* __restrict__ sd,
+                                            const float* __restrict__ act, const float* __restrict__ keep, const float* __restrict__ dlogp,
+                                            float dent, HeadParams hp, int T, int B, float* __restrict__ dout) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * KBJ_NU) return;
+  int b = i / KBJ_NU, j = i % KBJ_NU;
+  float gcarry = 0;  // gradient wrt the filter state entering step t+1 (before the keep mask of step t)
+  for (int t = T - 1; t >= 0; --t) {
+    size_t r = (size_t)t * B + b;
+    float s = sd[r * KBJ_NU + j], z = (act[r * KBJ_NU + j] - y[r * KBJ_NU + j]) / s;
+    float gl = dlogp[r];
+    float gy = gl * (z / s) + keep[r] * gcarry;
+    dout[r * 40 + j] = hp.alpha * gy;
+    gcarry = (1 - hp.alpha) * gy;
+    float gs = gl * ((z * z - 1.0f) / s) + dent / s;
+    float raw = out[r * 40 + KBJ_NU + j];
+    float pre = (softplusf_(raw) + hp.min_std) * hp.var_scale;
+    dout[r * 40 + KBJ_NU + j] = pre < hp.max_std ? gs * hp.var_scale * sigmoidf_(raw) : 0.0f;
+  }
+}
+
+// column sums: out[n] (+)= sum_m X[m][n]  (bias gradients); one block per 64 columns, 256 threads = 4 row phases
+__global__ void colsum_kernel(const float* __restrict__ X, int M, int N, int ld, float* __restrict__ out) {
+  __shared__ float red[4][64];
+  int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  float s = 0;
+  if (c < N) for (int m = ph + 4 * blockIdx.y; m < M; m += 4 * gridDim.y) s += X[(size_t)m * ld + c];
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- GAE (gamma, lambda train.py:1769-1770): one thread per env, reverse scan ------------------------------------------
+__global__ void gae_kernel(const float* __restrict__ value, const float* __restrict__ reward, const float* __restrict__ aux, int T, int N,
+                           float gamma, float lam, float* __restrict__ adv, float* __restrict__ target) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float last = 0;
+  for (int t = T - 1; t >= 0; --t) {
+    size_t r = (size_t)t * N + n;
+    float keep = aux[r * KBJ_AUX_SIZE + KBJ_AUX_DONE] != 0 ? 0.0f : 1.0f;
+    float v = value[r], vn = t + 1 < T ? value[r + N] : v;
+    float delta = reward[r] + gamma * vn * keep - v;
+    last = delta + gamma * lam * keep * last;
+    adv[r] = last; target[r] = last + v;
+  }
+}
+
+// ---- AdamW with global-norm clipping (optax.adamw, train.py:1059-1077) -------------------------------------------------
+__global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float scale, double* __restrict__ out) {
+  __shared__ double red[256];
+  double s = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { double v = (double)g[i] * scale; s += v * v; }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(out, red[0]);
+}
+struct AdamParams { float lr, b1, b2, eps, wd, max_norm, bc1, bc2, gscale; };
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g, size_t n,
+                             const double* __restrict__ sumsq, AdamParams ap) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float norm = (float)sqrt(*sumsq);
+  float clip = fminf(ap.max_norm / (norm + 1e-6f), 1.0f);
+  float gi = g[i] * ap.gscale * clip;
+  float mi = ap.b1 * m[i] + (1 - ap.b1) * gi, vi = ap.b2 * v[i] + (1 - ap.b2) * gi * gi;
+  m[i] = mi; v[i] = vi;
+  float mh = mi / ap.bc1, vh = vi / ap.bc2;
+  p[i] -= ap.lr * (mh / (sqrtf(vh) + ap.eps) + ap.wd * p[i]);
+}
+
+// ---- parameter init: U(+-1/sqrt(fan_in)) per leaf (equinox default), threefry stream KBJ_RNG_INIT ------------------------
+__global__ void init_uniform_kernel(float* __restrict__ p, size_t n, float bound, uint32_t seed, uint32_t leaf) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  uint32_t b0, b1;
+  nn_threefry(seed ^ ((uint32_t)KBJ_RNG_INIT * 0x9E3779B9u), leaf, (uint32_t)(i >> 32), (uint32_t)i, b0, b1);
+  float u = (float)(b0 >> 8) * (1.0f / 16777216.0f);
+  p[i] = fmaf(2 * bound, u, -bound);
+}
+
+}  // namespace kbj

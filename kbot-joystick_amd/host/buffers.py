@@ -1,0 +1,47 @@
+"""Device buffers of the hot path, owned by torch, handed to libkbj.so as raw pointers."""
+from __future__ import annotations
+
+import torch
+
+from ..spec import layout as L
+from . import binding as B
+
+
+class CarryBuffers:
+    """Model carry (train.py:1049-1055, 1526-1543): actor/critic LSTM (h, c) per layer + low-pass filter state."""
+
+    def __init__(self, N: int, H: int, depth: int, device):
+        self.actor_hc = torch.zeros(depth, 2, N, H, device=device)
+        self.critic_hc = torch.zeros(depth, 2, N, H, device=device)
+        self.lpf = torch.zeros(N, L.NU, device=device)
+        self.c = B.Carry(self.actor_hc.data_ptr(), self.critic_hc.data_ptr(), self.lpf.data_ptr())
+
+    def zero_(self):
+        self.actor_hc.zero_(); self.critic_hc.zero_(); self.lpf.zero_()
+
+
+class TrajBuffers:
+    """One rollout's worth of trajectory arrays ([T(+1)][N][dim], time-major)."""
+
+    def __init__(self, T: int, N: int, H: int, depth: int, device):
+        self.T, self.N = T, N
+        z = lambda *s: torch.zeros(*s, device=device)
+        self.actor_obs = z(T + 1, N, L.LD_ACTOR)
+        self.critic_obs = z(T + 1, N, L.LD_CRITIC)
+        self.aux = z(T + 1, N, L.AUX["SIZE"])
+        self.action = z(T, N, L.NU)
+        self.logp = z(T, N)
+        self.value = z(T, N)
+        self.reward = z(T, N)
+        self.carry0_actor_hc = z(depth, 2, N, H)
+        self.carry0_critic_hc = z(depth, 2, N, H)
+        self.carry0_lpf = z(N, L.NU)
+        self.adv = z(T, N)
+        self.target = z(T, N)
+        self.c = B.Traj(T, N, self.actor_obs.data_ptr(), self.critic_obs.data_ptr(), self.aux.data_ptr(), self.action.data_ptr(),
+                        self.logp.data_ptr(), self.value.data_ptr(), self.reward.data_ptr(), self.carry0_actor_hc.data_ptr(),
+                        self.carry0_critic_hc.data_ptr(), self.carry0_lpf.data_ptr())
+
+    @property
+    def done(self) -> torch.Tensor:
+        return self.aux[: self.T, :, L.AUX["DONE"]]

@@ -35,7 +35,8 @@ def test_reset_matches_oracle(which):
     o = O.Oracle(m, cfg, seed=5, precision="f32")
     a0, c0, x0 = o.reset_all()
     assert np.array_equal(o.ep, ep)
-    assert np.array_equal(o.es[:, 0:27], es[:, 0:27])
+    assert np.array_equal(o.es[:, 0:3], es[:, 0:3]) and np.array_equal(o.es[:, 7:27], es[:, 7:27])
+    assert np.abs(o.es[:, 3:7] - es[:, 3:7]).max() < 3e-7           # cosf/sinf(yaw/2): device libm vs glibc, 1-2 ulp
     assert np.abs(o.es[:, 28:54] - es[:, 28:54]).max() == 0
     assert np.array_equal(o.es[:, 80:125], es[:, 80:125])
     assert np.array_equal(o.es[:, 128:130].view(np.uint32), es[:, 128:130].view(np.uint32))

@@ -1,0 +1,148 @@
+"""GPU parity tests of the actor-critic / PPO kernels through the C ABI against the torch CPU oracle (oracle/nn.py).
+fp32 MFMA products are exact fp32 fma chains, so the tolerance is fp32 round-off of differently ordered sums."""
+import numpy as np
+import pytest
+
+from kbot_joystick_amd.spec import compiler, layout as L
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(N, B, T, H, **kw):
+    import torch
+    from kbot_joystick_amd.host import binding as Bd, buffers
+    m = compiler.load_model("kbot-headless")
+    cfg = L.default_config(num_envs=N, batch_size=B, rollout_len=T, hidden_size=H, **kw)
+    ctx = Bd.Context(m, cfg, 0, torch.cuda.current_stream().cuda_stream)
+    return m, cfg, ctx, torch, buffers
+
+
+@pytest.mark.parametrize("H", [64, 256])
+def test_policy_step_matches_oracle(H):
+    N = 96
+    m, cfg, ctx, torch, buffers = _setup(N, 32, 4, H)
+    P = ctx.param_count()
+    from oracle import nn as ON
+    assert P == ON.param_count(H)
+    params = torch.zeros(P, device="cuda:0")
+    ctx.init_params(3, params)
+    ctx.synchronize()
+    pn = params.cpu().numpy()
+    assert np.isfinite(pn).all() and abs(pn.mean()) < 1e-2 and np.abs(pn).max() <= 1 / np.sqrt(min(65, H)) + 1e-6
+    g = torch.Generator(device="cpu").manual_seed(0)
+    aobs = torch.zeros(N, L.LD_ACTOR); aobs[:, :65] = torch.randn(N, 65, generator=g)
+    cobs = torch.zeros(N, L.LD_CRITIC); cobs[:, :475] = torch.randn(N, 475, generator=g)
+    carry = buffers.CarryBuffers(N, H, 2, "cuda:0")
+    carry.actor_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.5)
+    carry.critic_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.5)
+    carry.lpf.copy_(torch.randn(N, 20, generator=g) * 0.3)
+    hc_a0, hc_c0, lpf0 = carry.actor_hc.cpu().double(), carry.critic_hc.cpu().double(), carry.lpf.cpu().double()
+    action, logp, value = torch.zeros(N, 20, device="cuda:0"), torch.zeros(N, device="cuda:0"), torch.zeros(N, device="cuda:0")
+    ctx.policy_step(params, aobs.cuda(), cobs.cuda(), carry.c, 7, 5, True, action, logp, value)
+    ctx.synchronize()
+    p = ON.unflatten(params.detach().cpu().double(), H)
+    jb = torch.tensor(list(m.joint_bias), dtype=torch.float64)
+    out_a, ca = ON.net_forward(p, "actor", aobs[:, :65].double(), [[hc_a0[l, 0], hc_a0[l, 1]] for l in range(2)])
+    mean, std, lpf1 = ON.actor_head(out_a, aobs.double(), lpf0, jb, cfg)
+    out_c, cc = ON.net_forward(p, "critic", cobs[:, :475].double(), [[hc_c0[l, 0], hc_c0[l, 1]] for l in range(2)])
+    assert (action.cpu().double() - mean).abs().max() < 2e-5            # argmax -> mode
+    assert (value.cpu().double() - out_c[:, 0]).abs().max() < 2e-5
+    assert (logp.cpu().double() - ON.gaussian_logp(mean, mean, std)).abs().max() < 1e-4
+    for l in range(2):
+        assert (carry.actor_hc[l, 0].cpu().double() - ca[l][0]).abs().max() < 1e-5
+        assert (carry.actor_hc[l, 1].cpu().double() - ca[l][1]).abs().max() < 1e-5
+        assert (carry.critic_hc[l, 1].cpu().double() - cc[l][1]).abs().max() < 1e-5
+    assert (carry.lpf.cpu().double() - lpf1).abs().max() < 1e-5
+    # sampling: same seed/step -> same draw; different step -> different draw; logp consistent with the sample
+    a1, a2, lp1 = torch.zeros_like(action), torch.zeros_like(action), torch.zeros_like(logp)
+    c2, c3, c4 = (buffers.CarryBuffers(N, H, 2, "cuda:0") for _ in range(3))
+    ctx.policy_step(params, aobs.cuda(), cobs.cuda(), c2.c, 7, 5, False, a1, lp1, value)
+    ctx.policy_step(params, aobs.cuda(), cobs.cuda(), c3.c, 7, 5, False, a2, logp, value)
+    ctx.synchronize()
+    assert torch.equal(a1, a2)
+    ctx.policy_step(params, aobs.cuda(), cobs.cuda(), c4.c, 7, 6, False, a2, logp, value)
+    ctx.synchronize()
+    assert not torch.equal(a1, a2)
+    out0, _ = ON.net_forward(p, "actor", aobs[:, :65].double(), ON.zero_carry(N, H, 2, torch.float64))
+    mean0, std0, _ = ON.actor_head(out0, aobs.double(), torch.zeros(N, 20, dtype=torch.float64), jb, cfg)
+    assert (lp1.cpu().double() - ON.gaussian_logp(a1.cpu().double(), mean0, std0)).abs().max() < 1e-3
+    z = ((a1.cpu().double() - mean0) / std0).flatten()
+    assert abs(z.mean()) < 0.1 and abs(z.std() - 1) < 0.1               # unit Gaussian draws
+    ctx.close()
+
+
+def _synthetic_traj(torch, buffers, N, T, H, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    tr = buffers.TrajBuffers(T, N, H, 2, "cuda:0")
+    tr.actor_obs[:, :, :65] = (torch.randn(T + 1, N, 65, generator=g) * 0.5).cuda()
+    tr.critic_obs[:, :, :475] = (torch.randn(T + 1, N, 475, generator=g) * 0.5).cuda()
+    tr.action.copy_(torch.randn(T, N, 20, generator=g) * 0.3)
+    done = (torch.rand(T, N, generator=g) < 0.15).float() * torch.where(torch.rand(T, N, generator=g) < 0.5, -1.0, 1.0)
+    tr.aux[:T, :, L.AUX["DONE"]] = done.cuda()
+    tr.reward.copy_(torch.rand(T, N, generator=g))
+    tr.carry0_actor_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
+    tr.carry0_critic_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
+    tr.carry0_lpf.copy_(torch.randn(N, 20, generator=g) * 0.2)
+    return tr
+
+
+@pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (256, 40, 32, 9)])
+def test_ppo_grad_matches_autograd(H, N, B, T):
+    m, cfg, ctx, torch, buffers = _setup(N, B, T, H)
+    from oracle import nn as ON
+    P = ctx.param_count()
+    params = torch.zeros(P, device="cuda:0")
+    ctx.init_params(11, params)
+    tr = _synthetic_traj(torch, buffers, N, T, H)
+    jb = torch.tensor(list(m.joint_bias), dtype=torch.float64)
+    p64 = params.detach().cpu().double()
+    pd = ON.unflatten(p64, H)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    idx = torch.randperm(N, generator=g)[:B].int()
+    ao, co = tr.actor_obs[:T].cpu().double(), tr.critic_obs[:T].cpu().double()
+    act, done = tr.action.cpu().double(), tr.done.cpu().double()
+    with torch.no_grad():
+        ca = [[tr.carry0_actor_hc[l, k].cpu().double() for k in range(2)] for l in range(2)]
+        cc = [[tr.carry0_critic_hc[l, k].cpu().double() for k in range(2)] for l in range(2)]
+        lp, v, en, *_ = ON.ppo_variables(pd, cfg, jb, ao, co, act, done, ca, cc, tr.carry0_lpf.cpu().double())
+    tr.logp.copy_((lp + 0.3 * torch.randn(T, N, generator=g).double()).float())       # some ratios leave the clip range
+    tr.value.copy_((v + 0.3 * torch.randn(T, N, generator=g).double()).float())
+    ctx.gae(tr.c, tr.adv, tr.target)
+    ctx.synchronize()
+    adv_o, tgt_o = ON.gae(tr.value.cpu().double(), tr.reward.cpu().double(), done, cfg.gamma, cfg.lam)
+    assert (tr.adv.cpu().double() - adv_o).abs().max() < 1e-5 and (tr.target.cpu().double() - tgt_o).abs().max() < 1e-5
+    grad, metrics = torch.zeros(P, device="cuda:0"), torch.zeros(8, device="cuda:0")
+    ctx.ppo_grad(params, tr.c, idx.cuda(), B, tr.adv, tr.target, grad, metrics)
+    ctx.synchronize()
+    # oracle: autograd through the minibatch
+    pf = p64.clone().requires_grad_(True)
+    pdg = ON.unflatten(pf, H)
+    ii = idx.long()
+    ca = [[tr.carry0_actor_hc[l, k].cpu().double()[ii] for k in range(2)] for l in range(2)]
+    cc = [[tr.carry0_critic_hc[l, k].cpu().double()[ii] for k in range(2)] for l in range(2)]
+    lp, v, en, *_ = ON.ppo_variables(pdg, cfg, jb, ao[:, ii], co[:, ii], act[:, ii], done[:, ii], ca, cc, tr.carry0_lpf.cpu().double()[ii])
+    loss, mt = ON.ppo_loss(cfg, lp, v, en, tr.logp.cpu().double()[:, ii], tr.value.cpu().double()[:, ii], adv_o[:, ii], tgt_o[:, ii])
+    loss.backward()
+    go = pf.grad
+    mg = metrics.cpu().double()
+    for k, name in enumerate(["loss", "policy", "value", "entropy", "clipfrac", "kl", "adv_mean", "adv_std"]):
+        assert abs(mg[k] - float(mt[name])) < 2e-4 * (1 + abs(float(mt[name]))), (name, float(mg[k]), float(mt[name]))
+    assert 0.02 < float(mt["clipfrac"]) < 0.98                         # both clip branches exercised
+    gg = grad.cpu().double()
+    off = 0
+    for name, shp in ON.param_shapes(H):
+        n = int(np.prod(shp))
+        a, b = gg[off:off + n], go[off:off + n]
+        err = (a - b).abs().max() / (b.abs().max() + 1e-12)
+        assert err < 2e-3, (name, float(err), float(b.abs().max()))
+        off += n
+    assert (gg - go).norm() / go.norm() < 1e-4
+    # AdamW + global-norm clip
+    mom, var = torch.zeros(P, device="cuda:0"), torch.zeros(P, device="cuda:0")
+    p_o, m_o, v_o = params.cpu().double().clone(), torch.zeros(P, dtype=torch.float64), torch.zeros(P, dtype=torch.float64)
+    for step in (1, 2):
+        ctx.adamw_step(params, mom, var, grad, step, 0.5)
+        ON.adamw_step(cfg, p_o, m_o, v_o, gg.clone(), step, 0.5)
+    ctx.synchronize()
+    assert (params.cpu().double() - p_o).abs().max() < 1e-6
+    ctx.close()
