@@ -78,6 +78,9 @@ def load_library() -> C.CDLL:
         if not os.path.exists(LIB_PATH):
             raise KbjError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
                            "There is no CPU fallback.")
+        # torch bundles its own ROCm runtime: import it first so that libkbj.so binds to the SAME libamdhip64
+        # (loading /opt/rocm's copy first leaves the process with two HIP runtimes and no visible device)
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError here means the library does not match include/kbj.h
