@@ -32,6 +32,7 @@ bool topology_ok(const kbj_model& m, std::string& why) {
 
 int kbj_nn_create(kbj_ctx* ctx);   // kbj_nn.hip
 void kbj_nn_destroy(kbj_ctx* ctx);
+int kbj_nn_check_errors(kbj_ctx* ctx);
 
 extern "C" {
 
@@ -98,7 +99,7 @@ int kbj_destroy(kbj_ctx* ctx) {
 int kbj_synchronize(kbj_ctx* ctx) {
   if (!ctx) return kbj_fail(nullptr, "kbj_synchronize: null ctx");
   KBJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  return 0;
+  return kbj_nn_check_errors(ctx);
 }
 
 int kbj_profile_begin(kbj_ctx* ctx) {

@@ -1,0 +1,251 @@
+// kbj_lstm_seq.h — persistent fused LSTM recurrence over a whole trajectory (forward and BPTT), fp32 MFMA.
+//
+// The recurrent products h_{t-1} W_hh^T (forward) and dG_{t+1} W_hh (backward) are sequential in t and tiny
+// (M = minibatch 512, 268 MFLOP): as separate launches they are latency bound (profiles/r01). Here ONE launch runs all
+// T steps of one (net, layer):
+//   * workgroup (rg, ug) owns rows [32 rg, 32 rg + 32) x hidden units [16 ug, 16 ug + 16) of the minibatch for the
+//     whole sequence; its slice of W_hh (64 x H, resp. 4H x 16 floats) stays in VGPRs as MFMA B-operands
+//     (16x16x4 f32 MFMA: A = one f32 per lane [row = lane&15][k = lane>>4], B = [k = lane>>4][col = lane&15]);
+//   * the LSTM cell (forward) / its derivative (backward) is fused; the cell state / its gradient lives in registers;
+//   * per time step the only exchange is the h tile (forward) or dG tile (backward) of the SAME row group, produced by the
+//     H/16 workgroups of that row group: a monotonic per-row-group arrival counter with agent-scope release/acquire
+//     (cdna_hip_programming.md Guideline 16) replaces the kernel boundary. Grid = (B/32)(H/16) <= 256 workgroups, all
+//     resident; every spin is bounded and reports through an error word instead of hanging.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kbj {
+
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+constexpr int SEQ_ROWS = 32;   // rows per workgroup
+constexpr int SEQ_UNITS = 16;  // hidden units per workgroup
+constexpr unsigned SEQ_SPIN_LIMIT = 1u << 24;
+
+struct SeqFwdArgs {
+  float* G;            // [T][B][4H] in: x W_ih^T + b, out: gate activations (i,f,g,o)
+  const float* Whh;    // [4H][H]
+  float* Hm;           // [T+1][B][H] masked h consumed by step t (slot 0 = initial carry)
+  float* Cm;           // [T+1][B][H]
+  float* Hout;         // [T][B][H]
+  float* TanhC;        // [T][B][H]
+  const float* keep;   // [T][B]
+  unsigned* counters;  // [ceil(B/32)] zeroed before launch
+  unsigned* err;       // set to 1 on a spin timeout
+  int T, B;
+};
+
+struct SeqBwdArgs {
+  const float* Gact;     // [T][B][4H]
+  const float* TanhC;    // [T][B][H]
+  const float* Cm;       // [T+1][B][H]
+  const float* dHabove;  // [T][B][H]
+  const float* keep;     // [T][B]
+  const float* Whh;      // [4H][H]
+  float* dG;             // [T][B][4H] out
+  unsigned* counters;
+  unsigned* err;
+  int T, B;
+};
+
+__device__ __forceinline__ float seq_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// wait until *ctr >= target (one lane polls, the workgroup then acquires); returns false on timeout
+__device__ __forceinline__ bool seq_wait(unsigned* ctr, unsigned target, unsigned* err, int* lds_flag) {
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    int ok = 1;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > SEQ_SPIN_LIMIT) { ok = 0; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *lds_flag = ok;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+__device__ __forceinline__ void seq_publish(unsigned* ctr) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
+  constexpr int LDH = H + 4;
+  constexpr int NUG = H / SEQ_UNITS;
+  __shared__ __attribute__((aligned(16))) float hs[SEQ_ROWS * LDH];
+  __shared__ float gbuf[4][SEQ_ROWS][SEQ_UNITS + 1];
+  __shared__ int flag;
+  const int tid = threadIdx.x, lane = tid & 63, gate = tid >> 6;
+  const int ug = blockIdx.x % NUG, rg = blockIdx.x / NUG;
+  const int r0 = rg * SEQ_ROWS, u0 = ug * SEQ_UNITS;
+  const int B = a.B, T = a.T;
+  // W_hh rows of this wave's gate for the 16 units, as B operands: B[k][col] = Whh[gate H + u0 + col][k]
+  float wreg[H / 4];
+  {
+    const float* wrow = a.Whh + (size_t)(gate * H + u0 + (lane & 15)) * H + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < H / 4; ++s) wreg[s] = wrow[4 * s];
+  }
+  // the two (row, unit) elements of this thread in the cell epilogue and their cell state
+  int erow[2], eunit[2];
+  float cm[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int e = tid + 256 * i;
+    erow[i] = e / SEQ_UNITS; eunit[i] = e % SEQ_UNITS;
+    int r = r0 + erow[i];
+    cm[i] = r < B ? a.Cm[(size_t)r * H + u0 + eunit[i]] : 0.0f;
+  }
+  for (int t = 0; t < T; ++t) {
+    if (t > 0) { if (!seq_wait(a.counters + rg, (unsigned)(NUG * t), a.err, &flag)) return; }
+    // stage h_{t-1} rows of this row group (all H columns)
+    const float* hsrc = a.Hm + (size_t)t * B * H;
+    for (int q = tid; q < SEQ_ROWS * (H / 4); q += 256) {
+      int row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
+      f32x4m v = {0, 0, 0, 0};
+      if (r < B) v = *reinterpret_cast<const f32x4m*>(hsrc + (size_t)r * H + 4 * c4);
+      *reinterpret_cast<f32x4m*>(hs + row * LDH + 4 * c4) = v;
+    }
+    // prefetch this step's input-projection pre-activations and keep flags
+    float gx[2][4], kp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int r = r0 + erow[i];
+      const float* g = a.G + ((size_t)t * B + (r < B ? r : 0)) * 4 * H + u0 + eunit[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gx[i][k] = r < B ? g[k * H] : 0.0f;
+      kp[i] = r < B ? a.keep[(size_t)t * B + r] : 0.0f;
+    }
+    __syncthreads();
+    f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    const float* a0p = hs + (lane & 15) * LDH + (lane >> 4);
+    const float* a1p = a0p + 16 * LDH;
+#pragma unroll
+    for (int s = 0; s < H / 4; ++s) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * s], wreg[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * s], wreg[s], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      gbuf[gate][(lane >> 4) * 4 + r][lane & 15] = acc0[r];
+      gbuf[gate][16 + (lane >> 4) * 4 + r][lane & 15] = acc1[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int r = r0 + erow[i];
+      if (r >= B) continue;
+      int row = erow[i], u = eunit[i];
+      float ig = seq_sigmoid(gbuf[0][row][u] + gx[i][0]), fg = seq_sigmoid(gbuf[1][row][u] + gx[i][1]);
+      float gg = tanhf(gbuf[2][row][u] + gx[i][2]), og = seq_sigmoid(gbuf[3][row][u] + gx[i][3]);
+      float c = fg * cm[i] + ig * gg, tc = tanhf(c), h = og * tc;
+      size_t o1 = ((size_t)t * B + r) * H + u0 + u;
+      float* g = a.G + ((size_t)t * B + r) * 4 * H + u0 + u;
+      g[0] = ig; g[H] = fg; g[2 * H] = gg; g[3 * H] = og;
+      a.Hout[o1] = h; a.TanhC[o1] = tc;
+      cm[i] = c * kp[i];
+      a.Hm[o1 + (size_t)B * H] = h * kp[i];
+      a.Cm[o1 + (size_t)B * H] = cm[i];
+    }
+    seq_publish(a.counters + rg);
+  }
+}
+
+template <int H>
+__global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
+  constexpr int LDH = H + 4;
+  constexpr int NUG = H / SEQ_UNITS;
+  __shared__ __attribute__((aligned(16))) float ds[SEQ_ROWS * LDH];   // one gate chunk of dG_{t+1}: [32][H]
+  __shared__ float pbuf[4][SEQ_ROWS][SEQ_UNITS + 1];                   // per-wave partial sums of dh
+  __shared__ int flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ug = blockIdx.x % NUG, rg = blockIdx.x / NUG;
+  const int r0 = rg * SEQ_ROWS, u0 = ug * SEQ_UNITS;
+  const int B = a.B, T = a.T;
+  constexpr int KW = H / 4;        // k range of one wave inside a gate chunk
+  constexpr int KS = KW / 4;       // k-steps per (wave, gate chunk)
+  // B operands: for gate chunk c and k-step s: B[k][col] = Whh[c H + wave KW + 4 s + (lane>>4)][u0 + col]
+  float wreg[4][KS];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int s = 0; s < KS; ++s) wreg[c][s] = a.Whh[(size_t)(c * H + wave * KW + 4 * s + (lane >> 4)) * H + u0 + (lane & 15)];
+  int erow[2], eunit[2];
+  float dcm[2] = {0.0f, 0.0f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { int e = tid + 256 * i; erow[i] = e / SEQ_UNITS; eunit[i] = e % SEQ_UNITS; }
+  for (int t = T - 1; t >= 0; --t) {
+    const bool last = t == T - 1;
+    // prefetch everything the cell derivative of step t needs
+    float act[2][4], tc[2], cprev[2], dha[2], kp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int r = r0 + erow[i];
+      bool ok = r < B;
+      size_t o1 = ((size_t)t * B + (ok ? r : 0)) * H + u0 + eunit[i];
+      const float* g = a.Gact + ((size_t)t * B + (ok ? r : 0)) * 4 * H + u0 + eunit[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) act[i][k] = ok ? g[k * H] : 0.0f;
+      tc[i] = ok ? a.TanhC[o1] : 0.0f;
+      cprev[i] = ok ? a.Cm[o1] : 0.0f;
+      dha[i] = ok ? a.dHabove[o1] : 0.0f;
+      kp[i] = ok ? a.keep[(size_t)t * B + r] : 0.0f;
+    }
+    float dhm[2] = {0.0f, 0.0f};
+    if (!last) {
+      if (!seq_wait(a.counters + rg, (unsigned)(NUG * (T - 1 - t)), a.err, &flag)) return;
+      f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      const float* src = a.dG + (size_t)(t + 1) * B * 4 * H;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (c) __syncthreads();
+        for (int q = tid; q < SEQ_ROWS * (H / 4); q += 256) {
+          int row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
+          f32x4m v = {0, 0, 0, 0};
+          if (r < B) v = *reinterpret_cast<const f32x4m*>(src + (size_t)r * 4 * H + c * H + 4 * c4);
+          *reinterpret_cast<f32x4m*>(ds + row * LDH + 4 * c4) = v;
+        }
+        __syncthreads();
+        const float* a0p = ds + (lane & 15) * LDH + wave * KW + (lane >> 4);
+        const float* a1p = a0p + 16 * LDH;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * s], wreg[c][s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * s], wreg[c][s], acc1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        pbuf[wave][(lane >> 4) * 4 + r][lane & 15] = acc0[r];
+        pbuf[wave][16 + (lane >> 4) * 4 + r][lane & 15] = acc1[r];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) dhm[i] = pbuf[0][erow[i]][eunit[i]] + pbuf[1][erow[i]][eunit[i]] + pbuf[2][erow[i]][eunit[i]] + pbuf[3][erow[i]][eunit[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int r = r0 + erow[i];
+      if (r >= B) continue;
+      float ig = act[i][0], fg = act[i][1], gg = act[i][2], og = act[i][3];
+      float dh = dha[i] + kp[i] * dhm[i];
+      float dc = kp[i] * dcm[i] + dh * og * (1 - tc[i] * tc[i]);
+      float* dg = a.dG + ((size_t)t * B + r) * 4 * H + u0 + eunit[i];
+      dg[0] = dc * gg * ig * (1 - ig);
+      dg[H] = dc * cprev[i] * fg * (1 - fg);
+      dg[2 * H] = dc * ig * (1 - gg * gg);
+      dg[3 * H] = dh * tc[i] * og * (1 - og);
+      dcm[i] = dc * fg;
+    }
+    seq_publish(a.counters + rg);
+  }
+}
+
+}  // namespace kbj

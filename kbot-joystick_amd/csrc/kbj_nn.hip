@@ -7,6 +7,7 @@
 #include "kbj_ctx.h"
 #include "kbj_gemm.h"
 #include "kbj_nn_kernels.h"
+#include "kbj_lstm_seq.h"
 
 using namespace kbj;
 
@@ -33,6 +34,8 @@ struct NnWs {
   float *keep = nullptr, *act = nullptr, *logp_old = nullptr, *val_old = nullptr, *adv = nullptr, *target = nullptr;
   float *y = nullptr, *sd = nullptr, *logp = nullptr, *ent = nullptr, *value = nullptr, *dlogp = nullptr, *dvalue = nullptr, *lpf0 = nullptr;
   double* stats = nullptr;  // [0..1] adv stats, [2..9] metric accumulators, [10] grad sumsq
+  unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
+  unsigned* seq_err = nullptr;       // spin-timeout flag
   std::vector<void*> allocs;
 };
 
@@ -89,7 +92,45 @@ void linear_bwd_weight(hipStream_t s, const float* dy, int lddy, const float* x,
   gemm_launch<false, false>(s, g);
 }
 
+template <int H> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a) {
+  int grid = (H / SEQ_UNITS) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
+  hipLaunchKernelGGL((lstm_seq_fwd_kernel<H>), dim3(grid), dim3(256), 0, s, a);
+}
+template <int H> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a) {
+  int grid = (H / SEQ_UNITS) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
+  hipLaunchKernelGGL((lstm_seq_bwd_kernel<H>), dim3(grid), dim3(256), 0, s, a);
+}
+int seq_fwd(kbj_ctx* ctx, int H, const SeqFwdArgs& a) {
+  hipMemsetAsync(a.counters, 0, 1024 * sizeof(unsigned), ctx->stream);
+  switch (H) {
+    case 64: seq_fwd_launch<64>(ctx->stream, a); break;
+    case 128: seq_fwd_launch<128>(ctx->stream, a); break;
+    case 256: seq_fwd_launch<256>(ctx->stream, a); break;
+    default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 256");
+  }
+  return 0;
+}
+int seq_bwd(kbj_ctx* ctx, int H, const SeqBwdArgs& a) {
+  hipMemsetAsync(a.counters, 0, 1024 * sizeof(unsigned), ctx->stream);
+  switch (H) {
+    case 64: seq_bwd_launch<64>(ctx->stream, a); break;
+    case 128: seq_bwd_launch<128>(ctx->stream, a); break;
+    case 256: seq_bwd_launch<256>(ctx->stream, a); break;
+    default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 256");
+  }
+  return 0;
+}
+
 }  // namespace
+
+int kbj_nn_check_errors(kbj_ctx* ctx) {
+  NnWs* w = ws_of(ctx);
+  if (!w) return 0;
+  unsigned e = 0;
+  if (hipMemcpy(&e, w->seq_err, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return kbj_fail(ctx, "hipMemcpy seq_err");
+  if (e) return kbj_fail(ctx, "persistent LSTM kernel: inter-workgroup wait timed out (grid not fully resident?)");
+  return 0;
+}
 
 int kbj_nn_create(kbj_ctx* ctx) {
   NnWs* w = new NnWs();
@@ -133,6 +174,10 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->sd, R * KBJ_NU)) return -1;
   if (dalloc(ctx, *w, &w->lpf0, B * KBJ_NU)) return -1;
   if (dalloc(ctx, *w, &w->stats, 16)) return -1;
+  if (dalloc(ctx, *w, &w->seq_counters, 1024)) return -1;
+  if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
+  if (hipMemset(w->seq_err, 0, 4 * sizeof(unsigned)) != hipSuccess) return kbj_fail(ctx, "hipMemset seq_err");
+  if ((B + SEQ_ROWS - 1) / SEQ_ROWS * (H / SEQ_UNITS) > 256) return kbj_fail(ctx, "kbj_create: (batch_size/32)*(hidden/16) must be <= 256 (persistent LSTM kernel residency)");
   return 0;
 }
 
@@ -286,14 +331,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     const float* xin = t.X0;
     for (int l = 0; l < 2; ++l) {
       linear_fwd(s, xin, H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
-      for (int tt = 0; tt < T; ++tt) {
-        float* G = t.G[l] + (size_t)tt * B * 4 * H;
-        linear_fwd(s, t.Hm[l] + (size_t)tt * B * H, H, params_d + o.w_hh[l], H, nullptr, G, 4 * H, B, 4 * H, H, 1);
-        CellFwdArgs2 ca;
-        ca.a[0] = CellFwdArgs{G, t.Cm[l] + (size_t)tt * B * H, t.Hout[l] + (size_t)tt * B * H, t.dhm /*scratch c_out*/, t.Hm[l] + (size_t)(tt + 1) * B * H,
-                              t.Cm[l] + (size_t)(tt + 1) * B * H, t.TanhC[l] + (size_t)tt * B * H, w.keep + (size_t)tt * B, B, H};
-        hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((B * H + 255) / 256, 1), dim3(256), 0, s, ca);
-      }
+      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters, w.seq_err, T, B};
+      if (seq_fwd(ctx, H, fa)) return -1;
       xin = t.Hout[l];
     }
     linear_fwd(s, xin, H, params_d + o.w_out, H, params_d + o.b_out, t.Out, 40, R, o.nout, H, 0);
@@ -326,15 +365,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     float* dh_above = t.dHa;
     float* dx_out = t.dHb;
     for (int l = 1; l >= 0; --l) {
-      for (int tt = T - 1; tt >= 0; --tt) {
-        bool last = tt == T - 1;
-        CellBwdArgs2 cb;
-        cb.a[0] = CellBwdArgs{t.G[l] + (size_t)tt * B * 4 * H, t.TanhC[l] + (size_t)tt * B * H, t.Cm[l] + (size_t)tt * B * H, dh_above + (size_t)tt * B * H,
-                              last ? nullptr : t.dhm, last ? nullptr : t.dcm[tt & 1 ? 0 : 1], w.keep + (size_t)tt * B, t.dG + (size_t)tt * B * 4 * H,
-                              t.dcm[tt & 1], B, H};
-        hipLaunchKernelGGL(lstm_cell_bwd_kernel, dim3((B * H + 255) / 256, 1), dim3(256), 0, s, cb);
-        if (tt > 0) linear_bwd_input(s, t.dG + (size_t)tt * B * 4 * H, 4 * H, params_d + o.w_hh[l], H, t.dhm, H, B, H, 4 * H, 0);
-      }
+      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above, w.keep, params_d + o.w_hh[l], t.dG, w.seq_counters, w.seq_err, T, B};
+      if (seq_bwd(ctx, H, ba)) return -1;
       const float* xin = l == 0 ? t.X0 : t.Hout[0];
       linear_bwd_weight(s, t.dG, 4 * H, t.Hm[l], H, grad_d + o.w_hh[l], H, 4 * H, H, R);
       linear_bwd_weight(s, t.dG, 4 * H, xin, H, grad_d + o.w_ih[l], H, 4 * H, H, R);
