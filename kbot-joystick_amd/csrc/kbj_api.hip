@@ -75,6 +75,9 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   KBJ_TRY(hipMemset(ctx->rcarry_d, 0, N * KBJ_RC_SIZE * sizeof(float)));
   KBJ_TRY(hipEventCreate(&ctx->ev0));
   KBJ_TRY(hipEventCreate(&ctx->ev1));
+  KBJ_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+  KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
 #undef KBJ_TRY
   if (kbj_nn_create(ctx) != 0) { std::string msg = ctx->error; kbj_destroy(ctx); return kbj_fail(nullptr, msg); }
   *out = ctx;
@@ -92,6 +95,9 @@ int kbj_destroy(kbj_ctx* ctx) {
   if (ctx->rcarry_d) hipFree(ctx->rcarry_d);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+  if (ctx->stream2) hipStreamDestroy(ctx->stream2);
   delete ctx;
   return 0;
 }

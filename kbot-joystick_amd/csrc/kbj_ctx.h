@@ -8,6 +8,8 @@
 struct kbj_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // second lane for the critic network inside kbj_ppo_grad
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   kbj_model model_h;
   kbj_config cfg_h;
   kbj_model* model_d = nullptr;

@@ -57,7 +57,7 @@ __device__ __forceinline__ bool seq_wait(unsigned* ctr, unsigned target, unsigne
     unsigned spins = 0;
     int ok = 1;
     while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      __builtin_amdgcn_s_sleep(2);
+      __builtin_amdgcn_s_sleep(1);
       if (++spins > SEQ_SPIN_LIMIT) { ok = 0; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -66,13 +66,13 @@ __device__ __forceinline__ bool seq_wait(unsigned* ctr, unsigned target, unsigne
   __syncthreads();
   return *lds_flag != 0;
 }
+// The handed-off payload is stored write-through (sc1: relaxed agent-scope atomic stores, seq_store), so publishing
+// needs no release fence: every storing wave drains its stores, the workgroup meets, one lane bumps the counter.
+__device__ __forceinline__ void seq_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void seq_publish(unsigned* ctr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int H>
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
       g[0] = ig; g[H] = fg; g[2 * H] = gg; g[3 * H] = og;
       a.Hout[o1] = h; a.TanhC[o1] = tc;
       cm[i] = c * kp[i];
-      a.Hm[o1 + (size_t)B * H] = h * kp[i];
+      seq_store(a.Hm + o1 + (size_t)B * H, h * kp[i]);   // consumed by the other workgroups of this row group
       a.Cm[o1 + (size_t)B * H] = cm[i];
     }
     seq_publish(a.counters + rg);
@@ -238,10 +238,10 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       float dh = dha[i] + kp[i] * dhm[i];
       float dc = kp[i] * dcm[i] + dh * og * (1 - tc[i] * tc[i]);
       float* dg = a.dG + ((size_t)t * B + r) * 4 * H + u0 + eunit[i];
-      dg[0] = dc * gg * ig * (1 - ig);
-      dg[H] = dc * cprev[i] * fg * (1 - fg);
-      dg[2 * H] = dc * ig * (1 - gg * gg);
-      dg[3 * H] = dh * tc[i] * og * (1 - og);
+      seq_store(dg, dc * gg * ig * (1 - ig));
+      seq_store(dg + H, dc * cprev[i] * fg * (1 - fg));
+      seq_store(dg + 2 * H, dc * ig * (1 - gg * gg));
+      seq_store(dg + 3 * H, dh * tc[i] * og * (1 - og));
       dcm[i] = dc * fg;
     }
     seq_publish(a.counters + rg);

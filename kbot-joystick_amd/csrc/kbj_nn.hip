@@ -100,22 +100,22 @@ template <int H> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a) {
   int grid = (H / SEQ_UNITS) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
   hipLaunchKernelGGL((lstm_seq_bwd_kernel<H>), dim3(grid), dim3(256), 0, s, a);
 }
-int seq_fwd(kbj_ctx* ctx, int H, const SeqFwdArgs& a) {
-  hipMemsetAsync(a.counters, 0, 1024 * sizeof(unsigned), ctx->stream);
+int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {
+  hipMemsetAsync(a.counters, 0, 256 * sizeof(unsigned), st);
   switch (H) {
-    case 64: seq_fwd_launch<64>(ctx->stream, a); break;
-    case 128: seq_fwd_launch<128>(ctx->stream, a); break;
-    case 256: seq_fwd_launch<256>(ctx->stream, a); break;
+    case 64: seq_fwd_launch<64>(st, a); break;
+    case 128: seq_fwd_launch<128>(st, a); break;
+    case 256: seq_fwd_launch<256>(st, a); break;
     default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 256");
   }
   return 0;
 }
-int seq_bwd(kbj_ctx* ctx, int H, const SeqBwdArgs& a) {
-  hipMemsetAsync(a.counters, 0, 1024 * sizeof(unsigned), ctx->stream);
+int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {
+  hipMemsetAsync(a.counters, 0, 256 * sizeof(unsigned), st);
   switch (H) {
-    case 64: seq_bwd_launch<64>(ctx->stream, a); break;
-    case 128: seq_bwd_launch<128>(ctx->stream, a); break;
-    case 256: seq_bwd_launch<256>(ctx->stream, a); break;
+    case 64: seq_bwd_launch<64>(st, a); break;
+    case 128: seq_bwd_launch<128>(st, a); break;
+    case 256: seq_bwd_launch<256>(st, a); break;
     default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 256");
   }
   return 0;
@@ -323,20 +323,27 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * H), dim3(256), 0, s, carry0[n] + (size_t)(2 * l + 1) * N * H, idx, 1, N, B, H, H, H, w.tb[n].Cm[l]);
     }
   hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * KBJ_NU), dim3(256), 0, s, tr->carry0_lpf_d, idx, 1, N, B, KBJ_NU, KBJ_NU, KBJ_NU, w.lpf0);
-  // ---- forward through time ----
+  // ---- forward through time: actor on the caller's stream, critic on the context's second stream (the recurrences are
+  // latency bound, so the two nets overlap) ----
+  hipStream_t ns[2] = {ctx->stream, ctx->stream2};
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   for (int n = 0; n < 2; ++n) {
     const NetOff& o = w.net[n];
     TrainBufs& t = w.tb[n];
+    hipStream_t s = ns[n];
     linear_fwd(s, t.obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, t.X0, H, R, H, o.nin, 0);
     const float* xin = t.X0;
     for (int l = 0; l < 2; ++l) {
       linear_fwd(s, xin, H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
-      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters, w.seq_err, T, B};
-      if (seq_fwd(ctx, H, fa)) return -1;
+      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * n, w.seq_err, T, B};
+      if (seq_fwd(ctx, s, H, fa)) return -1;
       xin = t.Hout[l];
     }
     linear_fwd(s, xin, H, params_d + o.w_out, H, params_d + o.b_out, t.Out, 40, R, o.nout, H, 0);
   }
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
   hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[0].Out, w.tb[0].obs, w.keep, w.lpf0, w.joint_bias_d, hp, T, B, w.y, w.sd);
   hipLaunchKernelGGL(gaussian_logp_kernel, g1(R), dim3(256), 0, s, w.y, w.sd, w.act, R, w.logp, w.ent);
@@ -355,9 +362,12 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[0].Out, w.y, w.sd, w.act, w.keep, w.dlogp,
                      -c.entropy_coef / (float)R, hp, T, B, w.tb[0].dOut);
   KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[1].dOut, 40 * sizeof(float), w.dvalue, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, s));
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   for (int n = 0; n < 2; ++n) {
     const NetOff& o = w.net[n];
     TrainBufs& t = w.tb[n];
+    hipStream_t s = ns[n];
     // output projection
     linear_bwd_weight(s, t.dOut, 40, t.Hout[1], H, grad_d + o.w_out, H, o.nout, H, R);
     hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 64), dim3(256), 0, s, t.dOut, R, o.nout, 40, grad_d + o.b_out);
@@ -365,8 +375,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     float* dh_above = t.dHa;
     float* dx_out = t.dHb;
     for (int l = 1; l >= 0; --l) {
-      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above, w.keep, params_d + o.w_hh[l], t.dG, w.seq_counters, w.seq_err, T, B};
-      if (seq_bwd(ctx, H, ba)) return -1;
+      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above, w.keep, params_d + o.w_hh[l], t.dG, w.seq_counters + 256 * n, w.seq_err, T, B};
+      if (seq_bwd(ctx, s, H, ba)) return -1;
       const float* xin = l == 0 ? t.X0 : t.Hout[0];
       linear_bwd_weight(s, t.dG, 4 * H, t.Hm[l], H, grad_d + o.w_hh[l], H, 4 * H, H, R);
       linear_bwd_weight(s, t.dG, 4 * H, xin, H, grad_d + o.w_ih[l], H, 4 * H, H, R);
@@ -378,6 +388,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     linear_bwd_weight(s, dh_above, H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
     hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, 64), dim3(256), 0, s, dh_above, R, H, H, grad_d + o.b_in);
   }
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_grad");
   return 0;
 }
