@@ -29,7 +29,10 @@ __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restri
   PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
 }
 
-__global__ __launch_bounds__(64) void env_step_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, uint32_t seed,
+#ifndef KBJ_ENV_NUM_VGPR
+#define KBJ_ENV_NUM_VGPR 128
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR))) void env_step_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, uint32_t seed,
                                                       float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ action,
                                                       float* aux_t, float* actor_next, float* critic_next, float* aux_next) {
   __shared__ KbjShared S;

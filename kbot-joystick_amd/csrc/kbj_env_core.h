@@ -131,37 +131,52 @@ KBJ_DEV void rotate_by_quat(const float* v, const float* q_in, bool inverse, flo
   quat_to_mat(q, mat); mat_vec(mat, v, o);
 }
 
-// ---- wave reductions: xor butterfly, identical summation order on the GPU and in the emulation ----
+// ---- wave reductions ------------------------------------------------------------------------------------------
+// Sum of one value per lane. Order (identical on the GPU and in the emulation, so both give the same bits):
+// within each row of 16 lanes: v += v[l^1]; v += v[l^2]; v += v[mirror in 8]; v += v[mirror in 16]  (DPP quad_perm /
+// row_half_mirror / row_mirror: register-to-register, no LDS), then ((row0 + row1) + row2) + row3 via v_readlane.
 #ifdef KBJ_EMU
+KBJ_DEV float wsum_lanes(float* v) {
+  float t[64];
+  for (int l = 0; l < 64; ++l) t[l] = v[l] + v[l ^ 1];
+  for (int l = 0; l < 64; ++l) v[l] = t[l] + t[l ^ 2];
+  for (int l = 0; l < 64; ++l) t[l] = v[l] + v[(l & ~7) | (7 - (l & 7))];
+  for (int l = 0; l < 64; ++l) v[l] = t[l] + t[(l & ~15) | (15 - (l & 15))];
+  return ((v[0] + v[16]) + v[32]) + v[48];
+}
 template <class F> KBJ_DEV float wsum(int n, F f) {
   float v[64];
   for (int l = 0; l < 64; ++l) v[l] = l < n ? f(l) : 0.0f;
-  for (int msk = 32; msk >= 1; msk >>= 1) { float t[64]; for (int l = 0; l < 64; ++l) t[l] = v[l] + v[l ^ msk]; for (int l = 0; l < 64; ++l) v[l] = t[l]; }
-  return v[0];
+  return wsum_lanes(v);
 }
 template <class F> KBJ_DEV void wsum2(int n, F f, float& a, float& b) {
   float va[64], vb[64];
   for (int l = 0; l < 64; ++l) { va[l] = 0; vb[l] = 0; if (l < n) f(l, va[l], vb[l]); }
-  for (int msk = 32; msk >= 1; msk >>= 1) {
-    float ta[64], tb[64];
-    for (int l = 0; l < 64; ++l) { ta[l] = va[l] + va[l ^ msk]; tb[l] = vb[l] + vb[l ^ msk]; }
-    for (int l = 0; l < 64; ++l) { va[l] = ta[l]; vb[l] = tb[l]; }
-  }
-  a = va[0]; b = vb[0];
+  a = wsum_lanes(va); b = wsum_lanes(vb);
 }
 #else
+template <int CTRL> KBJ_DEV float dpp_add(float v) {
+  int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true);
+  return v + __int_as_float(t);
+}
+KBJ_DEV float wsum_lanes(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
+  float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+  float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+  return ((r0 + r1) + r2) + r3;
+}
 template <class F> KBJ_DEV float wsum(int n, F f) {
   int l = KBJ_LANE;
-  float v = l < n ? f(l) : 0.0f;
-  for (int msk = 32; msk >= 1; msk >>= 1) v += __shfl_xor(v, msk, 64);
-  return v;
+  return wsum_lanes(l < n ? f(l) : 0.0f);
 }
 template <class F> KBJ_DEV void wsum2(int n, F f, float& a, float& b) {
   int l = KBJ_LANE;
   float va = 0, vb = 0;
   if (l < n) f(l, va, vb);
-  for (int msk = 32; msk >= 1; msk >>= 1) { va += __shfl_xor(va, msk, 64); vb += __shfl_xor(vb, msk, 64); }
-  a = va; b = vb;
+  a = wsum_lanes(va); b = wsum_lanes(vb);
 }
 #endif
 

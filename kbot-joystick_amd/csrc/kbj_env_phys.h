@@ -264,14 +264,11 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
     S.A[c][i][j] = v;
   }
   KBJ_SYNC();
+  // LDL^T elimination: column p keeps its unscaled entries (L_ip D_p), so each pivot is ONE phase
   for (int p = 0; p < 5; ++p) {
-    PFOR(c, 4) S.A[c][p][p] = sqrtf(S.A[c][p][p]);
-    KBJ_SYNC();
-    PFOR(w, 4 * 11) { int c = w / 11, i = p + 1 + w % 11; if (i <= 11) S.A[c][i][p] /= S.A[c][p][p]; }
-    KBJ_SYNC();
     PFOR(w, 4 * 121) {
       int c = w / 121, e = w % 121, i = p + 1 + e / 11, j = p + 1 + e % 11;
-      if (i <= 11 && j <= 10 && j <= i) S.A[c][i][j] -= S.A[c][i][p] * S.A[c][j][p];
+      if (i <= 11 && j <= 10 && j <= i) S.A[c][i][j] -= S.A[c][i][p] * S.A[c][j][p] / S.A[c][p][p];
     }
     KBJ_SYNC();
   }
@@ -285,11 +282,7 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
   }
   KBJ_SYNC();
   for (int p = 0; p < 6; ++p) {
-    PFOR(w, 1) S.B[p][p] = sqrtf(S.B[p][p]);
-    KBJ_SYNC();
-    PFOR(w, 6) { int i = p + 1 + w; if (i <= 6) S.B[i][p] /= S.B[p][p]; }
-    KBJ_SYNC();
-    PFOR(w, 36) { int i = p + 1 + w / 6, j = p + 1 + w % 6; if (i <= 6 && j <= 5 && j <= i) S.B[i][j] -= S.B[i][p] * S.B[j][p]; }
+    PFOR(w, 36) { int i = p + 1 + w / 6, j = p + 1 + w % 6; if (i <= 6 && j <= 5 && j <= i) S.B[i][j] -= S.B[i][p] * S.B[j][p] / S.B[p][p]; }
     KBJ_SYNC();
   }
   PFOR(w, 1) {

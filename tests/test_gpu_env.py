@@ -26,7 +26,7 @@ def test_reset_matches_oracle(which):
     from oracle import oracle as O
     m = compiler.load_model(which)
     N = 64
-    cfg = L.default_config(num_envs=N)
+    cfg = L.default_config(num_envs=N, batch_size=min(512, N))
     ctx, torch = _ctx(m, cfg)
     a, c, x = _obs(torch, N)
     ctx.env_reset_all(5, a, c, x)
@@ -49,7 +49,7 @@ def test_reset_matches_oracle(which):
 def test_teacher_forced_steps_match_oracle(model):
     from oracle import oracle as O
     N = 128
-    cfg = L.default_config(num_envs=N)
+    cfg = L.default_config(num_envs=N, batch_size=min(512, N))
     ctx, torch = _ctx(model, cfg)
     a, c, x = _obs(torch, N)
     a2, c2, x2 = _obs(torch, N)
@@ -88,7 +88,7 @@ def test_free_running_rollout_statistics(model):
     """Without teacher forcing trajectories diverge chaotically, but episode statistics must agree."""
     from oracle import oracle as O
     N = 256
-    cfg = L.default_config(num_envs=N)
+    cfg = L.default_config(num_envs=N, batch_size=min(512, N))
     ctx, torch = _ctx(model, cfg)
     a, c, x = _obs(torch, N)
     a2, c2, x2 = _obs(torch, N)
@@ -128,7 +128,7 @@ def test_free_running_rollout_statistics(model):
 def test_full_size_properties(model):
     """BASELINE config size (8192 envs): invariants that do not need the oracle."""
     N = 8192
-    cfg = L.default_config(num_envs=N)
+    cfg = L.default_config(num_envs=N, batch_size=min(512, N))
     ctx, torch = _ctx(model, cfg)
     a, c, x = _obs(torch, N)
     a2, c2, x2 = _obs(torch, N)
