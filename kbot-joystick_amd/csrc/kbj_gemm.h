@@ -169,10 +169,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
 // host-side launcher; picks the 128x128 tile for large outputs and 64x64 when that leaves the chip underfilled
 template <bool A_KC, bool B_KC>
-inline void gemm_launch(hipStream_t s, const GemmArgs& g) {
+inline void gemm_launch(hipStream_t s, const GemmArgs& g, int force_big = -1) {
   int sk = g.splitk > 1 ? g.splitk : 1;
   long big_blocks = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * sk;
-  if (big_blocks >= 192) {
+  bool big = force_big >= 0 ? force_big != 0 : big_blocks >= 192;
+  if (big) {
     dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, sk);
     hipLaunchKernelGGL((gemm_f32_kernel<2, 2, A_KC, B_KC>), grid, dim3(256), 0, s, g);
   } else {

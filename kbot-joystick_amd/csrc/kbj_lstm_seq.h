@@ -8,9 +8,13 @@
 //     (16x16x4 f32 MFMA: A = one f32 per lane [row = lane&15][k = lane>>4], B = [k = lane>>4][col = lane&15]);
 //   * the LSTM cell (forward) / its derivative (backward) is fused; the cell state / its gradient lives in registers;
 //   * per time step the only exchange is the h tile (forward) or dG tile (backward) of the SAME row group, produced by the
-//     H/16 workgroups of that row group: a monotonic per-row-group arrival counter with agent-scope release/acquire
-//     (cdna_hip_programming.md Guideline 16) replaces the kernel boundary. Grid = (B/32)(H/16) <= 256 workgroups, all
-//     resident; every spin is bounded and reports through an error word instead of hanging.
+//     H/16 workgroups of that row group. Hand-off protocol (cdna_hip_programming.md Guideline 16, recipe R1): the
+//     payload is stored write-through (sc1: relaxed agent-scope atomic stores), every storing wave drains, the
+//     workgroup meets, one lane bumps a monotonic per-row-group arrival counter; consumers poll that one word and read
+//     the payload with 16-byte sc1 buffer loads (L1 bypass), so neither a release nor an acquire cache operation is
+//     needed. The poll is issued with an empty vector-memory queue: stores nobody reads inside the launch (activations
+//     kept for BPTT) and prefetches of the next step's own inputs are issued AFTER the payload loads, behind the MFMAs.
+//     Grid = (B/32)(H/16) <= 256 workgroups, all resident; every spin is bounded and reports through an error word.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -34,6 +38,7 @@ struct SeqFwdArgs {
   unsigned* counters;  // [ceil(B/32)] zeroed before launch
   unsigned* err;       // set to 1 on a spin timeout
   int T, B;
+  long long* stamps;   // optional [T][6] shader-clock stamps of workgroup 0 (diagnostics), else null
 };
 
 struct SeqBwdArgs {
@@ -51,29 +56,59 @@ struct SeqBwdArgs {
 
 __device__ __forceinline__ float seq_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// wait until *ctr >= target (one lane polls, the workgroup then acquires); returns false on timeout
-__device__ __forceinline__ bool seq_wait(unsigned* ctr, unsigned target, unsigned* err, int* lds_flag) {
-  if (threadIdx.x == 0) {
+// wait until *ctr >= target: one lane polls the one word (relaxed, agent scope); returns false on timeout
+// flags: one word per producer workgroup of the row group (nflags consecutive words = one cache line), each holding the
+// number of steps that producer has published; lanes 0..nflags-1 of wave 0 poll them with sc1 loads until all reach target
+__device__ __forceinline__ bool seq_wait(unsigned* flags, int nflags, unsigned target, unsigned* err, int* lds_flag) {
+  if (threadIdx.x < 64) {
     unsigned spins = 0;
     int ok = 1;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    const int l = threadIdx.x;
+    for (;;) {
+      bool mine = l >= nflags || __hip_atomic_load(flags + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
+      if (__all(mine)) break;
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > SEQ_SPIN_LIMIT) { ok = 0; __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > SEQ_SPIN_LIMIT) { ok = 0; if (l == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    *lds_flag = ok;
+    if (l == 0) *lds_flag = ok;
   }
   __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the payload loads below the poll
   return *lds_flag != 0;
 }
-// The handed-off payload is stored write-through (sc1: relaxed agent-scope atomic stores, seq_store), so publishing
-// needs no release fence: every storing wave drains its stores, the workgroup meets, one lane bumps the counter.
+// payload store: write-through (sc1)
 __device__ __forceinline__ void seq_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void seq_publish(unsigned* ctr) {
+// every storing wave drains its (payload) stores, the workgroup meets, one lane signals
+__device__ __forceinline__ void seq_publish(unsigned* my_flag, unsigned steps_done) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) __hip_atomic_store(my_flag, steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 store, never a plain one
 }
+// payload tile: rows [r0, r0+32) x H floats of a handed-off [B][ld] array, 16-byte buffer loads with the sc1 bit
+// (aux = 16: bypass this CU's L1; counted by the compiler's s_waitcnt), then written to LDS as [32][H+4]
+template <int H> struct SeqTile {
+  static constexpr int NV = SEQ_ROWS * (H / 4) / 256;
+  f32x4m v[NV];
+  __device__ __forceinline__ void load(const float* src, int ld, int r0, int B) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7FFFFFFF, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int q = threadIdx.x + 256 * i, row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
+      unsigned off = (unsigned)(((size_t)(r < B ? r : 0) * ld + 4 * c4) * sizeof(float));
+      u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
+      v[i] = __builtin_bit_cast(f32x4m, u);
+      if (r >= B) v[i] = f32x4m{0, 0, 0, 0};
+    }
+  }
+  __device__ __forceinline__ void to_lds(float* lds) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int q = threadIdx.x + 256 * i, row = q / (H / 4), c4 = q % (H / 4);
+      *reinterpret_cast<f32x4m*>(lds + row * (H + 4) + 4 * c4) = v[i];
+    }
+  }
+};
 
 template <int H>
 __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
@@ -83,7 +118,11 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   __shared__ float gbuf[4][SEQ_ROWS][SEQ_UNITS + 1];
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, gate = tid >> 6;
-  const int ug = blockIdx.x % NUG, rg = blockIdx.x / NUG;
+  // XCD-aware mapping (speed only, the protocol is placement independent): workgroups b, b+8, b+16, ... share an XCD,
+  // so give each XCD whole row groups and the tile hand-off stays inside one L2
+  const int nblk = gridDim.x;
+  const int lid = (nblk % 8 == 0) ? (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * SEQ_ROWS, u0 = ug * SEQ_UNITS;
   const int B = a.B, T = a.T;
   // W_hh rows of this wave's gate for the 16 units, as B operands: B[k][col] = Whh[gate H + u0 + col][k]
@@ -103,17 +142,15 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     int r = r0 + erow[i];
     cm[i] = r < B ? a.Cm[(size_t)r * H + u0 + eunit[i]] : 0.0f;
   }
+  float ig[2], fg[2], gg[2], og[2], tc[2], hh[2];  // results of the previous step, stored lazily
+#define SEQ_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 6 + (k)] = clock64(); } while (0)
   for (int t = 0; t < T; ++t) {
-    if (t > 0) { if (!seq_wait(a.counters + rg, (unsigned)(NUG * t), a.err, &flag)) return; }
-    // stage h_{t-1} rows of this row group (all H columns)
-    const float* hsrc = a.Hm + (size_t)t * B * H;
-    for (int q = tid; q < SEQ_ROWS * (H / 4); q += 256) {
-      int row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
-      f32x4m v = {0, 0, 0, 0};
-      if (r < B) v = *reinterpret_cast<const f32x4m*>(hsrc + (size_t)r * H + 4 * c4);
-      *reinterpret_cast<f32x4m*>(hs + row * LDH + 4 * c4) = v;
-    }
-    // prefetch this step's input-projection pre-activations and keep flags
+    SEQ_STAMP(0);
+    if (t > 0) { if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)t, a.err, &flag)) return; }
+    SEQ_STAMP(1);
+    SeqTile<H> tile;
+    tile.load(a.Hm + (size_t)t * B * H, H, r0, B);
+    // behind the payload loads: this step's own inputs, then the previous step's BPTT stash
     float gx[2][4], kp[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -123,7 +160,21 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
       for (int k = 0; k < 4; ++k) gx[i][k] = r < B ? g[k * H] : 0.0f;
       kp[i] = r < B ? a.keep[(size_t)t * B + r] : 0.0f;
     }
+    if (t > 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int r = r0 + erow[i];
+        if (r >= B) continue;
+        size_t o1 = ((size_t)(t - 1) * B + r) * H + u0 + eunit[i];
+        float* g = a.G + ((size_t)(t - 1) * B + r) * 4 * H + u0 + eunit[i];
+        g[0] = ig[i]; g[H] = fg[i]; g[2 * H] = gg[i]; g[3 * H] = og[i];
+        a.Hout[o1] = hh[i]; a.TanhC[o1] = tc[i];
+        a.Cm[o1 + (size_t)B * H] = cm[i];
+      }
+    }
+    tile.to_lds(hs);
     __syncthreads();
+    SEQ_STAMP(2);
     f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     const float* a0p = hs + (lane & 15) * LDH + (lane >> 4);
     const float* a1p = a0p + 16 * LDH;
@@ -138,23 +189,31 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
       gbuf[gate][16 + (lane >> 4) * 4 + r][lane & 15] = acc1[r];
     }
     __syncthreads();
+    SEQ_STAMP(3);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int r = r0 + erow[i];
-      if (r >= B) continue;
       int row = erow[i], u = eunit[i];
-      float ig = seq_sigmoid(gbuf[0][row][u] + gx[i][0]), fg = seq_sigmoid(gbuf[1][row][u] + gx[i][1]);
-      float gg = tanhf(gbuf[2][row][u] + gx[i][2]), og = seq_sigmoid(gbuf[3][row][u] + gx[i][3]);
-      float c = fg * cm[i] + ig * gg, tc = tanhf(c), h = og * tc;
-      size_t o1 = ((size_t)t * B + r) * H + u0 + u;
-      float* g = a.G + ((size_t)t * B + r) * 4 * H + u0 + u;
-      g[0] = ig; g[H] = fg; g[2 * H] = gg; g[3 * H] = og;
-      a.Hout[o1] = h; a.TanhC[o1] = tc;
+      ig[i] = seq_sigmoid(gbuf[0][row][u] + gx[i][0]); fg[i] = seq_sigmoid(gbuf[1][row][u] + gx[i][1]);
+      gg[i] = tanhf(gbuf[2][row][u] + gx[i][2]); og[i] = seq_sigmoid(gbuf[3][row][u] + gx[i][3]);
+      float c = fg[i] * cm[i] + ig[i] * gg[i];
+      tc[i] = tanhf(c); hh[i] = og[i] * tc[i];
       cm[i] = c * kp[i];
-      seq_store(a.Hm + o1 + (size_t)B * H, h * kp[i]);   // consumed by the other workgroups of this row group
-      a.Cm[o1 + (size_t)B * H] = cm[i];
+      if (r0 + row < B) seq_store(a.Hm + ((size_t)(t + 1) * B + r0 + row) * H + u0 + u, hh[i] * kp[i]);  // the hand-off payload
     }
-    seq_publish(a.counters + rg);
+    SEQ_STAMP(4);
+    seq_publish(a.counters + rg * NUG + ug, (unsigned)(t + 1));
+    SEQ_STAMP(5);
+  }
+  // BPTT stash of the last step
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int r = r0 + erow[i];
+    if (r >= B) continue;
+    size_t o1 = ((size_t)(T - 1) * B + r) * H + u0 + eunit[i];
+    float* g = a.G + ((size_t)(T - 1) * B + r) * 4 * H + u0 + eunit[i];
+    g[0] = ig[i]; g[H] = fg[i]; g[2 * H] = gg[i]; g[3 * H] = og[i];
+    a.Hout[o1] = hh[i]; a.TanhC[o1] = tc[i];
+    a.Cm[o1 + (size_t)B * H] = cm[i];
   }
 }
 
@@ -162,11 +221,15 @@ template <int H>
 __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   constexpr int LDH = H + 4;
   constexpr int NUG = H / SEQ_UNITS;
-  __shared__ __attribute__((aligned(16))) float ds[SEQ_ROWS * LDH];   // one gate chunk of dG_{t+1}: [32][H]
-  __shared__ float pbuf[4][SEQ_ROWS][SEQ_UNITS + 1];                   // per-wave partial sums of dh
+  __shared__ __attribute__((aligned(16))) float ds[2][SEQ_ROWS * LDH];  // gate chunks of dG_{t+1}, double buffered
+  __shared__ float pbuf[4][SEQ_ROWS][SEQ_UNITS + 1];                     // per-wave partial sums of dh
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int ug = blockIdx.x % NUG, rg = blockIdx.x / NUG;
+  // XCD-aware mapping (speed only, the protocol is placement independent): workgroups b, b+8, b+16, ... share an XCD,
+  // so give each XCD whole row groups and the tile hand-off stays inside one L2
+  const int nblk = gridDim.x;
+  const int lid = (nblk % 8 == 0) ? (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+  const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * SEQ_ROWS, u0 = ug * SEQ_UNITS;
   const int B = a.B, T = a.T;
   constexpr int KW = H / 4;        // k range of one wave inside a gate chunk
@@ -183,37 +246,38 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   for (int i = 0; i < 2; ++i) { int e = tid + 256 * i; erow[i] = e / SEQ_UNITS; eunit[i] = e % SEQ_UNITS; }
   for (int t = T - 1; t >= 0; --t) {
     const bool last = t == T - 1;
-    // prefetch everything the cell derivative of step t needs
-    float act[2][4], tc[2], cprev[2], dha[2], kp[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int r = r0 + erow[i];
-      bool ok = r < B;
-      size_t o1 = ((size_t)t * B + (ok ? r : 0)) * H + u0 + eunit[i];
-      const float* g = a.Gact + ((size_t)t * B + (ok ? r : 0)) * 4 * H + u0 + eunit[i];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) act[i][k] = ok ? g[k * H] : 0.0f;
-      tc[i] = ok ? a.TanhC[o1] : 0.0f;
-      cprev[i] = ok ? a.Cm[o1] : 0.0f;
-      dha[i] = ok ? a.dHabove[o1] : 0.0f;
-      kp[i] = ok ? a.keep[(size_t)t * B + r] : 0.0f;
-    }
     float dhm[2] = {0.0f, 0.0f};
-    if (!last) {
-      if (!seq_wait(a.counters + rg, (unsigned)(NUG * (T - 1 - t)), a.err, &flag)) return;
+    float act[2][4], tc[2], cprev[2], dha[2], kp[2];
+    auto prefetch = [&]() {  // everything the cell derivative of step t needs (produced by earlier kernels)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int r = r0 + erow[i];
+        bool ok = r < B;
+        size_t o1 = ((size_t)t * B + (ok ? r : 0)) * H + u0 + eunit[i];
+        const float* g = a.Gact + ((size_t)t * B + (ok ? r : 0)) * 4 * H + u0 + eunit[i];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) act[i][k] = ok ? g[k * H] : 0.0f;
+        tc[i] = ok ? a.TanhC[o1] : 0.0f;
+        cprev[i] = ok ? a.Cm[o1] : 0.0f;
+        dha[i] = ok ? a.dHabove[o1] : 0.0f;
+        kp[i] = ok ? a.keep[(size_t)t * B + r] : 0.0f;
+      }
+    };
+    if (last) prefetch();
+    else {
+      if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)(T - 1 - t), a.err, &flag)) return;
       f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
       const float* src = a.dG + (size_t)(t + 1) * B * 4 * H;
+      SeqTile<H> tile;
+      tile.load(src, 4 * H, r0, B);
+      prefetch();                               // own inputs ride behind the first payload chunk
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        if (c) __syncthreads();
-        for (int q = tid; q < SEQ_ROWS * (H / 4); q += 256) {
-          int row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
-          f32x4m v = {0, 0, 0, 0};
-          if (r < B) v = *reinterpret_cast<const f32x4m*>(src + (size_t)r * 4 * H + c * H + 4 * c4);
-          *reinterpret_cast<f32x4m*>(ds + row * LDH + 4 * c4) = v;
-        }
+        float* buf = ds[c & 1];
+        tile.to_lds(buf);
+        if (c < 3) tile.load(src + (c + 1) * H, 4 * H, r0, B);   // next chunk in flight during this chunk's MFMAs
         __syncthreads();
-        const float* a0p = ds + (lane & 15) * LDH + wave * KW + (lane >> 4);
+        const float* a0p = buf + (lane & 15) * LDH + wave * KW + (lane >> 4);
         const float* a1p = a0p + 16 * LDH;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
@@ -238,13 +302,13 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       float dh = dha[i] + kp[i] * dhm[i];
       float dc = kp[i] * dcm[i] + dh * og * (1 - tc[i] * tc[i]);
       float* dg = a.dG + ((size_t)t * B + r) * 4 * H + u0 + eunit[i];
-      seq_store(dg, dc * gg * ig * (1 - ig));
+      seq_store(dg, dc * gg * ig * (1 - ig));            // dG is the hand-off payload (and the input of the batched dW GEMMs)
       seq_store(dg + H, dc * cprev[i] * fg * (1 - fg));
       seq_store(dg + 2 * H, dc * ig * (1 - gg * gg));
       seq_store(dg + 3 * H, dh * tc[i] * og * (1 - og));
       dcm[i] = dc * fg;
     }
-    seq_publish(a.counters + rg);
+    seq_publish(a.counters + rg * NUG + ug, (unsigned)(T - t));
   }
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <vector>
 #include <cmath>
+#include <cstdlib>
 #include "kbj_ctx.h"
 #include "kbj_gemm.h"
 #include "kbj_nn_kernels.h"
@@ -36,6 +37,7 @@ struct NnWs {
   double* stats = nullptr;  // [0..1] adv stats, [2..9] metric accumulators, [10] grad sumsq
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
+  long long* seq_stamps = nullptr;   // diagnostics (KBJ_SEQ_STAMPS=1): per-step clock stamps of one workgroup
   std::vector<void*> allocs;
 };
 
@@ -85,11 +87,14 @@ void linear_bwd_input(hipStream_t s, const float* dy, int lddy, const float* W, 
 }
 // dW[Nout][Nin] += dy^T x  (dy [R][Nout], x [R][Nin]); split-K over the R samples with atomics (dW pre-zeroed by the caller)
 void linear_bwd_weight(hipStream_t s, const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, int Nout, int Nin, int R) {
-  int tiles = ((Nout + 63) / 64) * ((Nin + 63) / 64);
-  int sk = std::max(1, std::min(64, 512 / std::max(1, tiles)));
-  sk = std::min(sk, (R + 255) / 256);
-  GemmArgs g{dy, x, dW, nullptr, Nout, Nin, R, lddy, ldx, lddw, 1, sk < 2 ? 2 : sk, nullptr};  // always the atomic path: accumulates into dW
-  gemm_launch<false, false>(s, g);
+  // the long contraction (R = T*B samples) is split over the grid: 128x128 tiles when the output allows it, ~768 workgroups
+  bool big = Nout >= 128 && Nin >= 128;
+  int ts = big ? 128 : 64;
+  int tiles = ((Nout + ts - 1) / ts) * ((Nin + ts - 1) / ts);
+  int sk = std::max(2, std::min(256, 768 / std::max(1, tiles)));
+  sk = std::max(2, std::min(sk, (R + 255) / 256));
+  GemmArgs g{dy, x, dW, nullptr, Nout, Nin, R, lddy, ldx, lddw, 1, sk, nullptr};  // always the atomic path: accumulates into dW
+  gemm_launch<false, false>(s, g, big ? 1 : 0);
 }
 
 template <int H> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a) {
@@ -126,6 +131,15 @@ int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {
 int kbj_nn_check_errors(kbj_ctx* ctx) {
   NnWs* w = ws_of(ctx);
   if (!w) return 0;
+  if (w->seq_stamps) {  // diagnostics: average shader-clock cycles per phase of the actor layer-0 forward recurrence
+    std::vector<long long> st((size_t)w->T * 6);
+    if (hipMemcpy(st.data(), w->seq_stamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess && w->T > 2) {
+      double d[6] = {0, 0, 0, 0, 0, 0};
+      for (int t = 1; t < w->T - 1; ++t) { for (int k = 0; k < 5; ++k) d[k] += (double)(st[t * 6 + k + 1] - st[t * 6 + k]); d[5] += (double)(st[(t + 1) * 6] - st[t * 6 + 5]); }
+      fprintf(stderr, "[kbj seq_fwd stamps, cycles/step] prefetch+wait %.0f stage %.0f mfma %.0f cell %.0f publish %.0f bulk-store %.0f\n",
+              d[0] / (w->T - 2), d[1] / (w->T - 2), d[2] / (w->T - 2), d[3] / (w->T - 2), d[4] / (w->T - 2), d[5] / (w->T - 2));
+    }
+  }
   unsigned e = 0;
   if (hipMemcpy(&e, w->seq_err, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return kbj_fail(ctx, "hipMemcpy seq_err");
   if (e) return kbj_fail(ctx, "persistent LSTM kernel: inter-workgroup wait timed out (grid not fully resident?)");
@@ -176,6 +190,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->stats, 16)) return -1;
   if (dalloc(ctx, *w, &w->seq_counters, 1024)) return -1;
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
+  if (getenv("KBJ_SEQ_STAMPS")) { if (dalloc(ctx, *w, &w->seq_stamps, (size_t)T * 6)) return -1; }
   if (hipMemset(w->seq_err, 0, 4 * sizeof(unsigned)) != hipSuccess) return kbj_fail(ctx, "hipMemset seq_err");
   if ((B + SEQ_ROWS - 1) / SEQ_ROWS * (H / SEQ_UNITS) > 256) return kbj_fail(ctx, "kbj_create: (batch_size/32)*(hidden/16) must be <= 256 (persistent LSTM kernel residency)");
   return 0;
@@ -336,7 +351,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     const float* xin = t.X0;
     for (int l = 0; l < 2; ++l) {
       linear_fwd(s, xin, H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
-      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * n, w.seq_err, T, B};
+      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * n, w.seq_err, T, B, (n == 0 && l == 0) ? w.seq_stamps : nullptr};
       if (seq_fwd(ctx, s, H, fa)) return -1;
       xin = t.Hout[l];
     }
