@@ -54,7 +54,9 @@ struct SeqBwdArgs {
   int T, B;
 };
 
-__device__ __forceinline__ float seq_sigmoid(float x) { return 1.0f / (1.0f + expf(-x)); }
+// gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each; shared with the rollout cell kernel)
+__device__ __forceinline__ float seq_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float seq_tanh(float x) { float xc = fminf(fmaxf(x, -15.0f), 15.0f); return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * xc)); }
 
 // wait until *ctr >= target: one lane polls the one word (relaxed, agent scope); returns false on timeout
 // flags: one word per producer workgroup of the row group (nflags consecutive words = one cache line), each holding the
@@ -144,22 +146,32 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   }
   float ig[2], fg[2], gg[2], og[2], tc[2], hh[2];  // results of the previous step, stored lazily
 #define SEQ_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 6 + (k)] = clock64(); } while (0)
+  // own inputs (input projection pre-activations, keep flags) are fetched ONE STEP AHEAD: their HBM latency hides behind
+  // a whole step instead of stalling the cell
+  float gxn[2][4], kpn[2];
+  auto fetch_inputs = [&](int tt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int r = r0 + erow[i];
+      bool ok = r < B && tt < T;
+      const float* g = a.G + ((size_t)(ok ? tt : 0) * B + (ok ? r : 0)) * 4 * H + u0 + eunit[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) gxn[i][k] = ok ? g[k * H] : 0.0f;
+      kpn[i] = ok ? a.keep[(size_t)tt * B + r] : 0.0f;
+    }
+  };
+  fetch_inputs(0);
   for (int t = 0; t < T; ++t) {
     SEQ_STAMP(0);
     if (t > 0) { if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)t, a.err, &flag)) return; }
     SEQ_STAMP(1);
     SeqTile<H> tile;
     tile.load(a.Hm + (size_t)t * B * H, H, r0, B);
-    // behind the payload loads: this step's own inputs, then the previous step's BPTT stash
+    // behind the payload loads: the next step's own inputs, then the previous step's BPTT stash
     float gx[2][4], kp[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int r = r0 + erow[i];
-      const float* g = a.G + ((size_t)t * B + (r < B ? r : 0)) * 4 * H + u0 + eunit[i];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) gx[i][k] = r < B ? g[k * H] : 0.0f;
-      kp[i] = r < B ? a.keep[(size_t)t * B + r] : 0.0f;
-    }
+    for (int i = 0; i < 2; ++i) { kp[i] = kpn[i]; for (int k = 0; k < 4; ++k) gx[i][k] = gxn[i][k]; }
+    fetch_inputs(t + 1);
     if (t > 0) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -194,9 +206,9 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     for (int i = 0; i < 2; ++i) {
       int row = erow[i], u = eunit[i];
       ig[i] = seq_sigmoid(gbuf[0][row][u] + gx[i][0]); fg[i] = seq_sigmoid(gbuf[1][row][u] + gx[i][1]);
-      gg[i] = tanhf(gbuf[2][row][u] + gx[i][2]); og[i] = seq_sigmoid(gbuf[3][row][u] + gx[i][3]);
+      gg[i] = seq_tanh(gbuf[2][row][u] + gx[i][2]); og[i] = seq_sigmoid(gbuf[3][row][u] + gx[i][3]);
       float c = fg[i] * cm[i] + ig[i] * gg[i];
-      tc[i] = tanhf(c); hh[i] = og[i] * tc[i];
+      tc[i] = seq_tanh(c); hh[i] = og[i] * tc[i];
       cm[i] = c * kp[i];
       if (r0 + row < B) seq_store(a.Hm + ((size_t)(t + 1) * B + r0 + row) * H + u0 + u, hh[i] * kp[i]);  // the hand-off payload
     }
@@ -244,24 +256,32 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   float dcm[2] = {0.0f, 0.0f};
 #pragma unroll
   for (int i = 0; i < 2; ++i) { int e = tid + 256 * i; erow[i] = e / SEQ_UNITS; eunit[i] = e % SEQ_UNITS; }
+  // everything the cell derivative of a step needs (produced by earlier kernels) is fetched ONE STEP AHEAD
+  float actn[2][4], tcn[2], cprevn[2], dhan[2], kpn[2];
+  auto fetch_inputs = [&](int tt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      int r = r0 + erow[i];
+      bool ok = r < B && tt >= 0;
+      size_t o1 = ((size_t)(ok ? tt : 0) * B + (ok ? r : 0)) * H + u0 + eunit[i];
+      const float* g = a.Gact + ((size_t)(ok ? tt : 0) * B + (ok ? r : 0)) * 4 * H + u0 + eunit[i];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) actn[i][k] = ok ? g[k * H] : 0.0f;
+      tcn[i] = ok ? a.TanhC[o1] : 0.0f;
+      cprevn[i] = ok ? a.Cm[o1] : 0.0f;
+      dhan[i] = ok ? a.dHabove[o1] : 0.0f;
+      kpn[i] = ok ? a.keep[(size_t)tt * B + r] : 0.0f;
+    }
+  };
+  fetch_inputs(T - 1);
   for (int t = T - 1; t >= 0; --t) {
     const bool last = t == T - 1;
     float dhm[2] = {0.0f, 0.0f};
     float act[2][4], tc[2], cprev[2], dha[2], kp[2];
-    auto prefetch = [&]() {  // everything the cell derivative of step t needs (produced by earlier kernels)
+    auto prefetch = [&]() {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        int r = r0 + erow[i];
-        bool ok = r < B;
-        size_t o1 = ((size_t)t * B + (ok ? r : 0)) * H + u0 + eunit[i];
-        const float* g = a.Gact + ((size_t)t * B + (ok ? r : 0)) * 4 * H + u0 + eunit[i];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) act[i][k] = ok ? g[k * H] : 0.0f;
-        tc[i] = ok ? a.TanhC[o1] : 0.0f;
-        cprev[i] = ok ? a.Cm[o1] : 0.0f;
-        dha[i] = ok ? a.dHabove[o1] : 0.0f;
-        kp[i] = ok ? a.keep[(size_t)t * B + r] : 0.0f;
-      }
+      for (int i = 0; i < 2; ++i) { tc[i] = tcn[i]; cprev[i] = cprevn[i]; dha[i] = dhan[i]; kp[i] = kpn[i]; for (int k = 0; k < 4; ++k) act[i][k] = actn[i][k]; }
+      fetch_inputs(t - 1);
     };
     if (last) prefetch();
     else {

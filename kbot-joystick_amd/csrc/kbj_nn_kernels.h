@@ -10,7 +10,9 @@ namespace kbj {
 
 constexpr float kLog2Pi = 1.8378770664093453f;
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// gate non-linearities on the hardware exp/rcp units (same definitions as kbj_lstm_seq.h so rollout and update agree)
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { float xc = fminf(fmaxf(x, -15.0f), 15.0f); return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * xc)); }
 __device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
 // ---- LSTM cell, forward ----------------------------------------------------------------------------------------
@@ -28,9 +30,9 @@ __global__ void lstm_cell_fwd_kernel(CellFwdArgs2 args) {
   if (idx >= a.M * a.H) return;
   int m = idx / a.H, u = idx - m * a.H;
   float* g = a.G + (size_t)m * 4 * a.H;
-  float i = sigmoidf_(g[u]), f = sigmoidf_(g[a.H + u]), gg = tanhf(g[2 * a.H + u]), o = sigmoidf_(g[3 * a.H + u]);
+  float i = sigmoidf_(g[u]), f = sigmoidf_(g[a.H + u]), gg = tanhf_(g[2 * a.H + u]), o = sigmoidf_(g[3 * a.H + u]);
   float c = f * a.c_prev[idx] + i * gg;
-  float tc = tanhf(c), h = o * tc;
+  float tc = tanhf_(c), h = o * tc;
   g[u] = i; g[a.H + u] = f; g[2 * a.H + u] = gg; g[3 * a.H + u] = o;
   a.h_out[idx] = h;
   a.c_out[idx] = c;
