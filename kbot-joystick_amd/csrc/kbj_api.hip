@@ -76,6 +76,10 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   KBJ_TRY(hipEventCreate(&ctx->ev0));
   KBJ_TRY(hipEventCreate(&ctx->ev1));
   KBJ_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  for (int n = 0; n < 2; ++n) {
+    KBJ_TRY(hipStreamCreateWithFlags(&ctx->side[n], hipStreamNonBlocking));
+    KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_side[n], hipEventDisableTiming));
+  }
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
 #undef KBJ_TRY
@@ -98,6 +102,10 @@ int kbj_destroy(kbj_ctx* ctx) {
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);
+  for (int n = 0; n < 2; ++n) {
+    if (ctx->side[n]) hipStreamDestroy(ctx->side[n]);
+    if (ctx->ev_side[n]) hipEventDestroy(ctx->ev_side[n]);
+  }
   delete ctx;
   return 0;
 }

@@ -10,6 +10,8 @@ struct kbj_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // second lane for the critic network inside kbj_ppo_grad
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipStream_t side[2] = {nullptr, nullptr};   // per-net side lanes for weight-gradient GEMMs
+  hipEvent_t ev_side[2] = {nullptr, nullptr};
   kbj_model model_h;
   kbj_config cfg_h;
   kbj_model* model_d = nullptr;

@@ -7,7 +7,9 @@
 //   dW = dy^T x       (A: dy [K][M] row-contig, B: x [K][N] row-contig)  weight gradients (split-K + atomics)
 // Tiling: workgroup = 4 wavefronts (2x2), each wavefront owns MT x NT 32x32 accumulator tiles (64 VGPRs at 2x2);
 // K is consumed in 32-wide LDS tiles. k-contiguous operands sit in LDS as [row][36] (ds_read_b128 fragments,
-// conflict-free), row-contiguous ones as [k][row] (4 x ds_read_b32).
+// conflict-free), row-contiguous ones as [k][row] (4 x ds_read_b32). The global loads of tile k+1 are issued into
+// registers before the MFMAs of tile k and written to LDS after them (software pipelining: HBM/L2 latency behind the
+// matrix pipe).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -21,12 +23,64 @@ struct GemmArgs {
   int M, N, K;          // C is M x N, contraction length K
   int lda, ldb, ldc;    // leading dimensions (elements) of the stored arrays
   int beta;             // 1: C += result, 0: C = result
-  int splitk;           // >1: grid.z slices of K, results atomically added into C (C must be pre-zeroed or beta semantics handled by caller)
-  const int* a_rows;    // optional gather: logical row m of A is stored row a_rows[m] (k-contiguous A only)
+  int splitk;           // >1: grid.z slices of K, results atomically added into C
+  const int* a_rows;    // unused (reserved)
 };
 
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_LDK = 36;  // padded k stride of a k-contiguous LDS tile
+
+// one operand tile (ROWS rows x 32 k) staged through registers: 256 threads, ROWS/32 float4 each
+template <int ROWS, bool KC>
+struct GemmStage {
+  static constexpr int NV = ROWS / 32;
+  f32x4 v[NV];
+  // P: operand base, ld, R: number of valid rows, r0: first row of the tile, k0/kend: k range
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int R, int r0, int k0, int kend, bool vec) {
+    const int tid = threadIdx.x;
+    if (KC) {
+      const int kq = tid & 7, rr = tid >> 3;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int r = r0 + rr + 32 * i, k = k0 + 4 * kq;
+        f32x4 x = {0, 0, 0, 0};
+        if (r < R) {
+          size_t base = (size_t)r * ld;
+          if (vec && k + 3 < kend) x = *reinterpret_cast<const f32x4*>(P + base + k);
+          else { for (int e = 0; e < 4; ++e) if (k + e < kend) x[e] = P[base + k + e]; }
+        }
+        v[i] = x;
+      }
+    } else {
+      constexpr int QPR = ROWS / 4, KROWS = 256 / QPR;
+      const int rq = tid % QPR, kr0 = tid / QPR;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int k = k0 + kr0 + KROWS * i, r = r0 + 4 * rq;
+        f32x4 x = {0, 0, 0, 0};
+        if (k < kend) {
+          size_t base = (size_t)k * ld;
+          if (vec && r + 3 < R) x = *reinterpret_cast<const f32x4*>(P + base + r);
+          else { for (int e = 0; e < 4; ++e) if (r + e < R) x[e] = P[base + r + e]; }
+        }
+        v[i] = x;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* lds) const {
+    const int tid = threadIdx.x;
+    if (KC) {
+      const int kq = tid & 7, rr = tid >> 3;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(lds + (rr + 32 * i) * GEMM_LDK + 4 * kq) = v[i];
+    } else {
+      constexpr int QPR = ROWS / 4, KROWS = 256 / QPR;
+      const int rq = tid % QPR, kr0 = tid / QPR;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(lds + (kr0 + KROWS * i) * (ROWS + 4) + 4 * rq) = v[i];
+    }
+  }
+};
 
 template <int MT, int NT, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
@@ -53,75 +107,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const bool a_vec = A_KC ? ((g.lda & 3) == 0 && (((size_t)g.A & 15) == 0)) : ((g.lda & 3) == 0 && (((size_t)g.A & 15) == 0));
-  const bool b_vec = B_KC ? ((g.ldb & 3) == 0 && (((size_t)g.B & 15) == 0)) : ((g.ldb & 3) == 0 && (((size_t)g.B & 15) == 0));
-
-  for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
-    // ---- stage A tile ----
-    if (A_KC) {
-      // BM rows x 32 k: 8 float4 per row; thread t -> k-quad t%8, rows t/8 + 32 i
-      const int kq = tid & 7, r0 = tid >> 3;
-#pragma unroll
-      for (int i = 0; i < BM / 32; ++i) {
-        int row = r0 + 32 * i, m = m0 + row, k = k0 + 4 * kq;
-        f32x4 v = {0, 0, 0, 0};
-        if (m < g.M) {
-          size_t base = (size_t)(g.a_rows ? g.a_rows[m] : m) * g.lda;
-          if (a_vec && k + 3 < kend) v = *reinterpret_cast<const f32x4*>(g.A + base + k);
-          else { for (int e = 0; e < 4; ++e) if (k + e < kend) v[e] = g.A[base + k + e]; }
-        }
-        *reinterpret_cast<f32x4*>(As + row * GEMM_LDK + 4 * kq) = v;
-      }
-    } else {
-      // 32 k-rows x BM m: BM/4 float4 per k-row
-      constexpr int QPR = BM / 4;           // float4 per k-row
-      constexpr int KROWS = 256 / QPR;      // k-rows covered per pass
-      const int mq = tid % QPR, kr0 = tid / QPR;
-#pragma unroll
-      for (int i = 0; i < GEMM_BK / KROWS; ++i) {
-        int kr = kr0 + KROWS * i, k = k0 + kr, m = m0 + 4 * mq;
-        f32x4 v = {0, 0, 0, 0};
-        if (k < kend) {
-          size_t base = (size_t)k * g.lda;
-          if (a_vec && m + 3 < g.M) v = *reinterpret_cast<const f32x4*>(g.A + base + m);
-          else { for (int e = 0; e < 4; ++e) if (m + e < g.M) v[e] = g.A[base + m + e]; }
-        }
-        *reinterpret_cast<f32x4*>(As + kr * (BM + 4) + 4 * mq) = v;
-      }
-    }
-    // ---- stage B tile ----
-    if (B_KC) {
-      const int kq = tid & 7, r0 = tid >> 3;
-#pragma unroll
-      for (int i = 0; i < BN / 32; ++i) {
-        int row = r0 + 32 * i, n = n0 + row, k = k0 + 4 * kq;
-        f32x4 v = {0, 0, 0, 0};
-        if (n < g.N) {
-          size_t base = (size_t)n * g.ldb;
-          if (b_vec && k + 3 < kend) v = *reinterpret_cast<const f32x4*>(g.B + base + k);
-          else { for (int e = 0; e < 4; ++e) if (k + e < kend) v[e] = g.B[base + k + e]; }
-        }
-        *reinterpret_cast<f32x4*>(Bs + row * GEMM_LDK + 4 * kq) = v;
-      }
-    } else {
-      constexpr int QPR = BN / 4;
-      constexpr int KROWS = 256 / QPR;
-      const int nq = tid % QPR, kr0 = tid / QPR;
-#pragma unroll
-      for (int i = 0; i < GEMM_BK / KROWS; ++i) {
-        int kr = kr0 + KROWS * i, k = k0 + kr, n = n0 + 4 * nq;
-        f32x4 v = {0, 0, 0, 0};
-        if (k < kend) {
-          size_t base = (size_t)k * g.ldb;
-          if (b_vec && n + 3 < g.N) v = *reinterpret_cast<const f32x4*>(g.B + base + n);
-          else { for (int e = 0; e < 4; ++e) if (n + e < g.N) v[e] = g.B[base + n + e]; }
-        }
-        *reinterpret_cast<f32x4*>(Bs + kr * (BN + 4) + 4 * nq) = v;
-      }
-    }
+  const bool a_vec = (g.lda & 3) == 0 && (((size_t)g.A & 15) == 0);
+  const bool b_vec = (g.ldb & 3) == 0 && (((size_t)g.B & 15) == 0);
+  GemmStage<BM, A_KC> sa;
+  GemmStage<BN, B_KC> sb;
+  const int lr = lane & 31, lh = lane >> 5;
+  if (kbeg < kend) {
+    sa.load(g.A, g.lda, g.M, m0, kbeg, kend, a_vec);
+    sb.load(g.B, g.ldb, g.N, n0, kbeg, kend, b_vec);
+    sa.store(As); sb.store(Bs);
     __syncthreads();
-    // ---- MFMA over the 32-wide k tile: 4 groups of 8 k; lane half h = lane>>5 owns k = 8 kk + 4 h + j ----
-    const int lr = lane & 31, lh = lane >> 5;
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
+    const bool more = k0 + GEMM_BK < kend;
+    if (more) {  // next tile in flight during this tile's MFMAs
+      sa.load(g.A, g.lda, g.M, m0, k0 + GEMM_BK, kend, a_vec);
+      sb.load(g.B, g.ldb, g.N, n0, k0 + GEMM_BK, kend, b_vec);
+    }
+    // MFMA over the 32-wide k tile: 4 groups of 8 k; lane half lh owns k = 8 kk + 4 lh + e
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       f32x4 a[MT], b[NT];
@@ -145,9 +148,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
           for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+    if (more) { sa.store(As); sb.store(Bs); __syncthreads(); }
   }
   // ---- epilogue: accumulator (col = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)) -> C ----
-  const int lr = lane & 31, lh = lane >> 5;
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll

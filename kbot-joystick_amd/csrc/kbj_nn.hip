@@ -20,7 +20,7 @@ struct NetOff {  // float offsets into the flat parameter vector (kbj.h layout =
 };
 
 struct TrainBufs {  // per net, minibatch-sized
-  float *obs, *X0, *G[2], *Hm[2], *Hout[2], *Cm[2], *TanhC[2], *Out, *dOut, *dHa, *dHb, *dG, *dhm, *dcm[2];
+  float *obs, *X0, *G[2], *Hm[2], *Hout[2], *Cm[2], *TanhC[2], *Out, *dOut, *dHa, *dHb, *dGl[2], *dhm, *dcm[2];
 };
 
 struct NnWs {
@@ -178,7 +178,8 @@ int kbj_nn_create(kbj_ctx* ctx) {
     if (dalloc(ctx, *w, &t.dOut, R * 40)) return -1;
     if (dalloc(ctx, *w, &t.dHa, R * H)) return -1;
     if (dalloc(ctx, *w, &t.dHb, R * H)) return -1;
-    if (dalloc(ctx, *w, &t.dG, R * 4 * H)) return -1;
+    if (dalloc(ctx, *w, &t.dGl[0], R * 4 * H)) return -1;
+    if (dalloc(ctx, *w, &t.dGl[1], R * 4 * H)) return -1;
     if (dalloc(ctx, *w, &t.dhm, B * H)) return -1;
   }
   float** small[] = {&w->keep, &w->logp_old, &w->val_old, &w->adv, &w->target, &w->logp, &w->ent, &w->value, &w->dlogp, &w->dvalue};
@@ -340,7 +341,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * KBJ_NU), dim3(256), 0, s, tr->carry0_lpf_d, idx, 1, N, B, KBJ_NU, KBJ_NU, KBJ_NU, w.lpf0);
   // ---- forward through time: actor on the caller's stream, critic on the context's second stream (the recurrences are
   // latency bound, so the two nets overlap) ----
-  hipStream_t ns[2] = {ctx->stream, ctx->stream2};
+  static const bool one_stream = getenv("KBJ_ONE_STREAM") != nullptr;   // diagnostics: serialise the two nets
+  hipStream_t ns[2] = {ctx->stream, one_stream ? ctx->stream : ctx->stream2};
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   for (int n = 0; n < 2; ++n) {
@@ -383,25 +385,32 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     const NetOff& o = w.net[n];
     TrainBufs& t = w.tb[n];
     hipStream_t s = ns[n];
-    // output projection
-    linear_bwd_weight(s, t.dOut, 40, t.Hout[1], H, grad_d + o.w_out, H, o.nout, H, R);
-    hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 64), dim3(256), 0, s, t.dOut, R, o.nout, 40, grad_d + o.b_out);
+    // The critical path of a net is dOut -> dH -> (recurrence, dX) per layer. Weight/bias gradients hang off it: they go to a
+    // side stream (ws) so the throughput-bound split-K GEMMs fill the chip under the latency-bound recurrences.
+    hipStream_t ws = one_stream ? s : ctx->side[n];
+    auto fork_side = [&]() { hipEventRecord(ctx->ev_side[n], s); hipStreamWaitEvent(ws, ctx->ev_side[n], 0); };
     linear_bwd_input(s, t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
+    if (!one_stream) fork_side();
+    linear_bwd_weight(ws, t.dOut, 40, t.Hout[1], H, grad_d + o.w_out, H, o.nout, H, R);
+    hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 64), dim3(256), 0, ws, t.dOut, R, o.nout, 40, grad_d + o.b_out);
     float* dh_above = t.dHa;
     float* dx_out = t.dHb;
     for (int l = 1; l >= 0; --l) {
-      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above, w.keep, params_d + o.w_hh[l], t.dG, w.seq_counters + 256 * n, w.seq_err, T, B};
+      float* dG = t.dGl[l];
+      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above, w.keep, params_d + o.w_hh[l], dG, w.seq_counters + 256 * n, w.seq_err, T, B};
       if (seq_bwd(ctx, s, H, ba)) return -1;
+      if (!one_stream) fork_side();
       const float* xin = l == 0 ? t.X0 : t.Hout[0];
-      linear_bwd_weight(s, t.dG, 4 * H, t.Hm[l], H, grad_d + o.w_hh[l], H, 4 * H, H, R);
-      linear_bwd_weight(s, t.dG, 4 * H, xin, H, grad_d + o.w_ih[l], H, 4 * H, H, R);
-      hipLaunchKernelGGL(colsum_kernel, dim3((4 * H + 63) / 64, 64), dim3(256), 0, s, t.dG, R, 4 * H, 4 * H, grad_d + o.b[l]);
-      linear_bwd_input(s, t.dG, 4 * H, params_d + o.w_ih[l], H, dx_out, H, R, H, 4 * H, 0);
+      linear_bwd_input(s, dG, 4 * H, params_d + o.w_ih[l], H, dx_out, H, R, H, 4 * H, 0);
+      linear_bwd_weight(ws, dG, 4 * H, t.Hm[l], H, grad_d + o.w_hh[l], H, 4 * H, H, R);
+      linear_bwd_weight(ws, dG, 4 * H, xin, H, grad_d + o.w_ih[l], H, 4 * H, H, R);
+      hipLaunchKernelGGL(colsum_kernel, dim3((4 * H + 63) / 64, 64), dim3(256), 0, ws, dG, R, 4 * H, 4 * H, grad_d + o.b[l]);
       std::swap(dh_above, dx_out);
     }
     // input projection (dh_above now holds dX0)
     linear_bwd_weight(s, dh_above, H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
     hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, 64), dim3(256), 0, s, dh_above, R, H, H, grad_d + o.b_in);
+    if (!one_stream) { hipEventRecord(ctx->ev_side[n], ws); hipStreamWaitEvent(s, ctx->ev_side[n], 0); }
   }
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
