@@ -19,6 +19,7 @@ import torch
 
 from ..spec import compiler, constants, layout as L
 from . import binding as B
+from . import dist as dist_util
 from .buffers import CarryBuffers, TrajBuffers
 
 
@@ -103,10 +104,8 @@ class HumanoidWalkingTask:
         self.config = config
         self.rank, self.world_size = rank, world_size
         self.device = device or torch.device("cuda", torch.cuda.current_device())
-        if config.num_envs % world_size != 0:
-            raise ValueError("num_envs must be divisible by the number of GPUs")
-        self.N = config.num_envs // world_size
-        self.kcfg = config.to_kbj(self.N, env_id_offset=rank * self.N)
+        self.N, env_off = dist_util.env_shard(config.num_envs, rank, world_size)
+        self.kcfg = config.to_kbj(self.N, env_id_offset=env_off)
         self.T, self.H, self.B = self.kcfg.rollout_len, self.kcfg.hidden_size, self.kcfg.batch_size
         self.model_blob = self.get_mujoco_model()
         with torch.cuda.device(self.device):
@@ -154,18 +153,13 @@ class HumanoidWalkingTask:
     def update(self):
         """GAE, then num_passes x (N / B) minibatch steps: BPTT gradient, all-reduce, AdamW."""
         self.ctx.gae(self.traj.c, self.traj.adv, self.traj.target)
-        dist_on = self.world_size > 1
-        if dist_on:
-            import torch.distributed as dist
-        scale = 1.0 / self.world_size
         for p in range(self.kcfg.num_passes):
             self._perm_gen.manual_seed((self.config.seed * 1000003 + self.iteration * 97 + p) & 0x7FFFFFFF)
             perm = torch.randperm(self.N, generator=self._perm_gen).int().to(self.device)
             for mb in range(self.N // self.B):
                 idx = perm[mb * self.B:(mb + 1) * self.B].contiguous()
                 self.ctx.ppo_grad(self.params, self.traj.c, idx, self.B, self.traj.adv, self.traj.target, self.grad, self.metrics)
-                if dist_on:
-                    dist.all_reduce(self.grad)          # RCCL over xGMI: the one exchange step of the path
+                scale = dist_util.allreduce_grad_(self.grad, self.world_size)   # RCCL over xGMI: the one exchange step
                 self.opt_step += 1
                 self.ctx.adamw_step(self.params, self.opt_m, self.opt_v, self.grad, self.opt_step, scale)
 

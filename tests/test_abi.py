@@ -1,0 +1,76 @@
+"""C-ABI checks that need no GPU: libkbj.so loads, exports every symbol include/kbj.h declares, struct sizes match the
+Python mirrors, and the library refuses to run without a HIP device (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from kbot_joystick_amd.spec import compiler, layout as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from kbot_joystick_amd.host import binding
+    if not os.path.exists(binding.LIB_PATH):
+        binding.build_library()
+    return binding.load_library()
+
+
+def test_every_declared_symbol_is_exported(lib):
+    hdr = open(os.path.join(ROOT, "include", "kbj.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(kbj_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    from kbot_joystick_amd.host import binding
+    assert declared == set(binding.SIGNATURES), declared ^ set(binding.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+
+
+def test_struct_sizes(lib):
+    assert lib.kbj_sizeof_model() == ctypes.sizeof(L.Model)
+    assert lib.kbj_sizeof_config() == ctypes.sizeof(L.Config)
+
+
+def test_param_counts_match_survey(lib):
+    # H=256 -> 1,077,800 + 1,172,737; H=128 -> 276,776 + 324,225
+    for H, a, c in ((256, 1077800, 1172737), (128, 276776, 324225)):
+        cfg = L.default_config(hidden_size=H)
+        assert lib.kbj_actor_param_count(ctypes.byref(cfg)) == a
+        assert lib.kbj_param_count(ctypes.byref(cfg)) == a + c
+        assert L.param_count(H) == (a, c)
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from kbot_joystick_amd.host import binding
+    with pytest.raises(binding.KbjError, match="no HIP device"):
+        binding.Context(compiler.load_model("kbot-headless"), L.default_config(num_envs=4, batch_size=4))
+
+
+def test_bad_blob_rejected(lib):
+    h = ctypes.c_void_p()
+    cfg = L.default_config(num_envs=4, batch_size=4)
+    assert lib.kbj_create(ctypes.byref(h), b"\0" * 10, 10, ctypes.byref(cfg), 0, None) != 0
+    assert b"wrong size" in lib.kbj_last_error(None)
+    m = compiler.load_model("kbot-headless")
+    m.body_parent[5] = 1          # break the topology the kernels are specialised on
+    blob = ctypes.string_at(ctypes.addressof(m), ctypes.sizeof(m))
+    assert lib.kbj_create(ctypes.byref(h), blob, len(blob), ctypes.byref(cfg), 0, None) != 0
+    assert b"topology" in lib.kbj_last_error(None)
+
+
+def test_task_config_guards():
+    from kbot_joystick_amd.host.task import HumanoidWalkingTaskConfig, launch_config
+    with pytest.raises(NotImplementedError):
+        HumanoidWalkingTaskConfig().to_kbj(4096)          # dataclass defaults enable the mirror losses (train.py:115-122)
+    with pytest.raises(ValueError):
+        launch_config(batch_size=500).to_kbj(4096)
+    c = launch_config().to_kbj(4096)
+    assert (c.rollout_len, c.substeps, c.hidden_size, c.batch_size, c.num_passes) == (100, 5, 256, 512, 3)
+    assert abs(c.lpf_alpha - 0.02 / (0.02 + 1 / (2 * 3.141592653589793 * 10))) < 1e-7

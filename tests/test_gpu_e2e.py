@@ -1,0 +1,76 @@
+"""End-to-end GPU parity: a whole (tiny) training iteration through the C ABI — rollout with sampled actions, rewards, GAE,
+minibatch BPTT gradients, AdamW — against the CPU oracle trainer on identical seeds, plus the committed golden rollout."""
+import os
+
+import numpy as np
+import pytest
+
+from kbot_joystick_amd.spec import layout as L
+
+pytestmark = pytest.mark.gpu
+
+
+def test_training_iteration_matches_oracle():
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
+    from oracle.trainer import OracleTrainer
+    cfg = launch_config(num_envs=8, batch_size=4, hidden_size=64, rollout_length_seconds=0.12, robot="kbot-headless", seed=5, num_passes=2)
+    task = HumanoidWalkingTask(cfg, device=torch.device("cuda", 0))
+    params0 = task.params.cpu().numpy().copy()
+    tr = OracleTrainer(task.model_blob, task.kcfg, seed=5, params=params0, precision="f32")
+    # ---- rollout (actions sampled with the same threefry Gaussian draws on both sides) ----
+    task.rollout()
+    torch.cuda.synchronize()
+    ref = tr.rollout()
+    T = task.T
+    act = task.traj.action.cpu().numpy()
+    assert np.abs(act[0] - ref["action"][0]).max() < 1e-4                      # step 0: identical observations
+    assert np.median(np.abs(act - ref["action"])) < 1e-4
+    assert np.array_equal(task.traj.aux[:T, :, L.AUX["DONE"]].cpu().numpy(), ref["aux"][:T, :, L.AUX["DONE"]])
+    assert np.median(np.abs(task.traj.logp.cpu().numpy() - ref["logp"])) < 1e-3
+    assert np.median(np.abs(task.traj.value.cpu().numpy() - ref["value"])) < 1e-4
+    assert np.median(np.abs(task.traj.reward.cpu().numpy() - ref["reward"])) < 1e-3
+    # ---- update on the ORACLE's trajectory (so both sides differentiate the same data) ----
+    for name in ("actor_obs", "critic_obs", "aux"):
+        getattr(task.traj, name).copy_(torch.from_numpy(ref[name]))
+    task.traj.action.copy_(torch.from_numpy(ref["action"])); task.traj.logp.copy_(torch.from_numpy(ref["logp"]))
+    task.traj.value.copy_(torch.from_numpy(ref["value"])); task.traj.reward.copy_(torch.from_numpy(ref["reward"]))
+    perms = []
+    for p in range(task.kcfg.num_passes):                                         # the permutations HumanoidWalkingTask.update draws
+        g = torch.Generator(device="cpu"); g.manual_seed((cfg.seed * 1000003 + task.iteration * 97 + p) & 0x7FFFFFFF)
+        perms.append(torch.randperm(task.N, generator=g).numpy())
+    task.update()
+    torch.cuda.synchronize()
+    tr.update(perms)
+    p_gpu, p_ref = task.params.cpu().numpy(), tr.params.numpy()
+    moved = np.abs(p_ref - params0).max()
+    assert moved > 1e-4                                                           # the optimizer really stepped
+    assert np.abs(p_gpu - p_ref).max() < 0.02 * moved + 1e-6
+    assert task.opt_step == tr.opt_step == 4
+
+
+def test_hip_env_matches_golden_rollout(model):
+    """The committed golden vectors (oracle fp64, tests/golden) — the HIP path from the same seed and actions."""
+    import torch
+    from kbot_joystick_amd.host import binding as B
+    ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_rollout.npz"))
+    cfg = L.default_config(num_envs=4, batch_size=4)
+    ctx = B.Context(model, cfg, 0, torch.cuda.current_stream().cuda_stream)
+    dev = "cuda:0"
+    T = ref["actions"].shape[0]
+    actor = torch.zeros(T + 1, 4, L.LD_ACTOR, device=dev); critic = torch.zeros(T + 1, 4, L.LD_CRITIC, device=dev)
+    aux = torch.zeros(T + 1, 4, L.AUX["SIZE"], device=dev)
+    ctx.env_reset_all(0, actor[0], critic[0], aux[0])
+    acts = torch.from_numpy(ref["actions"]).to(dev)
+    for t in range(T):
+        ctx.env_step(acts[t], aux[t], actor[t + 1], critic[t + 1], aux[t + 1])
+    ctx.synchronize()
+    ep, es = ctx.env_get_state()
+    assert np.abs(actor[0].cpu().numpy() - ref["actor"][0]).max() < 1e-5
+    assert np.abs(aux[:4].cpu().numpy() - ref["aux"][:4]).max() < 5e-3          # fp32 GPU vs fp64 oracle, early steps
+    assert np.median(np.abs(actor[:8].cpu().numpy() - ref["actor"][:8])) < 1e-5
+    rew = torch.zeros(T, 4, device=dev)
+    ctx.rewards(torch.from_numpy(ref["aux"][:T].copy()).to(dev), T, rew, None)
+    ctx.synchronize()
+    assert np.abs(rew.cpu().numpy() - ref["reward"]).max() < 2e-4
+    ctx.close()

@@ -1,0 +1,95 @@
+"""Pins for the torch oracle of the actor-critic / PPO maths (oracle/nn.py) against independent implementations:
+torch.nn.LSTMCell (equinox LSTMCell has the same gate order i,f,g,o and a single bias), torch.distributions.Normal,
+torch.optim.AdamW (same decoupled form as optax.adamw) and closed-form GAE."""
+import numpy as np
+import torch
+
+from kbot_joystick_amd.spec import layout as L
+from oracle import nn as ON
+
+
+def test_param_layout_counts():
+    assert ON.param_count(256) == 1077800 + 1172737 and ON.param_count(128) == 276776 + 324225
+    names = [n for n, _ in ON.param_shapes(64)]
+    assert names[0] == "actor.input_proj.weight" and names[2] == "actor.rnns.0.weight_ih" and names[-1] == "critic.output_proj.bias"
+
+
+def test_lstm_cell_matches_torch():
+    torch.manual_seed(0)
+    H, B = 32, 5
+    cell = torch.nn.LSTMCell(H, H, dtype=torch.float64)
+    x, h, c = (torch.randn(B, H, dtype=torch.float64) for _ in range(3))
+    h2, c2 = ON.lstm_cell(x, h, c, cell.weight_ih, cell.weight_hh, cell.bias_ih + cell.bias_hh)
+    ht, ct = cell(x, (h, c))
+    assert torch.allclose(h2, ht, atol=1e-12) and torch.allclose(c2, ct, atol=1e-12)
+
+
+def test_gaussian_matches_torch_distributions():
+    torch.manual_seed(1)
+    mean, std, a = torch.randn(7, 20, dtype=torch.float64), torch.rand(7, 20, dtype=torch.float64) + 0.1, torch.randn(7, 20, dtype=torch.float64)
+    d = torch.distributions.Normal(mean, std)
+    assert torch.allclose(ON.gaussian_logp(a, mean, std), d.log_prob(a).sum(-1), atol=1e-12)
+    assert torch.allclose(ON.gaussian_entropy(std), d.entropy().sum(-1), atol=1e-12)
+
+
+def test_actor_head_semantics(model):
+    cfg = L.default_config()
+    jb = torch.tensor(list(model.joint_bias), dtype=torch.float64)
+    out = torch.zeros(1, 40, dtype=torch.float64)
+    obs = torch.zeros(1, L.LD_ACTOR, dtype=torch.float64)
+    obs[0, 55:65] = 0.1                                             # arm commands are the last 10 actor inputs (train.py:932)
+    lpf = torch.zeros(1, 20, dtype=torch.float64)
+    y, std, lpf2 = ON.actor_head(out, obs, lpf, jb, cfg)
+    alpha = cfg.lpf_alpha
+    assert abs(alpha - 0.5568) < 1e-3                               # dt/(dt + 1/(2 pi 10)) at dt = 0.02
+    assert torch.allclose(y[0, :10], alpha * jb[:10]) and torch.allclose(y[0, 10:], alpha * (jb[10:] + 0.1))
+    assert torch.allclose(std, torch.full_like(std, (np.log(2.0) + 0.01) * 0.5))   # (softplus(0)+min_std)*var_scale (train.py:929)
+    big = torch.full((1, 40), 50.0, dtype=torch.float64)
+    assert torch.all(ON.actor_head(big, obs, lpf, jb, cfg)[1] == cfg.max_std)
+
+
+def test_gae_closed_form():
+    v = torch.tensor([[1.0], [2.0], [3.0]], dtype=torch.float64)
+    r = torch.tensor([[0.5], [0.25], [1.0]], dtype=torch.float64)
+    done = torch.tensor([[0.0], [-1.0], [0.0]], dtype=torch.float64)
+    g, lam = 0.9, 0.8
+    adv, tgt = ON.gae(v, r, done, g, lam)
+    d2 = 1.0 + g * 3.0 - 3.0                                        # bootstrap V_T := V_{T-1}
+    d1 = 0.25 - 2.0                                                 # done: no bootstrap, no propagation
+    d0 = 0.5 + g * 2.0 - 1.0 + g * lam * d1
+    assert torch.allclose(adv[:, 0], torch.tensor([d0, d1, d2], dtype=torch.float64))
+    assert torch.allclose(tgt, adv + v)
+
+
+def test_adamw_matches_torch_optim():
+    cfg = L.default_config(max_grad_norm=1e9)                       # no clipping: compare with torch.optim.AdamW
+    torch.manual_seed(2)
+    p0 = torch.randn(50, dtype=torch.float64)
+    p = p0.clone(); m = torch.zeros_like(p); v = torch.zeros_like(p)
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=cfg.learning_rate, betas=(cfg.adam_b1, cfg.adam_b2), eps=cfg.adam_eps, weight_decay=cfg.weight_decay)
+    for step in range(1, 4):
+        g = torch.randn(50, dtype=torch.float64)
+        ON.adamw_step(cfg, p, m, v, g.clone(), step)
+        pt.grad = g.clone(); opt.step()
+    # torch decays before the Adam update (p *= 1 - lr wd), optax adds wd*p to the update: differ at O(lr^2 wd)
+    assert torch.allclose(p, pt.detach(), atol=1e-9)
+    # global-norm clipping scales the gradient to max_grad_norm
+    cfg2 = L.default_config(max_grad_norm=0.5)
+    g = torch.randn(50, dtype=torch.float64) * 10
+    norm = ON.adamw_step(cfg2, p.clone(), torch.zeros(50, dtype=torch.float64), torch.zeros(50, dtype=torch.float64), g.clone(), 1)
+    assert abs(float(norm) - float(g.norm())) < 1e-9
+
+
+def test_ppo_loss_gradient_branches():
+    cfg = L.default_config()
+    lp_old = torch.zeros(1, 4, dtype=torch.float64)
+    lp = torch.tensor([[0.5, -0.5, 0.01, -0.01]], dtype=torch.float64, requires_grad=True)     # ratios 1.65, 0.61, ~1
+    v = torch.zeros(1, 4, dtype=torch.float64, requires_grad=True)
+    adv = torch.tensor([[1.0, -1.0, 1.0, -1.0]], dtype=torch.float64)
+    ent = torch.ones(1, 4, dtype=torch.float64)
+    loss, m = ON.ppo_loss(cfg, lp, v, ent, lp_old, torch.zeros(1, 4, dtype=torch.float64), adv, torch.ones(1, 4, dtype=torch.float64))
+    loss.backward()
+    assert lp.grad[0, 0] == 0 and lp.grad[0, 1] == 0                # clipped in the direction of improvement: no gradient
+    assert lp.grad[0, 2] < 0 and lp.grad[0, 3] > 0
+    assert abs(float(m["clipfrac"]) - 0.5) < 1e-12

@@ -1,0 +1,105 @@
+"""Hand-computed cases and properties for the oracle's task layer (rewards train.py:125-506, command sampler
+train.py:710-785, episode bookkeeping) — the pieces of the reference that live in-tree."""
+import numpy as np
+
+from kbot_joystick_amd.spec import layout as L
+from oracle import oracle as O
+
+A = L.AUX
+
+
+def _aux(T, N):
+    x = np.zeros((T, N, A["SIZE"]), np.float32)
+    x[..., A["BQUAT"]] = 1.0
+    x[..., A["LFQUAT"]] = 1.0
+    x[..., A["RFQUAT"]] = 1.0
+    x[..., A["BASEZ"]] = 0.80 + 0.0
+    return x
+
+
+def test_reward_hand_cases(model, quiet_cfg):
+    quiet_cfg.num_envs = 1
+    o = O.Oracle(model, quiet_cfg, precision="f64")
+    T = 4
+    x = _aux(T, 1)
+    x[..., A["CMD"]] = 0.5                                  # walking command vx = 0.5
+    x[..., A["QVEL"]] = 0.5                                 # base vx matches the command (yaw 0)
+    x[..., A["LFZ"]] = 0.06; x[..., A["RFZ"]] = 0.06        # feet on the ground: height = base z - (0.06 - 0.06)
+    x[..., A["ARMQ"]:A["ARMQ"] + 10] = np.array(model.joint_bias)[10:]
+    x[:, 0, A["TOUCH"]] = [1.0, 1.0, 0.0, 1.0]              # left foot: contact, contact, air, touchdown
+    x[:, 0, A["TOUCH"] + 1] = 0.0
+    rew, comps = o.rewards(x)
+    c = comps[:, 0]
+    assert np.allclose(c[:, 0], 1.0, atol=1e-6)             # linvel: perfect tracking
+    assert np.allclose(c[:, 1], np.exp(-0.0 / 0.2))         # angvel: wz command 0, yaw rate 0
+    assert np.allclose(c[:, 3], 1.0, atol=1e-5)             # base height 0.80 above the lowest foot origin - 0.06 + 0.06
+    assert np.allclose(c[:, 4], 1.0, atol=1e-6)             # arms at their biases, zero arm command
+    assert np.allclose(c[:, 5], [1, 1, 1, 1])               # single contact inside the 2 s grace period
+    assert np.allclose(c[:, 6], [0, 0, 1, 0])               # no-contact penalty only while airborne
+    # feet airtime: left foot touches down at t=3 after 1 step (0.02 s) in the air: (0.02 - 0.4); the right foot's
+    # initial carry says "in contact" (train.py:177) so it never produces a first contact
+    assert np.allclose(c[:, 7], [0, 0, 0, 0.02 - 0.4], atol=1e-6)
+    assert np.allclose(c[:, 11], 1.0)                       # torque reward is 1 when a command is active
+    assert np.allclose(c[0, 10], 1.0) and np.allclose(c[1:, 10], 1.0)   # constant base velocity: no acceleration
+    scales = np.array([0.2, 0.1, 0.2, 0.2, 0.2, 0.1, 0.1, 1.5, 0.1, 0.05, 0.1, 0.1])
+    assert np.allclose(rew[:, 0], comps[:, 0] @ scales, atol=1e-6)
+
+
+def test_reward_zero_command_branches(model, quiet_cfg):
+    quiet_cfg.num_envs = 1
+    o = O.Oracle(model, quiet_cfg, precision="f64")
+    x = _aux(3, 1)
+    x[..., A["COMDIST"]] = 0.02
+    x[..., A["CTRL"]:A["CTRL"] + 20] = 5.0
+    x[1, 0, A["DONE"]] = -1
+    x[:, 0, A["QVEL"]] = [0.0, 1.0, 5.0]
+    rew, comps = o.rewards(x)
+    c = comps[:, 0]
+    assert np.allclose(c[:, 9], np.exp(-0.02 / 0.04))       # com distance only rewarded when standing (train.py:466-478)
+    assert np.allclose(c[:, 11], np.exp(-1.0))              # torque: mean exp(-|5|/5) under the zero command
+    assert np.allclose(c[:, 5], 1.0) and np.allclose(c[:, 6], 0.0) and np.allclose(c[:, 7], 0.0)
+    # base accel: t=0 edge padded (0), t=1 |dv| = 1, t=2 follows a done -> zeroed (train.py:487-494)
+    assert np.allclose(c[:, 10], [1.0, np.exp(-1.0 / 5.0), 1.0])
+    # linvel under the zero command uses the steep kernel exp(-|e|/0.2) instead of exp(-e^2/0.2)
+    assert np.allclose(c[:, 0], np.exp(-np.array([0.0, 1.0, 5.0]) / 0.2), atol=1e-6)
+
+
+def test_command_sampler_statistics(model):
+    cfg = L.default_config(num_envs=4096)
+    o = O.Oracle(model, cfg, seed=2, precision="f32")
+    o.reset_all()
+    cmd = o.es[:, L.ES["CMD"]:L.ES["CMD"] + 16]
+    vx, vy, wz, bh, arms = cmd[:, 0], cmd[:, 1], cmd[:, 2], cmd[:, 3], cmd[:, 6:]
+    assert vx.min() >= -0.5 and vx.max() <= 1.2 and np.abs(vy).max() <= 0.5 and np.abs(wz).max() <= 1.0
+    assert bh.min() >= -0.25 and bh.max() <= 0.05
+    zero = (np.abs(cmd[:, :3]).sum(1) == 0)
+    assert abs(zero.mean() - 2 / 6) < 0.03                  # modes 4 and 5 of 6 stand (train.py:752)
+    has_arms = (np.abs(arms).sum(1) > 0)
+    assert abs(has_arms.mean() - (2 / 6) * (1 - 0.5 ** 10)) < 0.03   # arms only in omni / stand-bend modes
+    # uniform and bernoulli share a key (train.py:734-737): non-zero arm targets lie in the LOWER half of the joint range
+    lo = np.array([model.dof_range[16 + j][0] for j in range(10)]); hi = np.array([model.dof_range[16 + j][1] for j in range(10)])
+    nz = arms != 0
+    frac = ((arms - lo) / (hi - lo))[nz]
+    assert frac.max() < 0.5 + 1e-6
+    # env streams are independent of the sharding: env 5 of an offset shard equals env 5+off of the big run
+    cfg2 = L.default_config(num_envs=64, env_id_offset=1000)
+    o2 = O.Oracle(model, cfg2, seed=2, precision="f32"); o2.reset_all()
+    assert np.array_equal(o2.es[:8], o.es[1000:1008]) and np.array_equal(o2.ep[:8], o.ep[1000:1008])
+
+
+def test_episode_bookkeeping(model):
+    cfg = L.default_config(num_envs=8, max_episode_steps=5, enable_pushes=0)
+    o = O.Oracle(model, cfg, seed=0, precision="f32")
+    a, c, x = o.reset_all()
+    act = np.tile(np.array(model.joint_bias, np.float32), (8, 1))
+    dones = []
+    for t in range(6):
+        aux = x.copy()
+        a, c, x = o.step(act, aux)
+        dones.append(aux[:, A["DONE"]].copy())
+    dones = np.array(dones)
+    assert (dones[4] == 1).all()                            # episode-length truncation (+1) at step 5 (train.py:1268)
+    assert (dones[:4] == 0).all()
+    assert (o.es[:, L.ES["TIME"]] == 1).all()               # new episode has advanced one step
+    assert (o.es[:, L.ES["EPISODE"]].view(np.uint32) == 2).all()
+    assert (o.es[:, L.ES["STEP"]].view(np.uint32) == 6).all()
