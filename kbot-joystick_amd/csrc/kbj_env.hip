@@ -29,8 +29,11 @@ __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restri
   PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
 }
 
+// register budget of the step kernel: 13.4 KB of LDS lets 12 single-wavefront workgroups share a CU (3 waves/SIMD), which
+// needs <= 168 VGPRs; this cap makes hipcc allocate 129 and spill ~90 values of the long serial phases to scratch.
+// Measured (8192 envs): 3.26 ms/step at 2 waves/SIMD without spills vs 2.83 ms at 3 waves/SIMD with them.
 #ifndef KBJ_ENV_NUM_VGPR
-#define KBJ_ENV_NUM_VGPR 128
+#define KBJ_ENV_NUM_VGPR 62
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR))) void env_step_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, uint32_t seed,
                                                       float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ action,

@@ -43,29 +43,49 @@ KBJ_DEV int body_parent(int b) { return b <= 1 ? 0 : (b == 2 ? 1 : ((b - 3) % 5 
 KBJ_DEV int dof_body(int d) { return d < 6 ? 1 : d - 3; }
 KBJ_DEV int dof_parent(int d) { return d == 0 ? -1 : (d < 6 ? d - 1 : ((d - 6) % 5 == 0 ? 5 : d - 1)); }
 
+// Everything one env needs between phases, 13.4 KB so that 12 single-wavefront workgroups (3 waves per SIMD) share a CU.
+// Buffers whose lifetimes do not overlap share storage (union `u`): composite inertias (until the mass matrix exists),
+// RNE body forces (until the bias force exists), then the arrow-matrix blocks of the Newton solves. Rotation matrices
+// are recomputed from xquat where needed instead of being stored; the mass matrix is stored in its tree sparsity.
 struct KbjShared {
   float ep[KBJ_EP_SIZE];
   float es[KBJ_ES_SIZE];
-  float xpos[NB][3], xquat[NB][4], xmat[NB][9], xipos[NB][3], xaxis[NB][3];
+  float xpos[NB][3], xquat[NB][4], xipos[NB][3];
   float com[4];   // tree centre of mass (subtree_com[1]) and total mass
   float com2[3];  // subtree_com[2] (everything but the base body)
-  float cinert[NB][10], crb[NB][10];
-  float cdof[NV][6], cdof_dot[NV][6], cvel[NB][6], cfrc[NB][6], cfrc_acc[NB][6];
-  float M[NV][27];
-  float A[4][12][12];  // chain-local blocks [ankle..hip | base 6], row 11 = right-hand side
-  float B[7][8];       // base block, row 6 = right-hand side
-  float qfrc_bias[NV], qfrc_act[NV], qfrc_app[NV], qfrc_smooth[NV], qacc_smooth[NV], qacc[NV], warm[NV];
+  float cinert[NB][10];
+  float cdof[NV][6], cvel[NB][6];
+  union {
+    struct { float crb[NB][10]; };
+    struct { float cfrc[NB][6], cfrc_acc[NB][6]; };
+    struct {
+      float A[4][12][12];  // chain-local blocks [ankle..hip | base 6], row 11 = right-hand side
+      float B[7][8];       // base block, row 6 = right-hand side
+    };
+  } u;
+  float Mb[6][6];       // mass matrix, base block
+  float Mc[4][5][11];   // limb c, dof a (hip..ankle): columns 0..5 base dofs, 6..10 the limb's own dofs
+  float qfrc_act[NV], qfrc_smooth[NV], qacc_smooth[NV], qacc[NV];
   float Ma[NV], grad[NV], search[NV], mv[NV], vec[NV];
   float conpos[NCON][3], condist[NCON];
   int conact[NCON];
-  float Jc[32][12];  // contact rows: columns 0..5 base dofs, 6..10 the leg's dofs hip..ankle
-  float D[NROW], R[NROW], aref[NROW], floss[NROW], jar[NROW], jv[NROW], force[NROW], lsign[NU];
-  int active[NROW], quad[NROW];
+  float Jc[32][11];  // contact rows: columns 0..5 base dofs, 6..10 the leg's dofs hip..ankle
+  float D[NROW], aref[NROW], jar[NROW], jv[NROW], force[NROW];  // a row is active iff D != 0
+  float Rf[NU], floss[NU], lsign[NU];                           // Huber half-width data of the frictionloss rows, limit signs
+  int quad[NROW];
   float ctrl[NU], push[6], act_eff[NU];
   float gyro[3], imuquat[4], touch[2], pg[3];
-  float scal[8];
   int iters, pushing, done;
 };
+
+// symmetric access to the tree-sparse mass matrix (i, j must be related: same limb, or one of them a base dof)
+KBJ_DEV float& M_at(KbjShared& S, int i, int j) {
+  if (i < j) { int t = i; i = j; j = t; }
+  if (i < 6) return S.Mb[i][j];
+  int c = (i - 6) / 5, a = (i - 6) % 5;
+  return S.Mc[c][a][j < 6 ? j : 6 + (j - 6) % 5];
+}
+KBJ_DEV float M_get(const KbjShared& S, int i, int j) { return M_at(const_cast<KbjShared&>(S), i, j); }
 
 // ---- small vector helpers ----
 KBJ_DEV void cross3(const float* a, const float* b, float* o) {

@@ -23,26 +23,24 @@ struct PhysConst {  // per-launch constants derived from kbj_config
 KBJ_DEV void phys_kinematics(KbjShared& S, const kbj_model& m) {
   const float* qpos = S.es + KBJ_ES_QPOS;
   PFOR(w, 1) {
-    for (int k = 0; k < 3; ++k) { S.xpos[0][k] = 0; S.xipos[0][k] = 0; S.xaxis[0][k] = 0; S.xaxis[1][k] = 0; S.xaxis[2][k] = 0; S.xaxis[23][k] = 0; }
+    for (int k = 0; k < 3; ++k) { S.xpos[0][k] = 0; S.xipos[0][k] = 0; }
     S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
-    quat_to_mat(S.xquat[0], S.xmat[0]);
-    float q[4] = {qpos[3], qpos[4], qpos[5], qpos[6]};
+    float q[4] = {qpos[3], qpos[4], qpos[5], qpos[6]}, mat[9], t[3];
     quat_norm(q);
     for (int k = 0; k < 3; ++k) S.xpos[1][k] = qpos[k];
     for (int k = 0; k < 4; ++k) S.xquat[1][k] = q[k];
-    quat_to_mat(q, S.xmat[1]);
-    float t[3];
-    mat_vec(S.xmat[1], S.ep + KBJ_EP_IPOS + 3, t);
+    quat_to_mat(q, mat);
+    mat_vec(mat, S.ep + KBJ_EP_IPOS + 3, t);
     for (int k = 0; k < 3; ++k) S.xipos[1][k] = S.xpos[1][k] + t[k];
     // torso: welded to the base
-    mat_vec(S.xmat[1], m.body_pos[2], t);
+    mat_vec(mat, m.body_pos[2], t);
     for (int k = 0; k < 3; ++k) S.xpos[2][k] = S.xpos[1][k] + t[k];
     float q2[4];
     quat_mul(q, m.body_quat[2], q2);
     quat_norm(q2);
     for (int k = 0; k < 4; ++k) S.xquat[2][k] = q2[k];
-    quat_to_mat(q2, S.xmat[2]);
-    mat_vec(S.xmat[2], S.ep + KBJ_EP_IPOS + 6, t);
+    quat_to_mat(q2, mat);
+    mat_vec(mat, S.ep + KBJ_EP_IPOS + 6, t);
     for (int k = 0; k < 3; ++k) S.xipos[2][k] = S.xpos[2][k] + t[k];
   }
   KBJ_SYNC();
@@ -50,7 +48,7 @@ KBJ_DEV void phys_kinematics(KbjShared& S, const kbj_model& m) {
     float ppos[3], pquat[4], pmat[9];
     for (int k = 0; k < 3; ++k) ppos[k] = S.xpos[2][k];
     for (int k = 0; k < 4; ++k) pquat[k] = S.xquat[2][k];
-    for (int k = 0; k < 9; ++k) pmat[k] = S.xmat[2][k];
+    quat_to_mat(pquat, pmat);
     int nb = c < 4 ? 5 : 1;
     for (int k5 = 0; k5 < nb; ++k5) {
       int b = c < 4 ? 3 + 5 * c + k5 : 23;
@@ -70,10 +68,9 @@ KBJ_DEV void phys_kinematics(KbjShared& S, const kbj_model& m) {
       quat_to_mat(pquat, pmat);
       for (int k = 0; k < 3; ++k) S.xpos[b][k] = ppos[k];
       for (int k = 0; k < 4; ++k) S.xquat[b][k] = pquat[k];
-      for (int k = 0; k < 9; ++k) S.xmat[b][k] = pmat[k];
       mat_vec(pmat, S.ep + KBJ_EP_IPOS + 3 * b, t);
       for (int k = 0; k < 3; ++k) S.xipos[b][k] = ppos[k] + t[k];
-      if (c < 4) mat_vec(pmat, m.jnt_axis[b], S.xaxis[b]);
+      if (c < 4) mat_vec(pmat, m.jnt_axis[b], S.cdof[b + 3]);  // world hinge axis = angular part of the motion axis
     }
   }
   KBJ_SYNC();
@@ -89,13 +86,13 @@ KBJ_DEV void phys_com(KbjShared& S) {
     S.com[w] = s1 / m1;
     if (w == 0) S.com[3] = m1;
   }
-  PFOR(w, NV * 27) (&S.M[0][0])[w] = 0;
   KBJ_SYNC();
   PFOR(b, NB) {
     float* c = S.cinert[b];
     if (b == 0) { for (int k = 0; k < 10; ++k) c[k] = 0; }
     else {
-      const float* mat = S.xmat[b];
+      float mat[9];
+      quat_to_mat(S.xquat[b], mat);
       const float* in = S.ep + KBJ_EP_INERTIA + 3 * b;
       float dif[3] = {S.xipos[b][0] - S.com[0], S.xipos[b][1] - S.com[1], S.xipos[b][2] - S.com[2]};
       float ms = mass[b];
@@ -121,12 +118,14 @@ KBJ_DEV void phys_com(KbjShared& S) {
     if (d < 3) { for (int k = 0; k < 6; ++k) cd[k] = 0; cd[3 + d] = 1; }
     else if (d < 6) {
       int i = d - 3;
-      float ax[3] = {S.xmat[1][i], S.xmat[1][3 + i], S.xmat[1][6 + i]};
+      float mat[9];
+      quat_to_mat(S.xquat[1], mat);
+      float ax[3] = {mat[i], mat[3 + i], mat[6 + i]};
       for (int k = 0; k < 3; ++k) cd[k] = ax[k];
       cross3(ax, off, cd + 3);
     } else {
-      for (int k = 0; k < 3; ++k) cd[k] = S.xaxis[b][k];
-      cross3(S.xaxis[b], off, cd + 3);
+      float ax[3] = {cd[0], cd[1], cd[2]};  // written by the kinematics walkers
+      cross3(ax, off, cd + 3);
     }
   }
   KBJ_SYNC();
@@ -142,17 +141,16 @@ template <int W> KBJ_DEV float subtree_sum(const float (*q)[W], int b, int k) {
 }
 
 KBJ_DEV void phys_crb_mass(KbjShared& S) {
-  PFOR(w, NB * 10) { int b = w / 10, k = w % 10; S.crb[b][k] = subtree_sum<10>(S.cinert, b, k); }
+  PFOR(w, NB * 10) { int b = w / 10, k = w % 10; S.u.crb[b][k] = subtree_sum<10>(S.cinert, b, k); }
   KBJ_SYNC();
   PFOR(i, NV) {
     float buf[6];
-    inert_mul(S.crb[dof_body(i)], S.cdof[i], buf);
+    inert_mul(S.u.crb[dof_body(i)], S.cdof[i], buf);
     for (int j = i; j >= 0; j = dof_parent(j)) {
       float s = 0;
       for (int k = 0; k < 6; ++k) s += S.cdof[j][k] * buf[k];
       if (j == i) s += S.ep[KBJ_EP_ARMATURE + i];
-      S.M[i][j] = s;
-      S.M[j][i] = s;
+      M_at(S, i, j) = s;
     }
   }
   KBJ_SYNC();
@@ -163,9 +161,10 @@ KBJ_DEV void phys_collide_vel(KbjShared& S, const kbj_model& m) {
   const float* qvel = S.es + KBJ_ES_QVEL;
   PFOR(ci, NCON) {  // capsule end ci%2 of capsule ci/2 against the plane z = 0
     int c = ci / 2, b = c < 2 ? 7 : 12;
-    float t[3], ax[3];
-    mat_vec(S.xmat[b], S.ep + KBJ_EP_CAP_POS + 3 * c, t);
-    mat_vec(S.xmat[b], m.cap_axis[c], ax);
+    float t[3], ax[3], mat[9];
+    quat_to_mat(S.xquat[b], mat);
+    mat_vec(mat, S.ep + KBJ_EP_CAP_POS + 3 * c, t);
+    mat_vec(mat, m.cap_axis[c], ax);
     float sgn = (ci & 1) ? 1.0f : -1.0f, hl = S.ep[KBJ_EP_CAP_HALF + c], rad = S.ep[KBJ_EP_CAP_RAD + c];
     float end[3];
     for (int k = 0; k < 3; ++k) end[k] = S.xpos[b][k] + t[k] + sgn * hl * ax[k];
@@ -174,7 +173,7 @@ KBJ_DEV void phys_collide_vel(KbjShared& S, const kbj_model& m) {
     S.conpos[ci][0] = end[0]; S.conpos[ci][1] = end[1]; S.conpos[ci][2] = end[2] - (rad + dist / 2);
     S.conact[ci] = dist < 0;
   }
-  PFOR(c, 5) {  // limb walkers: spatial velocity, cdof_dot, acceleration bias and body forces (RNE forward pass)
+  PFOR(c, 5) {  // limb walkers: spatial velocity, acceleration bias and body forces (RNE forward pass)
     float v[6] = {0, 0, 0, 0, 0, 0}, a[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
     float cdd[6], Ia[6], Iv[6], x[6];
     // base body: 3 translations (cdof_dot = 0) then 3 rotations sharing the pre-rotation velocity
@@ -184,15 +183,13 @@ KBJ_DEV void phys_collide_vel(KbjShared& S, const kbj_model& m) {
     for (int i = 3; i < 6; ++i) {
       cross_motion(vb, S.cdof[i], cdd);
       for (int k = 0; k < 6; ++k) { v[k] += S.cdof[i][k] * qvel[i]; a[k] += cdd[k] * qvel[i]; }
-      if (c == 0) for (int k = 0; k < 6; ++k) S.cdof_dot[i][k] = cdd[k];
     }
     if (c == 0) {
-      for (int i = 0; i < 3; ++i) for (int k = 0; k < 6; ++k) S.cdof_dot[i][k] = 0;
       for (int b = 0; b < 3; ++b) {
-        if (b == 0) { for (int k = 0; k < 6; ++k) { S.cvel[0][k] = 0; S.cfrc[0][k] = 0; } continue; }
+        if (b == 0) { for (int k = 0; k < 6; ++k) { S.cvel[0][k] = 0; S.u.cfrc[0][k] = 0; } continue; }
         for (int k = 0; k < 6; ++k) S.cvel[b][k] = v[k];
         inert_mul(S.cinert[b], a, Ia); inert_mul(S.cinert[b], v, Iv); cross_force(v, Iv, x);
-        for (int k = 0; k < 6; ++k) S.cfrc[b][k] = Ia[k] + x[k];
+        for (int k = 0; k < 6; ++k) S.u.cfrc[b][k] = Ia[k] + x[k];
       }
     }
     int nb = c < 4 ? 5 : 1;
@@ -201,44 +198,45 @@ KBJ_DEV void phys_collide_vel(KbjShared& S, const kbj_model& m) {
       if (c < 4) {
         int d = b + 3;
         cross_motion(v, S.cdof[d], cdd);
-        for (int k = 0; k < 6; ++k) { S.cdof_dot[d][k] = cdd[k]; v[k] += S.cdof[d][k] * qvel[d]; a[k] += cdd[k] * qvel[d]; }
+        for (int k = 0; k < 6; ++k) { v[k] += S.cdof[d][k] * qvel[d]; a[k] += cdd[k] * qvel[d]; }
       }
       for (int k = 0; k < 6; ++k) S.cvel[b][k] = v[k];
       inert_mul(S.cinert[b], a, Ia); inert_mul(S.cinert[b], v, Iv); cross_force(v, Iv, x);
-      for (int k = 0; k < 6; ++k) S.cfrc[b][k] = Ia[k] + x[k];
+      for (int k = 0; k < 6; ++k) S.u.cfrc[b][k] = Ia[k] + x[k];
     }
   }
   KBJ_SYNC();
-  PFOR(w, NB * 6) { int b = w / 6, k = w % 6; S.cfrc_acc[b][k] = subtree_sum<6>(S.cfrc, b, k); }
+  PFOR(w, NB * 6) { int b = w / 6, k = w % 6; S.u.cfrc_acc[b][k] = subtree_sum<6>(S.u.cfrc, b, k); }
   KBJ_SYNC();
 }
 
 KBJ_DEV void phys_smooth_forces(KbjShared& S, const kbj_model& m) {
   PFOR(i, NV) {
     float s = 0;
-    for (int k = 0; k < 6; ++k) s += S.cdof[i][k] * S.cfrc_acc[dof_body(i)][k];
-    S.qfrc_bias[i] = s;
+    for (int k = 0; k < 6; ++k) s += S.cdof[i][k] * S.u.cfrc_acc[dof_body(i)][k];
     float act = 0, app = 0;
     if (i >= 6) act = fminf(fmaxf(S.ctrl[i - 6], m.act_range[i - 6][0]), m.act_range[i - 6][1]);
     else if (S.pushing) {
       if (i < 3) app = S.push[i];
       else {
-        float arm[3] = {S.xipos[1][0] - S.xpos[1][0], S.xipos[1][1] - S.xpos[1][1], S.xipos[1][2] - S.xpos[1][2]}, t[3], tq[3], loc[3];
+        float arm[3] = {S.xipos[1][0] - S.xpos[1][0], S.xipos[1][1] - S.xpos[1][1], S.xipos[1][2] - S.xpos[1][2]}, t[3], tq[3], loc[3], mat[9];
         cross3(arm, S.push, t);
         for (int k = 0; k < 3; ++k) tq[k] = S.push[3 + k] + t[k];
-        matT_vec(S.xmat[1], tq, loc);
+        quat_to_mat(S.xquat[1], mat);
+        matT_vec(mat, tq, loc);
         app = loc[i - 3];
       }
     }
-    S.qfrc_act[i] = act; S.qfrc_app[i] = app;
+    S.qfrc_act[i] = act;
     S.qfrc_smooth[i] = act + app - s;
   }
   KBJ_SYNC();
 }
 
-// ---- arrow-matrix Cholesky with the right-hand side carried as an extra row ------------------------------------
+// ---- arrow-matrix LDL^T with the right-hand side carried as an extra row -----------------------------------------
 // G = M (+ J^T D J over rows in their quadratic zone when `hess`); solves G x = rhs, result in S.vec.
 // local index li of chain c: li 0..4 <-> dof 10+5c-li (ankle first), li 5..10 <-> base dof li-5.
+// Overwrites the union S.u (crb / cfrc are dead by the time a solve runs).
 KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
   PFOR(w, 4 * 12 * 11) {
     int c = w / 132, i = (w % 132) / 11, j = w % 11;
@@ -247,7 +245,7 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
     if (i == 11) v = j < 5 ? rhs[10 + 5 * c - j] : 0.0f;
     else {
       int di = i < 5 ? 10 + 5 * c - i : i - 5, dj = j < 5 ? 10 + 5 * c - j : j - 5;
-      v = (i >= 5 && j >= 5) ? 0.0f : S.M[di][dj];
+      v = (i >= 5 && j >= 5) ? 0.0f : M_get(S, di, dj);
       if (hess) {
         if (c < 2) {  // legs: contact rows of this leg
           int ci_ = i < 5 ? 10 - i : i - 5, cj_ = j < 5 ? 10 - j : j - 5;
@@ -261,36 +259,36 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
         }
       }
     }
-    S.A[c][i][j] = v;
+    S.u.A[c][i][j] = v;
   }
   KBJ_SYNC();
-  // LDL^T elimination: column p keeps its unscaled entries (L_ip D_p), so each pivot is ONE phase
+  // column p keeps its unscaled entries (L_ip D_p), so each pivot is ONE phase
   for (int p = 0; p < 5; ++p) {
     PFOR(w, 4 * 121) {
       int c = w / 121, e = w % 121, i = p + 1 + e / 11, j = p + 1 + e % 11;
-      if (i <= 11 && j <= 10 && j <= i) S.A[c][i][j] -= S.A[c][i][p] * S.A[c][j][p] / S.A[c][p][p];
+      if (i <= 11 && j <= 10 && j <= i) S.u.A[c][i][j] -= S.u.A[c][i][p] * S.u.A[c][j][p] / S.u.A[c][p][p];
     }
     KBJ_SYNC();
   }
   PFOR(w, 7 * 6) {
     int i = w / 6, j = w % 6;
     if (i < 6 && j > i) continue;
-    float v = i < 6 ? S.M[i][j] : rhs[j];
+    float v = i < 6 ? S.Mb[i][j] : rhs[j];
     int ai = i < 6 ? 5 + i : 11;
-    for (int c = 0; c < 4; ++c) v += S.A[c][ai][5 + j];
-    S.B[i][j] = v;
+    for (int c = 0; c < 4; ++c) v += S.u.A[c][ai][5 + j];
+    S.u.B[i][j] = v;
   }
   KBJ_SYNC();
   for (int p = 0; p < 6; ++p) {
-    PFOR(w, 36) { int i = p + 1 + w / 6, j = p + 1 + w % 6; if (i <= 6 && j <= 5 && j <= i) S.B[i][j] -= S.B[i][p] * S.B[j][p] / S.B[p][p]; }
+    PFOR(w, 36) { int i = p + 1 + w / 6, j = p + 1 + w % 6; if (i <= 6 && j <= 5 && j <= i) S.u.B[i][j] -= S.u.B[i][p] * S.u.B[j][p] / S.u.B[p][p]; }
     KBJ_SYNC();
   }
   PFOR(w, 1) {
     float x[6];
     for (int p = 5; p >= 0; --p) {
-      float s = S.B[6][p];
-      for (int i = p + 1; i < 6; ++i) s -= S.B[i][p] * x[i];
-      x[p] = s / S.B[p][p];
+      float s = S.u.B[6][p];
+      for (int i = p + 1; i < 6; ++i) s -= S.u.B[i][p] * x[i];
+      x[p] = s / S.u.B[p][p];
       S.vec[p] = x[p];
     }
   }
@@ -298,10 +296,10 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
   PFOR(c, 4) {
     float x[5];
     for (int p = 4; p >= 0; --p) {
-      float s = S.A[c][11][p];
-      for (int i = p + 1; i < 5; ++i) s -= S.A[c][i][p] * x[i];
-      for (int i = 5; i < 11; ++i) s -= S.A[c][i][p] * S.vec[i - 5];
-      x[p] = s / S.A[c][p][p];
+      float s = S.u.A[c][11][p];
+      for (int i = p + 1; i < 5; ++i) s -= S.u.A[c][i][p] * x[i];
+      for (int i = 5; i < 11; ++i) s -= S.u.A[c][i][p] * S.vec[i - 5];
+      x[p] = s / S.u.A[c][p][p];
       S.vec[10 + 5 * c - p] = x[p];
     }
   }
@@ -311,11 +309,13 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
 // y = M v using the tree sparsity
 KBJ_DEV float mul_M_row(const KbjShared& S, int i, const float* v) {
   float s = 0;
-  if (i < 6) { for (int j = 0; j < NV; ++j) s += S.M[i][j] * v[j]; }
-  else {
-    for (int j = 0; j < 6; ++j) s += S.M[i][j] * v[j];
-    int c0 = 6 + 5 * ((i - 6) / 5);
-    for (int j = c0; j < c0 + 5; ++j) s += S.M[i][j] * v[j];
+  if (i < 6) {
+    for (int j = 0; j < 6; ++j) s += M_get(S, i, j) * v[j];
+    for (int j = 6; j < NV; ++j) s += S.Mc[(j - 6) / 5][(j - 6) % 5][i] * v[j];
+  } else {
+    int c = (i - 6) / 5, a = (i - 6) % 5;
+    for (int j = 0; j < 6; ++j) s += S.Mc[c][a][j] * v[j];
+    for (int b = 0; b < 5; ++b) s += (b <= a ? S.Mc[c][a][6 + b] : S.Mc[c][b][6 + a]) * v[6 + 5 * c + b];
   }
   return s;
 }
@@ -350,24 +350,23 @@ KBJ_DEV void phys_make_constraints(KbjShared& S, const kbj_model& m, const PhysC
     kbi(m.fric_solref, m.fric_solimp, 0.0f, pc.dt, k, b, imp);
     float fl = S.ep[KBJ_EP_FRICLOSS + dof];
     float Rr = fmaxf(1e-15f, (1 - imp) / imp * m.dof_invweight0[dof]);
-    S.R[u] = Rr; S.D[u] = 1 / Rr; S.aref[u] = -b * qvel[dof]; S.floss[u] = fl; S.active[u] = fl > 0;
+    S.Rf[u] = Rr; S.D[u] = fl > 0 ? 1 / Rr : 0.0f; S.aref[u] = -b * qvel[dof]; S.floss[u] = fl;
     float q = qpos[7 + u];
     float dlo = q - m.dof_range[dof][0], dhi = m.dof_range[dof][1] - q;
     float pos = fminf(dlo, dhi), sgn = dlo < dhi ? 1.0f : -1.0f;
     int r = ROW_LIM + u;
-    S.lsign[u] = sgn; S.floss[r] = 0;
+    S.lsign[u] = sgn;
     if (pos < 0) {
       kbi(m.limit_solref, m.limit_solimp, pos, pc.dt, k, b, imp);
       float Rl = fmaxf(1e-15f, (1 - imp) / imp * m.dof_invweight0[dof]);
-      S.R[r] = Rl; S.D[r] = 1 / Rl; S.aref[r] = -b * sgn * qvel[dof] - k * imp * pos; S.active[r] = 1;
-    } else { S.R[r] = 0; S.D[r] = 0; S.aref[r] = 0; S.active[r] = 0; }
+      S.D[r] = 1 / Rl; S.aref[r] = -b * sgn * qvel[dof] - k * imp * pos;
+    } else { S.D[r] = 0; S.aref[r] = 0; }
   }
   PFOR(r, 32) {
     int ci = r / 4, e = r % 4, leg = ci / 4, row = ROW_CON + r;
-    S.floss[row] = 0;
     if (!S.conact[ci]) {
-      S.active[row] = 0; S.D[row] = 0; S.R[row] = 0; S.aref[row] = 0;
-      for (int k = 0; k < 12; ++k) S.Jc[r][k] = 0;
+      S.D[row] = 0; S.aref[row] = 0;
+      for (int k = 0; k < 11; ++k) S.Jc[r][k] = 0;
       continue;
     }
     float off[3] = {S.conpos[ci][0] - S.com[0], S.conpos[ci][1] - S.com[1], S.conpos[ci][2] - S.com[2]};
@@ -383,43 +382,40 @@ KBJ_DEV void phys_make_constraints(KbjShared& S, const kbj_model& m, const PhysC
       S.Jc[r][k] = j;
       vel += j * qvel[dk];
     }
-    S.Jc[r][11] = 0;
     float k_, b_, imp;
     kbi(m.contact_solref, m.contact_solimp, S.condist[ci], pc.dt, k_, b_, imp);
     float tran = m.body_invweight0[leg ? 12 : 7][0];
     float invw = (tran + mu * mu * tran) * 2 * mu * mu;
     float Rc = fmaxf(1e-15f, (1 - imp) / imp * invw);
-    S.R[row] = Rc; S.D[row] = 1 / Rc; S.aref[row] = -b_ * vel - k_ * imp * S.condist[ci]; S.active[row] = 1;
+    S.D[row] = 1 / Rc; S.aref[row] = -b_ * vel - k_ * imp * S.condist[ci];
   }
   KBJ_SYNC();
+}
+
+// J q for row r (r active)
+KBJ_DEV float row_dot(const KbjShared& S, int r, const float* q) {
+  if (r < ROW_LIM) return q[6 + r];
+  if (r < ROW_CON) return S.lsign[r - ROW_LIM] * q[6 + r - ROW_LIM];
+  int rr = r - ROW_CON, leg = rr / 16;
+  float x = 0;
+  for (int k = 0; k < 6; ++k) x += S.Jc[rr][k] * q[k];
+  for (int k = 6; k < 11; ++k) x += S.Jc[rr][k] * q[6 + 5 * leg + (k - 6)];
+  return x;
 }
 
 // residual of every row for a candidate acceleration q: jar = J q - aref
 KBJ_DEV void rows_residual(KbjShared& S, const float* q) {
   PFOR(i, NV) S.Ma[i] = mul_M_row(S, i, q);
-  PFOR(r, NROW) {
-    float x = 0;
-    if (S.active[r]) {
-      if (r < ROW_LIM) x = q[6 + r];
-      else if (r < ROW_CON) x = S.lsign[r - ROW_LIM] * q[6 + r - ROW_LIM];
-      else {
-        int rr = r - ROW_CON, leg = rr / 16;
-        for (int k = 0; k < 6; ++k) x += S.Jc[rr][k] * q[k];
-        for (int k = 6; k < 11; ++k) x += S.Jc[rr][k] * q[6 + 5 * leg + (k - 6)];
-      }
-      x -= S.aref[r];
-    }
-    S.jar[r] = x;
-  }
+  PFOR(r, NROW) S.jar[r] = S.D[r] != 0 ? row_dot(S, r, q) - S.aref[r] : 0.0f;
   KBJ_SYNC();
 }
 
 // per-lane cost / derivative contributions: lane l < 20 owns friction+limit rows of joint l, lanes 32..63 one contact row
 KBJ_DEV float row_cost(const KbjShared& S, int r, float x) {
-  if (!S.active[r]) return 0.0f;
   float D = S.D[r];
+  if (D == 0) return 0.0f;
   if (r < ROW_LIM) {
-    float f = S.floss[r], Rr = S.R[r];
+    float f = S.floss[r], Rr = S.Rf[r];
     if (x <= -Rr * f) return f * (-0.5f * Rr * f - x);
     if (x >= Rr * f) return f * (-0.5f * Rr * f + x);
     return 0.5f * D * x * x;
@@ -427,10 +423,11 @@ KBJ_DEV float row_cost(const KbjShared& S, int r, float x) {
   return x < 0 ? 0.5f * D * x * x : 0.0f;
 }
 KBJ_DEV void row_deriv(const KbjShared& S, int r, float a, float& d1, float& d2) {
-  if (!S.active[r]) return;
-  float jv = S.jv[r], x = S.jar[r] + a * jv, D = S.D[r];
+  float D = S.D[r];
+  if (D == 0) return;
+  float jv = S.jv[r], x = S.jar[r] + a * jv;
   if (r < ROW_LIM) {
-    float f = S.floss[r], Rr = S.R[r];
+    float f = S.floss[r], Rr = S.Rf[r];
     if (x <= -Rr * f) d1 -= f * jv;
     else if (x >= Rr * f) d1 += f * jv;
     else { d1 += D * x * jv; d2 += D * jv * jv; }
@@ -448,12 +445,12 @@ KBJ_DEV float total_cost(const KbjShared& S, const float* q) {
 
 KBJ_DEV void rows_force(KbjShared& S) {
   PFOR(r, NROW) {
-    float f = 0;
+    float f = 0, D = S.D[r];
     int quad = 0;
-    if (S.active[r]) {
-      float x = S.jar[r], D = S.D[r];
+    if (D != 0) {
+      float x = S.jar[r];
       if (r < ROW_LIM) {
-        float fl = S.floss[r], Rr = S.R[r];
+        float fl = S.floss[r], Rr = S.Rf[r];
         if (x <= -Rr * fl) f = fl;
         else if (x >= Rr * fl) f = -fl;
         else { f = -D * x; quad = 1; }
@@ -466,6 +463,7 @@ KBJ_DEV void rows_force(KbjShared& S) {
 
 // Newton iterations on the convex constraint cost with an exact (safeguarded Newton) line search
 KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
+  float* warm = S.es + KBJ_ES_WARM;
   arrow_solve(S, S.qfrc_smooth, false);
   PFOR(i, NV) S.qacc_smooth[i] = S.vec[i];
   KBJ_SYNC();
@@ -473,11 +471,11 @@ KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
   rows_residual(S, S.qacc_smooth);
   float cs = total_cost(S, S.qacc_smooth);
   KBJ_SYNC();
-  rows_residual(S, S.warm);
-  float cw = total_cost(S, S.warm);
+  rows_residual(S, warm);
+  float cw = total_cost(S, warm);
   KBJ_SYNC();
   bool use_warm = cw < cs;
-  PFOR(i, NV) S.qacc[i] = use_warm ? S.warm[i] : S.qacc_smooth[i];
+  PFOR(i, NV) S.qacc[i] = use_warm ? warm[i] : S.qacc_smooth[i];
   KBJ_SYNC();
   if (!use_warm) rows_residual(S, S.qacc);
   float scale = 1.0f / (m.meaninertia * NV);
@@ -502,19 +500,7 @@ KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
     PFOR(i, NV) S.search[i] = S.vec[i];
     KBJ_SYNC();
     PFOR(i, NV) S.mv[i] = mul_M_row(S, i, S.search);
-    PFOR(r, NROW) {
-      float x = 0;
-      if (S.active[r]) {
-        if (r < ROW_LIM) x = S.search[6 + r];
-        else if (r < ROW_CON) x = S.lsign[r - ROW_LIM] * S.search[6 + r - ROW_LIM];
-        else {
-          int rr = r - ROW_CON, leg = rr / 16;
-          for (int k = 0; k < 6; ++k) x += S.Jc[rr][k] * S.search[k];
-          for (int k = 6; k < 11; ++k) x += S.Jc[rr][k] * S.search[6 + 5 * leg + (k - 6)];
-        }
-      }
-      S.jv[r] = x;
-    }
+    PFOR(r, NROW) S.jv[r] = S.D[r] != 0 ? row_dot(S, r, S.search) : 0.0f;
     KBJ_SYNC();
     float g1, g2;
     wsum2(NV, [&](int l, float& a, float& b) { a = S.search[l] * (S.Ma[l] - S.qfrc_smooth[l]); b = S.search[l] * S.mv[l]; }, g1, g2);
@@ -562,11 +548,12 @@ KBJ_DEV void phys_sensors(KbjShared& S, const kbj_model& m) {
       rotate_by_quat(g, iq, true, S.pg);
     } else {
       int foot = w - 1, body = foot ? 12 : 7;
-      float tot = 0;
+      float tot = 0, mat[9];
+      quat_to_mat(S.xquat[body], mat);
       for (int ci = 4 * foot; ci < 4 * foot + 4; ++ci) {
         if (!S.conact[ci]) continue;
         float rel[3] = {S.conpos[ci][0] - S.xpos[body][0], S.conpos[ci][1] - S.xpos[body][1], S.conpos[ci][2] - S.xpos[body][2]}, loc[3];
-        matT_vec(S.xmat[body], rel, loc);
+        matT_vec(mat, rel, loc);
         bool inside = true;
         for (int k = 0; k < 3; ++k) inside = inside && fabsf(loc[k] - m.site_pos[foot][k]) <= m.site_size[foot][k];
         if (!inside) continue;
@@ -590,11 +577,11 @@ KBJ_DEV void phys_forward(KbjShared& S, const kbj_model& m, const PhysConst& pc)
   phys_sensors(S, m);
 }
 
-// semi-implicit Euler; also refreshes the warm start
+// semi-implicit Euler; also refreshes the warm start (kept in the state row)
 KBJ_DEV void phys_integrate(KbjShared& S, const PhysConst& pc) {
   float* qpos = S.es + KBJ_ES_QPOS;
   float* qvel = S.es + KBJ_ES_QVEL;
-  PFOR(i, NV) { qvel[i] += pc.dt * S.qacc[i]; S.warm[i] = S.qacc[i]; }
+  PFOR(i, NV) { qvel[i] += pc.dt * S.qacc[i]; S.es[KBJ_ES_WARM + i] = S.qacc[i]; }
   KBJ_SYNC();
   PFOR(i, NV) {
     if (i < 3) qpos[i] += pc.dt * qvel[i];

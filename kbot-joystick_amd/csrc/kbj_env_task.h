@@ -100,7 +100,7 @@ KBJ_DEV void task_reset(KbjShared& S, const kbj_model& m, const kbj_config& c, c
     es[KBJ_ES_QVEL + 6 + u] = rng_uniform(rng, KBJ_RNG_RESET, e, 20 + u, -c.reset_joint_vel_scale, c.reset_joint_vel_scale);
     es[KBJ_ES_ACT_PREV + u] = m.joint_bias[u];
   }
-  PFOR(i, NV) { es[KBJ_ES_WARM + i] = 0; S.warm[i] = 0; if (i < 6) es[KBJ_ES_QVEL + i] = 0; }
+  PFOR(i, NV) { es[KBJ_ES_WARM + i] = 0; if (i < 6) es[KBJ_ES_QVEL + i] = 0; }
   KBJ_SYNC();
   PFOR(w, 1) {
     es[KBJ_ES_QVEL + 0] = rng_uniform(rng, KBJ_RNG_RESET, e, 40, -c.reset_base_vel_xy_scale, c.reset_base_vel_xy_scale);
@@ -245,7 +245,6 @@ KBJ_DEV void task_step(KbjShared& S, const kbj_model& m, const kbj_config& c, co
   uint32_t st = f2u(es[KBJ_ES_STEP]);
   bool drop = rng_u01(rng, KBJ_RNG_DROP, st, 0) < c.drop_action_prob;
   PFOR(u, NU) S.act_eff[u] = drop ? es[KBJ_ES_ACT_PREV + u] : action[u];
-  PFOR(i, NV) S.warm[i] = es[KBJ_ES_WARM + i];
   PFOR(w, 1) {  // ForcePushEvent (train.py:1134-1144)
     int pushing = 0;
     if (c.enable_pushes) {
@@ -271,7 +270,6 @@ KBJ_DEV void task_step(KbjShared& S, const kbj_model& m, const kbj_config& c, co
     phys_integrate(S, pc);
   }
   PFOR(u, NU) { es[KBJ_ES_ACT_PREV + u] = S.act_eff[u]; aux_t[KBJ_AUX_CTRL + u] = S.ctrl[u]; }
-  PFOR(i, NV) es[KBJ_ES_WARM + i] = S.warm[i];
   PFOR(w, 1) {
     es[KBJ_ES_TIME] += 1;
     es[KBJ_ES_STEP] = u2f(st + 1u);
