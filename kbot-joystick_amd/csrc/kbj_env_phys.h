@@ -517,8 +517,10 @@ KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
       float lo = 0, hi = 0;
       bool hi_valid = false;
       float a = -d1 / d2;
+      const float d1_stop = 0.01f * fabsf(d1);  // MuJoCo's default ls_tolerance: relative slope reduction
       for (int ls = 0; ls < pc.ls_iterations; ++ls) {
         eval(a, d1, d2);
+        if (fabsf(d1) <= d1_stop) break;
         if (d1 < 0) lo = a; else { hi = a; hi_valid = true; }
         float an = a - d1 / d2;
         if (an <= lo || (hi_valid && an >= hi)) an = hi_valid ? 0.5f * (lo + hi) : 2 * a;

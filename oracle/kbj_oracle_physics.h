@@ -517,8 +517,10 @@ template <class R> struct Physics {
       if (d1 < 0 && d2 > 0) {
         R lo = 0, hi = 0; bool hi_valid = false;
         R a = -d1 / d2;
+        const R d1_stop = (R)0.01 * std::fabs(d1);  // MuJoCo's default ls_tolerance: relative slope reduction
         for (int ls = 0; ls < opt.ls_iterations; ++ls) {
           eval(a, d1, d2);
+          if (std::fabs(d1) <= d1_stop) break;
           if (d1 < 0) lo = a; else { hi = a; hi_valid = true; }
           R an = a - d1 / d2;
           if (an <= lo || (hi_valid && an >= hi)) an = hi_valid ? (R)0.5 * (lo + hi) : 2 * a;
