@@ -237,10 +237,31 @@ KBJ_DEV void phys_smooth_forces(KbjShared& S, const kbj_model& m) {
 // G = M (+ J^T D J over rows in their quadratic zone when `hess`); solves G x = rhs, result in S.vec.
 // local index li of chain c: li 0..4 <-> dof 10+5c-li (ankle first), li 5..10 <-> base dof li-5.
 // Overwrites the union S.u (crb / cfrc are dead by the time a solve runs).
+// The 77 stored entries (i, j) of one augmented 12 x 11 lower-triangular block, sorted by column j DESCENDING: the trailing
+// sub-block a pivot p updates (j > p) is then the contiguous prefix of n_p = TRI_N[p] entries, so no lane idles.
+struct TriTab { unsigned char i[77], j[77]; };
+constexpr TriTab make_tri() {
+  TriTab t{};
+  int n = 0;
+  for (int j = 10; j >= 0; --j) for (int i = j; i <= 11; ++i) { t.i[n] = (unsigned char)i; t.j[n] = (unsigned char)j; ++n; }
+  return t;
+}
+#ifdef KBJ_EMU
+static const TriTab TRI = make_tri();
+#else
+__device__ const TriTab TRI = make_tri();
+#endif
+KBJ_DEV int tri_count(int p) { return 65 - p * (23 - p) / 2; }  // entries with j > p: 65, 54, 44, 35, 27 for p = 0..4
+
+#ifdef KBJ_EMU
+#define KBJ_RCP(x) (1.0f / (x))
+#else
+#define KBJ_RCP(x) __frcp_rn(x)
+#endif
+
 KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
-  PFOR(w, 4 * 12 * 11) {
-    int c = w / 132, i = (w % 132) / 11, j = w % 11;
-    if (i < 11 && j > i) continue;
+  PFOR(w, 4 * 77) {
+    int c = w / 77, e = w % 77, i = TRI.i[e], j = TRI.j[e];
     float v;
     if (i == 11) v = j < 5 ? rhs[10 + 5 * c - j] : 0.0f;
     else {
@@ -264,9 +285,10 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
   KBJ_SYNC();
   // column p keeps its unscaled entries (L_ip D_p), so each pivot is ONE phase
   for (int p = 0; p < 5; ++p) {
-    PFOR(w, 4 * 121) {
-      int c = w / 121, e = w % 121, i = p + 1 + e / 11, j = p + 1 + e % 11;
-      if (i <= 11 && j <= 10 && j <= i) S.u.A[c][i][j] -= S.u.A[c][i][p] * S.u.A[c][j][p] / S.u.A[c][p][p];
+    const int np = tri_count(p);
+    PFOR(w, 4 * np) {
+      int c = w / np, e = w % np, i = TRI.i[e], j = TRI.j[e];
+      S.u.A[c][i][j] -= S.u.A[c][i][p] * S.u.A[c][j][p] * KBJ_RCP(S.u.A[c][p][p]);
     }
     KBJ_SYNC();
   }
@@ -280,7 +302,7 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
   }
   KBJ_SYNC();
   for (int p = 0; p < 6; ++p) {
-    PFOR(w, 36) { int i = p + 1 + w / 6, j = p + 1 + w % 6; if (i <= 6 && j <= 5 && j <= i) S.u.B[i][j] -= S.u.B[i][p] * S.u.B[j][p] / S.u.B[p][p]; }
+    PFOR(w, 36) { int i = p + 1 + w / 6, j = p + 1 + w % 6; if (i <= 6 && j <= 5 && j <= i) S.u.B[i][j] -= S.u.B[i][p] * S.u.B[j][p] * KBJ_RCP(S.u.B[p][p]); }
     KBJ_SYNC();
   }
   PFOR(w, 1) {
@@ -288,9 +310,17 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
     for (int p = 5; p >= 0; --p) {
       float s = S.u.B[6][p];
       for (int i = p + 1; i < 6; ++i) s -= S.u.B[i][p] * x[i];
-      x[p] = s / S.u.B[p][p];
+      x[p] = s * KBJ_RCP(S.u.B[p][p]);
       S.vec[p] = x[p];
     }
+  }
+  KBJ_SYNC();
+  // chains: the base part of every back-substitution row is independent -> 20 lanes; only the 10 in-chain products stay serial
+  PFOR(w, 4 * 5) {
+    int c = w / 5, p = w % 5;
+    float s = S.u.A[c][11][p];
+    for (int i = 5; i < 11; ++i) s -= S.u.A[c][i][p] * S.vec[i - 5];
+    S.u.A[c][11][p] = s;
   }
   KBJ_SYNC();
   PFOR(c, 4) {
@@ -298,8 +328,7 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
     for (int p = 4; p >= 0; --p) {
       float s = S.u.A[c][11][p];
       for (int i = p + 1; i < 5; ++i) s -= S.u.A[c][i][p] * x[i];
-      for (int i = 5; i < 11; ++i) s -= S.u.A[c][i][p] * S.vec[i - 5];
-      x[p] = s / S.u.A[c][p][p];
+      x[p] = s * KBJ_RCP(S.u.A[c][p][p]);
       S.vec[10 + 5 * c - p] = x[p];
     }
   }
