@@ -52,6 +52,7 @@ struct SeqBwdArgs {
   unsigned* counters;
   unsigned* err;
   int T, B;
+  float* db;             // optional [4H]: bias gradient accumulated with atomics (column sums of dG)
 };
 
 // gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each; shared with the rollout cell kernel)
@@ -233,7 +234,9 @@ template <int H>
 __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   constexpr int LDH = H + 4;
   constexpr int NUG = H / SEQ_UNITS;
-  __shared__ __attribute__((aligned(16))) float ds[2][SEQ_ROWS * LDH];  // gate chunks of dG_{t+1}, double buffered
+  // one gate chunk of dG_{t+1} at a time: a single 33 KB buffer (plus pbuf) keeps the workgroup at 42 KB of LDS so that two
+  // recurrences (actor + critic) AND two GEMM workgroups fit on a CU together (profiles/r01: double buffering starved the GEMMs)
+  __shared__ __attribute__((aligned(16))) float ds[SEQ_ROWS * LDH];
   __shared__ float pbuf[4][SEQ_ROWS][SEQ_UNITS + 1];                     // per-wave partial sums of dh
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -254,6 +257,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
     for (int s = 0; s < KS; ++s) wreg[c][s] = a.Whh[(size_t)(c * H + wave * KW + 4 * s + (lane >> 4)) * H + u0 + (lane & 15)];
   int erow[2], eunit[2];
   float dcm[2] = {0.0f, 0.0f};
+  float bsum[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // running column sums of dG (bias gradient)
 #pragma unroll
   for (int i = 0; i < 2; ++i) { int e = tid + 256 * i; erow[i] = e / SEQ_UNITS; eunit[i] = e % SEQ_UNITS; }
   // everything the cell derivative of a step needs (produced by earlier kernels) is fetched ONE STEP AHEAD
@@ -293,7 +297,8 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       prefetch();                               // own inputs ride behind the first payload chunk
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        float* buf = ds[c & 1];
+        float* buf = ds;
+        if (c) __syncthreads();                                   // the previous chunk's fragment reads are done
         tile.to_lds(buf);
         if (c < 3) tile.load(src + (c + 1) * H, 4 * H, r0, B);   // next chunk in flight during this chunk's MFMAs
         __syncthreads();
@@ -322,13 +327,31 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       float dh = dha[i] + kp[i] * dhm[i];
       float dc = kp[i] * dcm[i] + dh * og * (1 - tc[i] * tc[i]);
       float* dg = a.dG + ((size_t)t * B + r) * 4 * H + u0 + eunit[i];
-      seq_store(dg, dc * gg * ig * (1 - ig));            // dG is the hand-off payload (and the input of the batched dW GEMMs)
-      seq_store(dg + H, dc * cprev[i] * fg * (1 - fg));
-      seq_store(dg + 2 * H, dc * ig * (1 - gg * gg));
-      seq_store(dg + 3 * H, dh * tc[i] * og * (1 - og));
+      float d0 = dc * gg * ig * (1 - ig), d1 = dc * cprev[i] * fg * (1 - fg), d2 = dc * ig * (1 - gg * gg), d3 = dh * tc[i] * og * (1 - og);
+      seq_store(dg, d0);            // dG is the hand-off payload (and the input of the batched dW GEMMs)
+      seq_store(dg + H, d1);
+      seq_store(dg + 2 * H, d2);
+      seq_store(dg + 3 * H, d3);
+      bsum[i][0] += d0; bsum[i][1] += d1; bsum[i][2] += d2; bsum[i][3] += d3;
       dcm[i] = dc * fg;
     }
     seq_publish(a.counters + rg * NUG + ug, (unsigned)(T - t));
+  }
+  // bias gradient = column sums of dG over all rows and steps: reduce this workgroup's 32 rows in LDS, one atomic per column
+  if (a.db) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      pbuf[k][erow[0]][eunit[0]] = bsum[0][k];
+      pbuf[k][erow[1]][eunit[1]] = bsum[1][k];
+    }
+    __syncthreads();
+    if (tid < 64) {
+      int k = tid / SEQ_UNITS, u = tid % SEQ_UNITS;
+      float s = 0;
+      for (int r = 0; r < SEQ_ROWS; ++r) s += pbuf[k][r][u];
+      atomicAdd(a.db + k * H + u0 + u, s);
+    }
   }
 }
 

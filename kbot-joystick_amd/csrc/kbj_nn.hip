@@ -397,14 +397,13 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     float* dx_out = t.dHb;
     for (int l = 1; l >= 0; --l) {
       float* dG = t.dGl[l];
-      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above, w.keep, params_d + o.w_hh[l], dG, w.seq_counters + 256 * n, w.seq_err, T, B};
+      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above, w.keep, params_d + o.w_hh[l], dG, w.seq_counters + 256 * n, w.seq_err, T, B, grad_d + o.b[l]};
       if (seq_bwd(ctx, s, H, ba)) return -1;
       if (!one_stream) fork_side();
       const float* xin = l == 0 ? t.X0 : t.Hout[0];
       linear_bwd_input(s, dG, 4 * H, params_d + o.w_ih[l], H, dx_out, H, R, H, 4 * H, 0);
       linear_bwd_weight(ws, dG, 4 * H, t.Hm[l], H, grad_d + o.w_hh[l], H, 4 * H, H, R);
       linear_bwd_weight(ws, dG, 4 * H, xin, H, grad_d + o.w_ih[l], H, 4 * H, H, R);
-      hipLaunchKernelGGL(colsum_kernel, dim3((4 * H + 63) / 64, 64), dim3(256), 0, ws, dG, R, 4 * H, 4 * H, grad_d + o.b[l]);
       std::swap(dh_above, dx_out);
     }
     // input projection (dh_above now holds dX0)
