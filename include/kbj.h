@@ -119,6 +119,9 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* traj, cons
 /* replaces: optax.adamw + global-norm clip (train.py:1059-1077). step is 1-based. grad_scale multiplies the
  * gradient first (1/world_size after an all-reduce sum). */
 int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const float* grad_d, int64_t step, float grad_scale);
+/* replaces: optax.cosine_decay_schedule feeding adamw (train.py:1067-1077): the host evaluates the schedule and sets the
+ * learning rate used by the following kbj_adamw_step calls. */
+int kbj_set_learning_rate(kbj_ctx* ctx, float learning_rate);
 
 /* per-launch timing of the dominant kernels, measured with HIP events on the context's stream (bench.py roofline) */
 int kbj_profile_begin(kbj_ctx* ctx);

@@ -417,6 +417,12 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   return 0;
 }
 
+int kbj_set_learning_rate(kbj_ctx* ctx, float learning_rate) {
+  if (!ctx || !(learning_rate >= 0.0f)) return kbj_fail(ctx, "kbj_set_learning_rate: bad argument");
+  ctx->cfg_h.learning_rate = learning_rate;
+  return 0;
+}
+
 int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const float* grad_d, int64_t step, float grad_scale) {
   if (!ctx || !params_d || !m_d || !v_d || !grad_d || step < 1) return kbj_fail(ctx, "kbj_adamw_step: bad argument");
   NnWs& w = *ws_of(ctx);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "kbj_gae": (_i, [_vp, C.POINTER(Traj), _vp, _vp]),
     "kbj_ppo_grad": (_i, [_vp, _vp, C.POINTER(Traj), _vp, _i, _vp, _vp, _vp, _vp]),
     "kbj_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _f]),
+    "kbj_set_learning_rate": (_i, [_vp, _f]),
     "kbj_profile_begin": (_i, [_vp]),
     "kbj_profile_end": (_i, [_vp, C.POINTER(_f), C.POINTER(_i), C.POINTER(_f), C.POINTER(_i)]),
 }
@@ -185,6 +186,9 @@ class Context:
 
     def adamw_step(self, params, m, v, grad, step, grad_scale=1.0):
         self.call("kbj_adamw_step", _ptr(params), _ptr(m), _ptr(v), _ptr(grad), step, grad_scale)
+
+    def set_learning_rate(self, lr: float):
+        self.call("kbj_set_learning_rate", lr)
 
     def profile_begin(self):
         self.call("kbj_profile_begin")

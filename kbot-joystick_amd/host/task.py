@@ -66,8 +66,9 @@ class HumanoidWalkingTaskConfig:
         if self.actor_mirror_loss_scale != 0.0 or self.critic_mirror_loss_scale != 0.0:
             raise NotImplementedError("mirror aux losses (train.py:1463-1481) are not built yet; the launch config sets both "
                                       "scales to 0.0 (train.py:1771-1772)")
-        if self.use_lr_decay:
-            raise NotImplementedError("cosine lr decay (train.py:1067-1077) is not built yet; the launch config disables it")
+        if self.use_lr_decay and self.adam_weight_decay == 0.0:
+            # train.py:1074-1075 chains scale_by_adam with scale_by_schedule and no sign flip (gradient ascent as written)
+            raise NotImplementedError("use_lr_decay with adam_weight_decay == 0 is not supported")
         T = int(round(self.rollout_length_seconds / self.ctrl_dt))
         kw = dict(num_envs=num_envs_local, env_id_offset=env_id_offset, rollout_len=T, substeps=int(round(self.ctrl_dt / self.dt)),
                   solver_iterations=self.iterations, ls_iterations=self.ls_iterations, hidden_size=self.hidden_size, depth=self.depth,
@@ -80,6 +81,13 @@ class HumanoidWalkingTaskConfig:
             cmd = list(self.fixed_command) + [0.0] * (L.NCMD - len(self.fixed_command))
             kw.update(command_mode=1, fixed_command=cmd)
         return L.default_config(**kw)
+
+
+def cosine_decay_lr(config: HumanoidWalkingTaskConfig, count: int) -> float:
+    """optax.cosine_decay_schedule(init_value, decay_steps, alpha) at optimizer-update count `count` (train.py:1068-1072)."""
+    frac = min(max(count, 0), config.lr_decay_steps) / config.lr_decay_steps
+    cosine = 0.5 * (1.0 + math.cos(math.pi * frac))
+    return config.learning_rate * ((1.0 - config.lr_final_multiplier) * cosine + config.lr_final_multiplier)
 
 
 def launch_config(**overrides) -> HumanoidWalkingTaskConfig:
@@ -160,6 +168,8 @@ class HumanoidWalkingTask:
                 idx = perm[mb * self.B:(mb + 1) * self.B].contiguous()
                 self.ctx.ppo_grad(self.params, self.traj.c, idx, self.B, self.traj.adv, self.traj.target, self.grad, self.metrics)
                 scale = dist_util.allreduce_grad_(self.grad, self.world_size)   # RCCL over xGMI: the one exchange step
+                if self.config.use_lr_decay:
+                    self.ctx.set_learning_rate(cosine_decay_lr(self.config, self.opt_step))
                 self.opt_step += 1
                 self.ctx.adamw_step(self.params, self.opt_m, self.opt_v, self.grad, self.opt_step, scale)
 

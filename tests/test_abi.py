@@ -74,3 +74,15 @@ def test_task_config_guards():
     c = launch_config().to_kbj(4096)
     assert (c.rollout_len, c.substeps, c.hidden_size, c.batch_size, c.num_passes) == (100, 5, 256, 512, 3)
     assert abs(c.lpf_alpha - 0.02 / (0.02 + 1 / (2 * 3.141592653589793 * 10))) < 1e-7
+
+
+def test_cosine_decay_schedule():
+    """optax.cosine_decay_schedule restated on the host (train.py:1067-1072)."""
+    from kbot_joystick_amd.host.task import cosine_decay_lr, launch_config
+    c = launch_config(use_lr_decay=True, lr_decay_steps=1000, lr_final_multiplier=0.01, learning_rate=5e-4)
+    assert abs(cosine_decay_lr(c, 0) - 5e-4) < 1e-12
+    assert abs(cosine_decay_lr(c, 500) - 5e-4 * (0.99 * 0.5 + 0.01)) < 1e-12
+    assert abs(cosine_decay_lr(c, 1000) - 5e-6) < 1e-12 and abs(cosine_decay_lr(c, 5000) - 5e-6) < 1e-12
+    c.to_kbj(4096)                                               # adamw + schedule is supported
+    with pytest.raises(NotImplementedError):
+        launch_config(use_lr_decay=True, adam_weight_decay=0.0).to_kbj(4096)
