@@ -79,6 +79,10 @@ typedef struct kbj_carry {
   float* actor_hc_d;
   float* critic_hc_d;
   float* lpf_d;
+  /* mirror branches of the aux losses (train.py:1051-1055, 1463-1481); may be NULL when both mirror scales are 0 */
+  float* actor_mirror_hc_d;
+  float* critic_mirror_hc_d;
+  float* lpf_mirror_d;
 } kbj_carry;
 
 /* replaces: sample_action() (train.py:1545-1572) for all envs at one control step, fused with what the
@@ -103,6 +107,9 @@ typedef struct kbj_traj {
   float* carry0_actor_hc_d;  /* [depth][2][N][H] carry at the start of the trajectory (BPTT initial state) */
   float* carry0_critic_hc_d;
   float* carry0_lpf_d;       /* [N][20] */
+  float* carry0_actor_mirror_hc_d;   /* mirror-branch carries at the start of the trajectory (NULL when the mirror losses are off) */
+  float* carry0_critic_mirror_hc_d;
+  float* carry0_lpf_mirror_d;
 } kbj_traj;
 /* replaces: ksim's jitted rollout scan (vmap over envs, scan over T). Copies observation row T to row 0,
  * snapshots the carry, then T x (policy_step, env_step, carry_reset), then rewards. */
@@ -113,7 +120,10 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
 int kbj_gae(kbj_ctx* ctx, const kbj_traj* traj, float* adv_d, float* target_d);
 /* replaces: the loss/grad of one minibatch: get_ppo_variables under grad (BPTT through T LSTM steps,
  * train.py:1435-1524) + ksim's clipped PPO loss. env_idx_d [B] int32 env indices of the minibatch.
- * grad_d [P] flat gradient (overwritten), metrics_d [8]: loss, policy, value, entropy, clipfrac, kl, adv_mean, adv_std */
+ * When config.actor_mirror_loss_scale / critic_mirror_loss_scale are non-zero the mirror branches (train.py:1463-1481) run
+ * under the gradient too and their aux losses are added; the carry / trajectory mirror arrays must then be non-NULL.
+ * grad_d [P] flat gradient (overwritten), metrics_d [10]: loss, policy, value, entropy, clipfrac, kl, adv_mean, adv_std,
+ * action_mirror_loss, value_mirror_loss */
 int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* traj, const int32_t* env_idx_d, int B, const float* adv_d,
                  const float* target_d, float* grad_d, float* metrics_d);
 /* replaces: optax.adamw + global-norm clip (train.py:1059-1077). step is 1-based. grad_scale multiplies the

@@ -136,7 +136,9 @@ typedef struct kbj_config {
   float gamma, lam, clip_param, value_loss_coef, entropy_coef, log_ratio_clip, max_grad_norm;
   float learning_rate, adam_b1, adam_b2, adam_eps, weight_decay, adv_eps;
   float value_clip;          /* clipped value loss range */
-  float reserved_f[8];
+  float actor_mirror_loss_scale;  /* train.py:115-122 (dataclass defaults 1.0 / 0.01; launch config 0.0 / 0.0, train.py:1771-1772) */
+  float critic_mirror_loss_scale;
+  float reserved_f[6];
 } kbj_config;
 
 /* ---- per-env randomised model parameters ("EP" record, floats, one contiguous row per env) ---- */

@@ -30,8 +30,14 @@ struct NnWs {
   // rollout scratch
   float *rX[2] = {nullptr, nullptr}, *rG[2] = {nullptr, nullptr}, *rOut[2] = {nullptr, nullptr};
   float* joint_bias_d = nullptr;
+  // mirror aux losses (nets 2, 3 = actor, critic evaluated on mirrored observations with the SAME weights)
+  bool mirror = false;
+  int nnets = 2;
+  MirrorEntry* mtab[2] = {nullptr, nullptr};
+  float *rObsM[2] = {nullptr, nullptr};   // rollout: mirrored observation rows [N][ld]
+  float *y_m = nullptr, *sd_m = nullptr, *value_m = nullptr, *lpf0_m = nullptr, *dy = nullptr, *dy_m = nullptr, *dvalue_m = nullptr, *zeroR = nullptr;
   // training
-  TrainBufs tb[2];
+  TrainBufs tb[4];
   float *keep = nullptr, *act = nullptr, *logp_old = nullptr, *val_old = nullptr, *adv = nullptr, *target = nullptr;
   float *y = nullptr, *sd = nullptr, *logp = nullptr, *ent = nullptr, *value = nullptr, *dlogp = nullptr, *dvalue = nullptr, *lpf0 = nullptr;
   double* stats = nullptr;  // [0..1] adv stats, [2..9] metric accumulators, [10] grad sumsq
@@ -62,6 +68,44 @@ void layout_params(NnWs& w, int H) {
     if (n == 0) w.nactor = off;
   }
   w.nparams = off;
+}
+
+// Mirror of the packed observation rows as (source index, multiplier, offset) per element (mirror_rows_kernel).
+// Follows the index/sign lists of the reference's mirror_obs functions (train.py:1574-1756); element order = the obs packing
+// of kbj_env_task.h write_obs (kbj_model.h KBJ_NOBS_*).
+void build_mirror_tables(const kbj_model& m, std::vector<MirrorEntry>& ta, std::vector<MirrorEntry>& tc) {
+  auto swp = [](int i) { return i < 5 ? i + 5 : (i < 10 ? i - 5 : i); };  // left leg <-> right leg, arms stay (train.py:1574-1582)
+  tc.assign(KBJ_LD_CRITIC, MirrorEntry{0, 0.0f, 0.0f});
+  for (int k = 0; k < KBJ_LD_CRITIC; ++k) tc[k].src = k;
+  auto keep = [&](int k, float sgn) { tc[k] = MirrorEntry{k, sgn, 0.0f}; };
+  for (int i = 0; i < KBJ_NU; ++i) {
+    int s = swp(i);
+    auto rng = [&](int j) { return std::fmax(m.joint_bias[j] - m.joint_lo[j], m.joint_hi[j] - m.joint_bias[j]); };
+    tc[i] = MirrorEntry{s, -rng(s) / rng(i), (-m.joint_bias[s] - m.joint_bias[i]) / rng(i)};   // normalised joint positions
+    tc[20 + i] = MirrorEntry{20 + s, -1.0f, 0.0f};                                                // joint velocities / 10
+    tc[454 + i] = MirrorEntry{454 + s, -1.0f, 0.0f};                                              // actuator force / 4 (critic)
+  }
+  keep(40, -1); keep(41, 1); keep(42, 1); keep(43, -1); keep(44, 1);       // roll, pitch, unit projected gravity
+  keep(45, -1); keep(46, 1); keep(47, -1);                                   // gyro
+  keep(48, 1);                                                               // zero-command flag
+  const float cs[16] = {1, -1, -1, 1, -1, 1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // vx, vy, wz, height, roll, pitch, 10 arm targets
+  for (int k = 0; k < 16; ++k) keep(49 + k, cs[k]);
+  ta.assign(tc.begin(), tc.begin() + KBJ_LD_ACTOR);
+  for (int k = KBJ_NOBS_ACTOR; k < KBJ_LD_ACTOR; ++k) ta[k] = MirrorEntry{k, 0.0f, 0.0f};
+  tc[65] = MirrorEntry{66, 1, 0}; tc[66] = MirrorEntry{65, 1, 0};           // foot touch L <-> R
+  const float fs[3] = {1, -1, 1};
+  for (int k = 0; k < 3; ++k) { tc[67 + k] = MirrorEntry{70 + k, fs[k], 0}; tc[70 + k] = MirrorEntry{67 + k, fs[k], 0}; }   // feet positions
+  keep(73, 1); keep(74, 1); keep(75, 1);                                      // base position
+  keep(76, 1); keep(77, -1); keep(78, -1); keep(79, 1);                      // base quaternion
+  const float ci[10] = {1, 1, -1, 1, 1, 1, 1, -1, 1, -1}, cv[6] = {1, -1, 1, -1, 1, -1};
+  for (int b = 0; b < 23; ++b) {
+    for (int k = 0; k < 10; ++k) keep(80 + 10 * b + k, ci[k]);                // cinert
+    for (int k = 0; k < 6; ++k) keep(310 + 6 * b + k, cv[k]);                 // cvel
+  }
+  keep(448, 1); keep(449, -1); keep(450, 1);                                  // base linear velocity
+  keep(451, -1); keep(452, 1); keep(453, -1);                                 // base angular velocity
+  keep(474, 1);                                                               // base height
+  for (int k = KBJ_NOBS_CRITIC; k < KBJ_LD_CRITIC; ++k) tc[k] = MirrorEntry{k, 0.0f, 0.0f};
 }
 
 template <class T> int dalloc(kbj_ctx* ctx, NnWs& w, T** p, size_t count) {
@@ -162,9 +206,25 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->joint_bias_d, KBJ_NU)) return -1;
   if (hipMemcpy(w->joint_bias_d, ctx->model_h.joint_bias, KBJ_NU * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return kbj_fail(ctx, "hipMemcpy joint_bias");
   size_t R = T * B;
-  for (int n = 0; n < 2; ++n) {
+  w->mirror = c.actor_mirror_loss_scale != 0.0f || c.critic_mirror_loss_scale != 0.0f;
+  w->nnets = w->mirror ? 4 : 2;
+  if (w->mirror) {
+    std::vector<MirrorEntry> ta, tc;
+    build_mirror_tables(ctx->model_h, ta, tc);
+    if (dalloc(ctx, *w, &w->mtab[0], ta.size()) || dalloc(ctx, *w, &w->mtab[1], tc.size())) return -1;
+    if (hipMemcpy(w->mtab[0], ta.data(), ta.size() * sizeof(MirrorEntry), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(w->mtab[1], tc.data(), tc.size() * sizeof(MirrorEntry), hipMemcpyHostToDevice) != hipSuccess) return kbj_fail(ctx, "hipMemcpy mirror tables");
+    if (dalloc(ctx, *w, &w->rObsM[0], N * KBJ_LD_ACTOR) || dalloc(ctx, *w, &w->rObsM[1], N * KBJ_LD_CRITIC)) return -1;
+    float** rs[] = {&w->value_m, &w->dvalue_m, &w->zeroR};
+    for (float** p : rs) if (dalloc(ctx, *w, p, R)) return -1;
+    float** r20[] = {&w->y_m, &w->sd_m, &w->dy, &w->dy_m};
+    for (float** p : r20) if (dalloc(ctx, *w, p, R * KBJ_NU)) return -1;
+    if (dalloc(ctx, *w, &w->lpf0_m, B * KBJ_NU)) return -1;
+    if (hipMemset(w->zeroR, 0, R * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset zeroR");
+  }
+  for (int n = 0; n < w->nnets; ++n) {
     TrainBufs& t = w->tb[n];
-    if (dalloc(ctx, *w, &t.obs, R * w->net[n].ld_obs)) return -1;
+    if (dalloc(ctx, *w, &t.obs, R * w->net[n & 1].ld_obs)) return -1;
     if (dalloc(ctx, *w, &t.X0, R * H)) return -1;
     for (int l = 0; l < 2; ++l) {
       if (dalloc(ctx, *w, &t.G[l], R * 4 * H)) return -1;
@@ -236,28 +296,38 @@ int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_
   hipStream_t s = ctx->stream;
   int N = w.N, H = w.H;
   KbjTimed timed(ctx, true);
-  const float* obs[2] = {actor_obs_d, critic_obs_d};
-  float* hc[2] = {carry->actor_hc_d, carry->critic_hc_d};
-  for (int n = 0; n < 2; ++n) {
-    const NetOff& o = w.net[n];
-    linear_fwd(s, obs[n], o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, w.rX[n], H, N, H, o.nin, 0);
-    const float* x = w.rX[n];
+  if (w.mirror && (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d))
+    return kbj_fail(ctx, "kbj_policy_step: the mirror losses are enabled, the carry needs the mirror-branch arrays");
+  const float* obs[4] = {actor_obs_d, critic_obs_d, w.rObsM[0], w.rObsM[1]};
+  float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
+  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
+  for (int n = 0; n < w.nnets; ++n) {
+    const NetOff& o = w.net[n & 1];
+    const int k = n & 1;
+    if (n >= 2)  // mirror branches advance their own carries on the mirrored observations (train.py:1463-1481, 1555-1560)
+      hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)N * o.ld_obs), dim3(256), 0, s, obs[k], w.rObsM[k], (size_t)N, o.ld_obs, w.mtab[k]);
+    linear_fwd(s, obs[n], o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, w.rX[k], H, N, H, o.nin, 0);
+    const float* x = w.rX[k];
     for (int l = 0; l < 2; ++l) {
       float* h = hc[n] + (size_t)(2 * l) * N * H;
       float* cc = hc[n] + (size_t)(2 * l + 1) * N * H;
-      linear_fwd(s, x, H, params_d + o.w_ih[l], H, params_d + o.b[l], w.rG[n], 4 * H, N, 4 * H, H, 0);
-      linear_fwd(s, h, H, params_d + o.w_hh[l], H, nullptr, w.rG[n], 4 * H, N, 4 * H, H, 1);
+      linear_fwd(s, x, H, params_d + o.w_ih[l], H, params_d + o.b[l], w.rG[k], 4 * H, N, 4 * H, H, 0);
+      linear_fwd(s, h, H, params_d + o.w_hh[l], H, nullptr, w.rG[k], 4 * H, N, 4 * H, H, 1);
       CellFwdArgs2 ca;
-      ca.a[0] = CellFwdArgs{w.rG[n], cc, h, cc, nullptr, nullptr, nullptr, nullptr, N, H};
+      ca.a[0] = CellFwdArgs{w.rG[k], cc, h, cc, nullptr, nullptr, nullptr, nullptr, N, H};
       hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((N * H + 255) / 256, 1), dim3(256), 0, s, ca);
       x = h;
     }
-    linear_fwd(s, x, H, params_d + o.w_out, H, params_d + o.b_out, w.rOut[n], 40, N, o.nout, H, 0);
+    if (n == 3) break;  // the mirrored critic's value is only needed under the gradient; at rollout time only its carry advances
+    linear_fwd(s, x, H, params_d + o.w_out, H, params_d + o.b_out, w.rOut[k], 40, N, o.nout, H, 0);
+    if (n == 0)
+      hipLaunchKernelGGL(actor_head_sample_kernel, g1(N, 64), dim3(64), 0, s, w.rOut[0], actor_obs_d, carry->lpf_d, w.joint_bias_d, hp, seed,
+                         (uint32_t)c.env_id_offset, step_index, argmax, N, action_d, logp_d);
+    else if (n == 1)
+      hipLaunchKernelGGL(critic_value_kernel, g1(N), dim3(256), 0, s, w.rOut[1], 40, N, value_d);
+    else
+      hipLaunchKernelGGL(actor_head_lpf_kernel, g1((size_t)N * KBJ_NU), dim3(256), 0, s, w.rOut[0], w.rObsM[0], carry->lpf_mirror_d, w.joint_bias_d, c.lpf_alpha, N);
   }
-  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
-  hipLaunchKernelGGL(actor_head_sample_kernel, g1(N, 64), dim3(64), 0, s, w.rOut[0], actor_obs_d, carry->lpf_d, w.joint_bias_d, hp, seed,
-                     (uint32_t)c.env_id_offset, step_index, argmax, N, action_d, logp_d);
-  hipLaunchKernelGGL(critic_value_kernel, g1(N), dim3(256), 0, s, w.rOut[1], 40, N, value_d);
   KBJ_CHECK_LAUNCH(ctx, "kbj_policy_step");
   return 0;
 }
@@ -268,6 +338,11 @@ int kbj_carry_reset(kbj_ctx* ctx, kbj_carry* carry, const float* done_d, int don
   size_t n = (size_t)4 * w.N * w.H;
   hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, ctx->stream, carry->actor_hc_d, 4, w.N, w.H, carry->lpf_d, done_d, done_stride);
   hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, ctx->stream, carry->critic_hc_d, 4, w.N, w.H, (float*)nullptr, done_d, done_stride);
+  if (w.mirror) {
+    if (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d) return kbj_fail(ctx, "kbj_carry_reset: mirror-branch carry arrays are NULL");
+    hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, ctx->stream, carry->actor_mirror_hc_d, 4, w.N, w.H, carry->lpf_mirror_d, done_d, done_stride);
+    hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, ctx->stream, carry->critic_mirror_hc_d, 4, w.N, w.H, (float*)nullptr, done_d, done_stride);
+  }
   KBJ_CHECK_LAUNCH(ctx, "carry_reset_kernel");
   return 0;
 }
@@ -287,6 +362,13 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
   KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_actor_hc_d, carry->actor_hc_d, hcb, hipMemcpyDeviceToDevice, s));
   KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_critic_hc_d, carry->critic_hc_d, hcb, hipMemcpyDeviceToDevice, s));
   KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_lpf_d, carry->lpf_d, (size_t)N * KBJ_NU * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (w.mirror) {
+    if (!tr->carry0_actor_mirror_hc_d || !tr->carry0_critic_mirror_hc_d || !tr->carry0_lpf_mirror_d || !carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d)
+      return kbj_fail(ctx, "kbj_rollout: the mirror losses are enabled, carry and trajectory need the mirror-branch arrays");
+    KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_actor_mirror_hc_d, carry->actor_mirror_hc_d, hcb, hipMemcpyDeviceToDevice, s));
+    KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_critic_mirror_hc_d, carry->critic_mirror_hc_d, hcb, hipMemcpyDeviceToDevice, s));
+    KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_lpf_mirror_d, carry->lpf_mirror_d, (size_t)N * KBJ_NU * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
   for (int t = 0; t < T; ++t) {
     int rc = kbj_policy_step(ctx, params_d, tr->actor_obs_d + (size_t)t * N * la, tr->critic_obs_d + (size_t)t * N * lc, carry, seed,
                              first_step_index + (uint32_t)t, 0, tr->action_d + (size_t)t * N * KBJ_NU, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N);
@@ -332,8 +414,14 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   gather(adv_d, 1, 1, w.adv, 1);
   gather(target_d, 1, 1, w.target, 1);
   hipLaunchKernelGGL(gather_keep_kernel, g1(R), dim3(256), 0, s, tr->aux_d, idx, T, N, B, w.keep);
-  const float* carry0[2] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d};
-  for (int n = 0; n < 2; ++n)
+  const float* carry0[4] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d, tr->carry0_actor_mirror_hc_d, tr->carry0_critic_mirror_hc_d};
+  if (w.mirror) {
+    if (!carry0[2] || !carry0[3] || !tr->carry0_lpf_mirror_d) return kbj_fail(ctx, "kbj_ppo_grad: the mirror losses are enabled, the trajectory needs the mirror-branch carries");
+    for (int k = 0; k < 2; ++k)
+      hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)R * w.net[k].ld_obs), dim3(256), 0, s, w.tb[k].obs, w.tb[2 + k].obs, (size_t)R, w.net[k].ld_obs, w.mtab[k]);
+    hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * KBJ_NU), dim3(256), 0, s, tr->carry0_lpf_mirror_d, idx, 1, N, B, KBJ_NU, KBJ_NU, KBJ_NU, w.lpf0_m);
+  }
+  for (int n = 0; n < w.nnets; ++n)
     for (int l = 0; l < 2; ++l) {  // carry at the start of the trajectory: T = 1 gather of [N][H] planes
       hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * H), dim3(256), 0, s, carry0[n] + (size_t)(2 * l) * N * H, idx, 1, N, B, H, H, H, w.tb[n].Hm[l]);
       hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * H), dim3(256), 0, s, carry0[n] + (size_t)(2 * l + 1) * N * H, idx, 1, N, B, H, H, H, w.tb[n].Cm[l]);
@@ -345,10 +433,10 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipStream_t ns[2] = {ctx->stream, one_stream ? ctx->stream : ctx->stream2};
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  for (int n = 0; n < 2; ++n) {
-    const NetOff& o = w.net[n];
+  for (int n = 0; n < w.nnets; ++n) {   // nets 2, 3: the mirror branches, same weights, queued behind nets 0, 1 on the same two streams
+    const NetOff& o = w.net[n & 1];
     TrainBufs& t = w.tb[n];
-    hipStream_t s = ns[n];
+    hipStream_t s = ns[n & 1];
     linear_fwd(s, t.obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, t.X0, H, R, H, o.nin, 0);
     const float* xin = t.X0;
     for (int l = 0; l < 2; ++l) {
@@ -371,24 +459,34 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(256), 0, s, w.adv, R, w.stats);
   hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, s, w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
                      w.stats + 2);
+  if (w.mirror) {   // aux losses between each net and its mirror branch (train.py:1463-1481)
+    hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[2].Out, w.tb[2].obs, w.keep, w.lpf0_m, w.joint_bias_d, hp, T, B, w.y_m, w.sd_m);
+    hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, s, w.tb[3].Out, 40, R, w.value_m);
+    hipLaunchKernelGGL(mirror_loss_kernel, g1(R), dim3(256), 0, s, w.y, w.y_m, w.value, w.value_m, c.actor_mirror_loss_scale, c.critic_mirror_loss_scale, R, w.dy, w.dy_m,
+                       w.dvalue, w.dvalue_m, w.stats + 2);
+  }
   hipLaunchKernelGGL(ppo_metrics_kernel, dim3(1), dim3(1), 0, s, w.stats + 2, w.stats, pp, R, metrics_d);
   // ---- backward ----
   KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), s));
-  KBJ_HIP(ctx, hipMemsetAsync(w.tb[0].dOut, 0, (size_t)R * 40 * sizeof(float), s));
-  KBJ_HIP(ctx, hipMemsetAsync(w.tb[1].dOut, 0, (size_t)R * 40 * sizeof(float), s));
+  for (int n = 0; n < w.nnets; ++n) KBJ_HIP(ctx, hipMemsetAsync(w.tb[n].dOut, 0, (size_t)R * 40 * sizeof(float), s));
   hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[0].Out, w.y, w.sd, w.act, w.keep, w.dlogp,
-                     -c.entropy_coef / (float)R, hp, T, B, w.tb[0].dOut);
+                     w.mirror ? w.dy : (const float*)nullptr, -c.entropy_coef / (float)R, hp, T, B, w.tb[0].dOut);
   KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[1].dOut, 40 * sizeof(float), w.dvalue, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, s));
+  if (w.mirror) {   // the mirror actor only sees the aux gradient on its filtered mean (no log-prob, no entropy term)
+    hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[2].Out, w.y_m, w.sd_m, w.y_m, w.keep, w.zeroR,
+                       w.dy_m, 0.0f, hp, T, B, w.tb[2].dOut);
+    KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[3].dOut, 40 * sizeof(float), w.dvalue_m, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, s));
+  }
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  for (int n = 0; n < 2; ++n) {
-    const NetOff& o = w.net[n];
+  for (int n = 0; n < w.nnets; ++n) {
+    const NetOff& o = w.net[n & 1];
     TrainBufs& t = w.tb[n];
-    hipStream_t s = ns[n];
+    hipStream_t s = ns[n & 1];
     // The critical path of a net is dOut -> dH -> (recurrence, dX) per layer. Weight/bias gradients hang off it: they go to a
     // side stream (ws) so the throughput-bound split-K GEMMs fill the chip under the latency-bound recurrences.
-    hipStream_t ws = one_stream ? s : ctx->side[n];
-    auto fork_side = [&]() { hipEventRecord(ctx->ev_side[n], s); hipStreamWaitEvent(ws, ctx->ev_side[n], 0); };
+    hipStream_t ws = one_stream ? s : ctx->side[n & 1];
+    auto fork_side = [&]() { hipEventRecord(ctx->ev_side[n & 1], s); hipStreamWaitEvent(ws, ctx->ev_side[n & 1], 0); };
     linear_bwd_input(s, t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
     if (!one_stream) fork_side();
     linear_bwd_weight(ws, t.dOut, 40, t.Hout[1], H, grad_d + o.w_out, H, o.nout, H, R);
@@ -409,7 +507,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     // input projection (dh_above now holds dX0)
     linear_bwd_weight(s, dh_above, H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
     hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, 64), dim3(256), 0, s, dh_above, R, H, H, grad_d + o.b_in);
-    if (!one_stream) { hipEventRecord(ctx->ev_side[n], ws); hipStreamWaitEvent(s, ctx->ev_side[n], 0); }
+    if (!one_stream) { hipEventRecord(ctx->ev_side[n & 1], ws); hipStreamWaitEvent(s, ctx->ev_side[n & 1], 0); }
   }
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));

@@ -222,20 +222,67 @@ __global__ void ppo_loss_kernel(const float* __restrict__ logp, const float* __r
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) for (int k = 0; k < 5; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) for (int k = 0; k < 5; ++k) atomicAdd(&macc[k], red[k][0]);
 }
-// metrics[8] = loss, policy, value, entropy, clipfrac, kl, adv_mean, adv_std
+// metrics[10] = loss, policy, value, entropy, clipfrac, kl, adv_mean, adv_std, action_mirror_loss, value_mirror_loss
 __global__ void ppo_metrics_kernel(const double* __restrict__ macc, const double* __restrict__ stats, PpoParams pp, int R, float* __restrict__ metrics) {
-  double pol = macc[0] / R, vl = macc[1] / R, en = macc[2] / R;
+  double pol = macc[0] / R, vl = macc[1] / R, en = macc[2] / R, ma = macc[5] / R, mc = macc[6] / R;
   double mean = stats[0] / R, var = stats[1] / R - mean * mean;
-  metrics[0] = (float)(pol + pp.vcoef * vl - pp.ecoef * en);
+  metrics[0] = (float)(pol + pp.vcoef * vl - pp.ecoef * en + ma + mc);
+  metrics[8] = (float)ma; metrics[9] = (float)mc;
   metrics[1] = (float)pol; metrics[2] = (float)vl; metrics[3] = (float)en; metrics[4] = (float)(macc[3] / R); metrics[5] = (float)(macc[4] / R);
   metrics[6] = (float)mean; metrics[7] = (float)sqrt(var > 0 ? var : 0);
 }
 
+// ---- mirror aux losses (train.py:1463-1481, 1574-1756) ---------------------------------------------------------------
+// The sagittal mirror of a PACKED observation row is a signed permutation plus an affine fix-up of the normalised joint
+// positions (source and destination joints have different biases/ranges): out[k] = mul[k] * in[src[k]] + add[k].
+struct MirrorEntry { int src; float mul, add; };
+__global__ void mirror_rows_kernel(const float* __restrict__ in, float* __restrict__ out, size_t rows, int ld, const MirrorEntry* __restrict__ tab) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ld) return;
+  size_t r = i / ld;
+  int k = (int)(i - r * ld);
+  MirrorEntry e = tab[k];
+  out[i] = e.mul * in[r * ld + e.src] + e.add;
+}
+// mirror branch of the actor head at rollout time: only the low-pass state advances (no sampling)
+__global__ void actor_head_lpf_kernel(const float* __restrict__ out, const float* __restrict__ obs, float* __restrict__ lpf,
+                                      const float* __restrict__ joint_bias, float alpha, int N) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * KBJ_NU) return;
+  int n = i / KBJ_NU, j = i % KBJ_NU;
+  float mean = out[n * 40 + j] + joint_bias[j] + (j >= 10 ? obs[(size_t)n * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
+  float y0 = lpf[i];
+  lpf[i] = y0 + alpha * (mean - y0);
+}
+// per sample: action_mirror_loss = mean_j (y_j - mirror_joints(y_m)_j)^2 * sa, value_mirror_loss = (v - v_m)^2 * sc; both are
+// averaged over the minibatch and added to the loss. Writes the direct gradients on y, y_m (dy, dym [R][20]) and adds the
+// value terms to dvalue / writes dvalue_m. macc[5], macc[6] accumulate the two loss sums.
+__global__ void mirror_loss_kernel(const float* __restrict__ y, const float* __restrict__ ym, const float* __restrict__ v, const float* __restrict__ vm,
+                                   float sa, float sc, int R, float* __restrict__ dy, float* __restrict__ dym, float* __restrict__ dvalue,
+                                   float* __restrict__ dvalue_m, double* __restrict__ macc) {
+  int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  float ca = sa / (20.0f * R), la = 0;
+  for (int i = 0; i < KBJ_NU; ++i) {
+    int s = i < 5 ? i + 5 : (i < 10 ? i - 5 : i);
+    float e = y[(size_t)r * KBJ_NU + i] + ym[(size_t)r * KBJ_NU + s];     // y_i - (-y_m[s(i)])
+    la += e * e;
+    dy[(size_t)r * KBJ_NU + i] = 2 * ca * e;
+    dym[(size_t)r * KBJ_NU + s] = 2 * ca * e;
+  }
+  float ev = v[r] - vm[r];
+  float gv = 2 * sc / R * ev;
+  dvalue[r] += gv;
+  dvalue_m[r] = -gv;
+  atomicAdd(&macc[5], (double)(sa * la / 20.0f));
+  atomicAdd(&macc[6], (double)(sc * ev * ev));
+}
+
 // actor head backward: per (b, j) thread, reverse scan through the low-pass recursion.
-// dL/dlogp [T][B] and the constant entropy coefficient -> dOut [T][B][40]
+// dL/dlogp [T][B] and the constant entropy coefficient (+ an optional direct gradient on y) -> dOut [T][B][40]
 __global__ void actor_head_train_bwd_kernel(const float* __restrict__ out, const float* __restrict__ y, const float* __restrict__ sd,
                                             const float* __restrict__ act, const float* __restrict__ keep, const float* __restrict__ dlogp,
-                                            float dent, HeadParams hp, int T, int B, float* __restrict__ dout) {
+                                            const float* __restrict__ dy_extra, float dent, HeadParams hp, int T, int B, float* __restrict__ dout) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * KBJ_NU) return;
   int b = i / KBJ_NU, j = i % KBJ_NU;
@@ -244,7 +291,7 @@ __global__ void actor_head_train_bwd_kernel(const float* __restrict__ out, const
     size_t r = (size_t)t * B + b;
     float s = sd[r * KBJ_NU + j], z = (act[r * KBJ_NU + j] - y[r * KBJ_NU + j]) / s;
     float gl = dlogp[r];
-    float gy = gl * (z / s) + keep[r] * gcarry;
+    float gy = gl * (z / s) + (dy_extra ? dy_extra[r * KBJ_NU + j] : 0.0f) + keep[r] * gcarry;
     dout[r * 40 + j] = hp.alpha * gy;
     gcarry = (1 - hp.alpha) * gy;
     float gs = gl * ((z * z - 1.0f) / s) + dent / s;

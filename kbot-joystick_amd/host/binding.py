@@ -21,14 +21,17 @@ class KbjError(RuntimeError):
 
 
 class Carry(C.Structure):
-    _fields_ = [("actor_hc_d", C.c_void_p), ("critic_hc_d", C.c_void_p), ("lpf_d", C.c_void_p)]
+    _fields_ = [("actor_hc_d", C.c_void_p), ("critic_hc_d", C.c_void_p), ("lpf_d", C.c_void_p),
+                ("actor_mirror_hc_d", C.c_void_p), ("critic_mirror_hc_d", C.c_void_p), ("lpf_mirror_d", C.c_void_p)]
 
 
 class Traj(C.Structure):
     _fields_ = [("T", C.c_int32), ("N", C.c_int32),
                 ("actor_obs_d", C.c_void_p), ("critic_obs_d", C.c_void_p), ("aux_d", C.c_void_p),
                 ("action_d", C.c_void_p), ("logp_d", C.c_void_p), ("value_d", C.c_void_p), ("reward_d", C.c_void_p),
-                ("carry0_actor_hc_d", C.c_void_p), ("carry0_critic_hc_d", C.c_void_p), ("carry0_lpf_d", C.c_void_p)]
+                ("carry0_actor_hc_d", C.c_void_p), ("carry0_critic_hc_d", C.c_void_p), ("carry0_lpf_d", C.c_void_p),
+                ("carry0_actor_mirror_hc_d", C.c_void_p), ("carry0_critic_mirror_hc_d", C.c_void_p),
+                ("carry0_lpf_mirror_d", C.c_void_p)]
 
 
 _vp, _i, _u32, _f, _sz = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t

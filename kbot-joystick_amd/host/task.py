@@ -63,9 +63,6 @@ class HumanoidWalkingTaskConfig:
     def to_kbj(self, num_envs_local: int, env_id_offset: int = 0) -> L.Config:
         if self.batch_size <= 0 or num_envs_local % self.batch_size != 0:
             raise ValueError(f"batch_size {self.batch_size} must divide the per-GPU num_envs {num_envs_local}")
-        if self.actor_mirror_loss_scale != 0.0 or self.critic_mirror_loss_scale != 0.0:
-            raise NotImplementedError("mirror aux losses (train.py:1463-1481) are not built yet; the launch config sets both "
-                                      "scales to 0.0 (train.py:1771-1772)")
         if self.use_lr_decay and self.adam_weight_decay == 0.0:
             # train.py:1074-1075 chains scale_by_adam with scale_by_schedule and no sign flip (gradient ascent as written)
             raise NotImplementedError("use_lr_decay with adam_weight_decay == 0 is not supported")
@@ -76,6 +73,7 @@ class HumanoidWalkingTaskConfig:
                   latency_lo=self.action_latency_range[0], latency_hi=self.action_latency_range[1],
                   drop_action_prob=self.drop_action_prob, var_scale=self.var_scale, entropy_coef=self.entropy_coef, gamma=self.gamma,
                   lam=self.lam, learning_rate=self.learning_rate, weight_decay=self.adam_weight_decay, switch_prob=self.ctrl_dt / 5,
+                  actor_mirror_loss_scale=self.actor_mirror_loss_scale, critic_mirror_loss_scale=self.critic_mirror_loss_scale,
                   lpf_alpha=self.ctrl_dt / (self.ctrl_dt + 1.0 / (2.0 * math.pi * self.cutoff_frequency)))
         if self.fixed_command is not None:
             cmd = list(self.fixed_command) + [0.0] * (L.NCMD - len(self.fixed_command))
@@ -123,9 +121,10 @@ class HumanoidWalkingTask:
         self.opt_m = torch.zeros_like(self.params)
         self.opt_v = torch.zeros_like(self.params)
         self.grad = torch.zeros_like(self.params)
-        self.metrics = torch.zeros(8, device=self.device)
+        self.metrics = torch.zeros(10, device=self.device)
+        self.mirror = config.actor_mirror_loss_scale != 0.0 or config.critic_mirror_loss_scale != 0.0
         self.carry = self.get_initial_model_carry()
-        self.traj = TrajBuffers(self.T, self.N, self.H, self.kcfg.depth, self.device)
+        self.traj = TrajBuffers(self.T, self.N, self.H, self.kcfg.depth, self.device, mirror=self.mirror)
         self.opt_step = 0
         self.iteration = 0
         self._perm_gen = torch.Generator(device="cpu")
@@ -144,7 +143,7 @@ class HumanoidWalkingTask:
 
     def get_initial_model_carry(self) -> CarryBuffers:
         """train.py:1526-1543: zero LSTM carries and low-pass filter state."""
-        return CarryBuffers(self.N, self.H, self.kcfg.depth, self.device)
+        return CarryBuffers(self.N, self.H, self.kcfg.depth, self.device, mirror=self.mirror)
 
     def sample_action(self, actor_obs, critic_obs, step_index: int, argmax: bool = False):
         """train.py:1545-1572 for all envs at one control step; returns (action, log_prob, value)."""
@@ -185,10 +184,14 @@ class HumanoidWalkingTask:
     def save_checkpoint(self, path: str):
         import numpy as np
         ep, es = self.ctx.env_get_state()
+        extra = {}
+        if self.mirror:
+            extra = dict(actor_mirror_hc=self.carry.actor_mirror_hc.cpu().numpy(), critic_mirror_hc=self.carry.critic_mirror_hc.cpu().numpy(),
+                         lpf_mirror=self.carry.lpf_mirror.cpu().numpy())
         np.savez(path, params=self.params.cpu().numpy(), opt_m=self.opt_m.cpu().numpy(), opt_v=self.opt_v.cpu().numpy(),
                  opt_step=self.opt_step, iteration=self.iteration, ep=ep, es=es, actor_hc=self.carry.actor_hc.cpu().numpy(),
                  critic_hc=self.carry.critic_hc.cpu().numpy(), lpf=self.carry.lpf.cpu().numpy(),
-                 config=str(dataclasses.asdict(self.config)))
+                 config=str(dataclasses.asdict(self.config)), **extra)
 
     def load_checkpoint(self, path: str):
         import numpy as np
@@ -201,6 +204,10 @@ class HumanoidWalkingTask:
         self.ctx.env_set_state(z["ep"], z["es"])
         self.carry.actor_hc.copy_(torch.from_numpy(z["actor_hc"])); self.carry.critic_hc.copy_(torch.from_numpy(z["critic_hc"]))
         self.carry.lpf.copy_(torch.from_numpy(z["lpf"]))
+        if self.mirror:
+            self.carry.actor_mirror_hc.copy_(torch.from_numpy(z["actor_mirror_hc"]))
+            self.carry.critic_mirror_hc.copy_(torch.from_numpy(z["critic_mirror_hc"]))
+            self.carry.lpf_mirror.copy_(torch.from_numpy(z["lpf_mirror"]))
 
     @classmethod
     def launch(cls, config: HumanoidWalkingTaskConfig, num_iterations: int = 10, log_every: int = 1):

@@ -67,7 +67,7 @@ class Config(C.Structure):
         ("gamma", f32), ("lam", f32), ("clip_param", f32), ("value_loss_coef", f32), ("entropy_coef", f32),
         ("log_ratio_clip", f32), ("max_grad_norm", f32),
         ("learning_rate", f32), ("adam_b1", f32), ("adam_b2", f32), ("adam_eps", f32), ("weight_decay", f32),
-        ("adv_eps", f32), ("value_clip", f32), ("reserved_f", f32 * 8),
+        ("adv_eps", f32), ("value_clip", f32), ("actor_mirror_loss_scale", f32), ("critic_mirror_loss_scale", f32), ("reserved_f", f32 * 6),
     ]
 
 

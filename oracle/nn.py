@@ -152,3 +152,95 @@ def adamw_step(cfg, p, m, v, g, step, grad_scale=1.0):
     vh = v / (1 - cfg.adam_b2 ** step)
     p.sub_(cfg.learning_rate * (mh / (torch.sqrt(vh) + cfg.adam_eps) + cfg.weight_decay * p))
     return norm
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# mirror aux losses (train.py:1463-1481, 1574-1756): the packed observation vectors are unpacked to the raw pieces the
+# reference mirrors, mirrored exactly as train.py does, and packed again (train.py:1329-1433)
+# ---------------------------------------------------------------------------------------------------------------------
+def mirror_joints(j):
+    """train.py:1574-1582 (legs swapped, arm blocks kept in place, everything negated)."""
+    return -torch.cat([j[..., 5:10], j[..., 0:5], j[..., 10:15], j[..., 15:20]], -1)
+
+
+def _joint_norm(model, dtype):
+    bias = torch.tensor(list(model.joint_bias), dtype=dtype)
+    lo = torch.tensor(list(model.joint_lo), dtype=dtype)
+    hi = torch.tensor(list(model.joint_hi), dtype=dtype)
+    return bias, torch.maximum(bias - lo, hi - bias)
+
+
+def _encode_pg(g):
+    roll = torch.atan2(g[..., 1], -g[..., 2])
+    pitch = torch.atan2(-g[..., 0], torch.sqrt(g[..., 1] ** 2 + g[..., 2] ** 2))
+    return torch.cat([roll[..., None], pitch[..., None], g / g.norm(dim=-1, keepdim=True)], -1)
+
+
+def _mirror_shared_block(x, model):
+    """The first 65 entries of both observation vectors (train.py:1367-1374 / 1410-1416)."""
+    bias, rng = _joint_norm(model, x.dtype)
+    q = x[..., 0:20] * rng + bias
+    v = x[..., 20:40] * 10.0
+    g = x[..., 42:45]
+    gyro = x[..., 45:48]
+    cmd = x[..., 49:65]
+    q_m, v_m = mirror_joints(q), mirror_joints(v)
+    g_m = torch.stack([g[..., 0], -g[..., 1], g[..., 2]], -1)                       # train.py:1596-1603, 1616-1623
+    gyro_m = torch.stack([-gyro[..., 0], gyro[..., 1], -gyro[..., 2]], -1)          # train.py:1588-1595, 1608-1615
+    arms = mirror_joints(torch.cat([torch.zeros_like(cmd[..., :10]), cmd[..., 6:16]], -1))[..., 10:20]
+    cmd_m = torch.cat([cmd[..., 0:1], -cmd[..., 1:2], -cmd[..., 2:3], cmd[..., 3:4], -cmd[..., 4:5], cmd[..., 5:6], arms], -1)  # :1737-1755
+    zc = (cmd_m[..., :3].norm(dim=-1, keepdim=True) < 1e-3).to(x.dtype)
+    return torch.cat([(q_m - bias) / rng, v_m / 10.0, _encode_pg(g_m), gyro_m, zc, cmd_m], -1)
+
+
+def mirror_actor_obs(x, model):
+    out = torch.zeros_like(x)
+    out[..., :NOBS_ACTOR] = _mirror_shared_block(x, model)
+    return out
+
+
+def mirror_critic_obs(x, model):
+    out = torch.zeros_like(x)
+    out[..., :65] = _mirror_shared_block(x, model)
+    out[..., 65], out[..., 66] = x[..., 66], x[..., 65]                              # touch L <-> R (train.py:1625-1626)
+    fp = x[..., 67:73]
+    out[..., 67:73] = torch.stack([fp[..., 3], -fp[..., 4], fp[..., 5], fp[..., 0], -fp[..., 1], fp[..., 2]], -1)  # :1627-1637
+    out[..., 73:76] = x[..., 73:76]                                                  # base position (train.py:1638)
+    bq = x[..., 76:80]
+    out[..., 76:80] = torch.stack([bq[..., 0], -bq[..., 1], -bq[..., 2], bq[..., 3]], -1)   # train.py:1639-1647
+    ci = x[..., 80:310].reshape(*x.shape[:-1], 23, 10)
+    sgn_ci = torch.tensor([1, 1, -1, 1, 1, 1, 1, -1, 1, -1], dtype=x.dtype)          # index pattern of train.py:1652-1665
+    out[..., 80:310] = (ci * sgn_ci).reshape(*x.shape[:-1], 230)
+    cv = x[..., 310:448].reshape(*x.shape[:-1], 23, 6)
+    sgn_cv = torch.tensor([1, -1, 1, -1, 1, -1], dtype=x.dtype)                      # train.py:1670-1689
+    out[..., 310:448] = (cv * sgn_cv).reshape(*x.shape[:-1], 138)
+    lv, av = x[..., 448:451], x[..., 451:454]
+    out[..., 448:451] = torch.stack([lv[..., 0], -lv[..., 1], lv[..., 2]], -1)       # train.py:1691-1698
+    out[..., 451:454] = torch.stack([-av[..., 0], av[..., 1], -av[..., 2]], -1)      # train.py:1699-1706
+    out[..., 454:474] = mirror_joints(x[..., 454:474])                               # actuator force / 4 (train.py:1708)
+    out[..., 474] = x[..., 474]                                                      # base height (train.py:1709)
+    return out
+
+
+def ppo_variables_mirror(p, cfg, model, joint_bias, actor_obs, critic_obs, actions, done, carry_a, carry_c, lpf, carry_am, carry_cm, lpf_m, depth=2):
+    """_ppo_scan_fn with the mirror branches (train.py:1435-1508): returns logp, value, entropy, the two aux-loss series and the carries."""
+    T = actor_obs.shape[0]
+    logps, values, ents, la, lc = [], [], [], [], []
+    for t in range(T):
+        out_a, carry_a = net_forward(p, "actor", actor_obs[t][..., :NOBS_ACTOR], carry_a, depth)
+        mean, std, lpf = actor_head(out_a, actor_obs[t], lpf, joint_bias, cfg)
+        logps.append(gaussian_logp(actions[t], mean, std)); ents.append(gaussian_entropy(std))
+        out_c, carry_c = net_forward(p, "critic", critic_obs[t][..., :NOBS_CRITIC], carry_c, depth)
+        values.append(out_c[..., 0])
+        ao_m, co_m = mirror_actor_obs(actor_obs[t], model), mirror_critic_obs(critic_obs[t], model)
+        out_am, carry_am = net_forward(p, "actor", ao_m[..., :NOBS_ACTOR], carry_am, depth)
+        mean_m, _, lpf_m = actor_head(out_am, ao_m, lpf_m, joint_bias, cfg)
+        la.append(((mean - mirror_joints(mean_m)) ** 2).mean(-1) * cfg.actor_mirror_loss_scale)       # train.py:1470-1473
+        out_cm, carry_cm = net_forward(p, "critic", co_m[..., :NOBS_CRITIC], carry_cm, depth)
+        lc.append((out_c[..., 0] - out_cm[..., 0]) ** 2 * cfg.critic_mirror_loss_scale)               # train.py:1481
+        keep = (done[t] == 0).to(mean.dtype)[:, None]
+        carry_a = [[h * keep, c * keep] for h, c in carry_a]; carry_c = [[h * keep, c * keep] for h, c in carry_c]
+        carry_am = [[h * keep, c * keep] for h, c in carry_am]; carry_cm = [[h * keep, c * keep] for h, c in carry_cm]
+        lpf, lpf_m = lpf * keep, lpf_m * keep
+    return (torch.stack(logps), torch.stack(values), torch.stack(ents), torch.stack(la), torch.stack(lc),
+            carry_a, carry_c, lpf, carry_am, carry_cm, lpf_m)

@@ -67,8 +67,10 @@ def test_bad_blob_rejected(lib):
 
 def test_task_config_guards():
     from kbot_joystick_amd.host.task import HumanoidWalkingTaskConfig, launch_config
-    with pytest.raises(NotImplementedError):
-        HumanoidWalkingTaskConfig().to_kbj(4096)          # dataclass defaults enable the mirror losses (train.py:115-122)
+    d = HumanoidWalkingTaskConfig().to_kbj(4096)          # dataclass defaults enable the mirror losses (train.py:115-122)
+    assert (d.actor_mirror_loss_scale, abs(d.critic_mirror_loss_scale - 0.01) < 1e-9) == (1.0, True)
+    z = launch_config().to_kbj(4096)                      # the launch block switches them off (train.py:1771-1772)
+    assert (z.actor_mirror_loss_scale, z.critic_mirror_loss_scale) == (0.0, 0.0)
     with pytest.raises(ValueError):
         launch_config(batch_size=500).to_kbj(4096)
     c = launch_config().to_kbj(4096)

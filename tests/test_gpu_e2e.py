@@ -74,3 +74,22 @@ def test_hip_env_matches_golden_rollout(model):
     ctx.synchronize()
     assert np.abs(rew.cpu().numpy() - ref["reward"]).max() < 2e-4
     ctx.close()
+
+
+def test_training_with_mirror_losses_runs():
+    """Dataclass-default mirror scales (train.py:115-122): rollout advances the mirror carries, update adds the aux losses."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
+    cfg = launch_config(num_envs=64, batch_size=32, hidden_size=64, rollout_length_seconds=0.2, robot="kbot-headless", seed=2, num_passes=1,
+                        actor_mirror_loss_scale=1.0, critic_mirror_loss_scale=0.01)
+    task = HumanoidWalkingTask(cfg)
+    p0 = task.params.clone()
+    for _ in range(2):
+        task.train_iteration()
+    torch.cuda.synchronize()
+    m = task.metrics.cpu()
+    assert torch.isfinite(m).all() and torch.isfinite(task.params).all()
+    assert float(m[8]) > 0 and float(m[9]) >= 0
+    assert float(task.carry.actor_mirror_hc.abs().max()) > 0 and float(task.traj.carry0_actor_mirror_hc.abs().max()) > 0
+    assert not torch.equal(p0, task.params)
+    task.ctx.close()

@@ -71,9 +71,9 @@ def test_policy_step_matches_oracle(H):
     ctx.close()
 
 
-def _synthetic_traj(torch, buffers, N, T, H, seed=0):
+def _synthetic_traj(torch, buffers, N, T, H, seed=0, mirror=False):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    tr = buffers.TrajBuffers(T, N, H, 2, "cuda:0")
+    tr = buffers.TrajBuffers(T, N, H, 2, "cuda:0", mirror=mirror)
     tr.actor_obs[:, :, :65] = (torch.randn(T + 1, N, 65, generator=g) * 0.5).cuda()
     tr.critic_obs[:, :, :475] = (torch.randn(T + 1, N, 475, generator=g) * 0.5).cuda()
     tr.action.copy_(torch.randn(T, N, 20, generator=g) * 0.3)
@@ -83,6 +83,10 @@ def _synthetic_traj(torch, buffers, N, T, H, seed=0):
     tr.carry0_actor_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
     tr.carry0_critic_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
     tr.carry0_lpf.copy_(torch.randn(N, 20, generator=g) * 0.2)
+    if mirror:
+        tr.carry0_actor_mirror_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
+        tr.carry0_critic_mirror_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
+        tr.carry0_lpf_mirror.copy_(torch.randn(N, 20, generator=g) * 0.2)
     return tr
 
 
@@ -111,7 +115,7 @@ def test_ppo_grad_matches_autograd(H, N, B, T):
     ctx.synchronize()
     adv_o, tgt_o = ON.gae(tr.value.cpu().double(), tr.reward.cpu().double(), done, cfg.gamma, cfg.lam)
     assert (tr.adv.cpu().double() - adv_o).abs().max() < 1e-5 and (tr.target.cpu().double() - tgt_o).abs().max() < 1e-5
-    grad, metrics = torch.zeros(P, device="cuda:0"), torch.zeros(8, device="cuda:0")
+    grad, metrics = torch.zeros(P, device="cuda:0"), torch.zeros(10, device="cuda:0")
     ctx.ppo_grad(params, tr.c, idx.cuda(), B, tr.adv, tr.target, grad, metrics)
     ctx.synchronize()
     # oracle: autograd through the minibatch
@@ -145,4 +149,109 @@ def test_ppo_grad_matches_autograd(H, N, B, T):
         ON.adamw_step(cfg, p_o, m_o, v_o, gg.clone(), step, 0.5)
     ctx.synchronize()
     assert (params.cpu().double() - p_o).abs().max() < 1e-6
+    ctx.close()
+
+
+def _make_obs_consistent(torch, tr):
+    """The mirror of roll/pitch/zero-command is re-derived from the projected gravity / command by the reference
+    (train.py:1596-1623); give the synthetic rows the same internal consistency the env's rows have."""
+    from oracle import nn as ON
+    for obs in (tr.actor_obs, tr.critic_obs):
+        g = obs[..., 42:45].cpu().double()
+        g = g / g.norm(dim=-1, keepdim=True)
+        obs[..., 40:45] = ON._encode_pg(g).float().cuda()
+        obs[..., 48] = (obs[..., 49:52].norm(dim=-1) < 1e-3).float()
+
+
+def test_mirror_obs_and_carries_match_oracle():
+    """kbj_policy_step with the mirror losses on: the mirror-branch carries advance on mirrored observations."""
+    N, H = 64, 64
+    m, cfg, ctx, torch, buffers = _setup(N, 32, 4, H, actor_mirror_loss_scale=1.0, critic_mirror_loss_scale=0.01)
+    from oracle import nn as ON
+    params = torch.zeros(ctx.param_count(), device="cuda:0")
+    ctx.init_params(3, params)
+    tr = _synthetic_traj(torch, buffers, N, 1, H, seed=4, mirror=True)
+    _make_obs_consistent(torch, tr)
+    carry = buffers.CarryBuffers(N, H, 2, "cuda:0", mirror=True)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    carry.actor_mirror_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.5)
+    carry.critic_mirror_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.5)
+    carry.lpf_mirror.copy_(torch.randn(N, 20, generator=g) * 0.3)
+    am0, cm0, lm0 = carry.actor_mirror_hc.cpu().double(), carry.critic_mirror_hc.cpu().double(), carry.lpf_mirror.cpu().double()
+    action, logp, value = torch.zeros(N, 20, device="cuda:0"), torch.zeros(N, device="cuda:0"), torch.zeros(N, device="cuda:0")
+    ctx.policy_step(params, tr.actor_obs[0], tr.critic_obs[0], carry.c, 7, 0, True, action, logp, value)
+    ctx.synchronize()
+    p = ON.unflatten(params.cpu().double(), H)
+    jb = torch.tensor(list(m.joint_bias), dtype=torch.float64)
+    ao_m = ON.mirror_actor_obs(tr.actor_obs[0].cpu().double(), m)
+    co_m = ON.mirror_critic_obs(tr.critic_obs[0].cpu().double(), m)
+    out_am, cam = ON.net_forward(p, "actor", ao_m[:, :65], [[am0[l, 0], am0[l, 1]] for l in range(2)])
+    _, _, lpf_m1 = ON.actor_head(out_am, ao_m, lm0, jb, cfg)
+    _, ccm = ON.net_forward(p, "critic", co_m[:, :475], [[cm0[l, 0], cm0[l, 1]] for l in range(2)])
+    for l in range(2):
+        for k in range(2):
+            assert (carry.actor_mirror_hc[l, k].cpu().double() - cam[l][k]).abs().max() < 1e-5
+            assert (carry.critic_mirror_hc[l, k].cpu().double() - ccm[l][k]).abs().max() < 1e-5
+    assert (carry.lpf_mirror.cpu().double() - lpf_m1).abs().max() < 1e-5
+    # carry reset clears the mirror branches too
+    done = torch.zeros(N, device="cuda:0"); done[::2] = 1.0
+    ctx.carry_reset(carry.c, done, 1)
+    ctx.synchronize()
+    assert float(carry.actor_mirror_hc[:, :, ::2].abs().max()) == 0 and float(carry.lpf_mirror[::2].abs().max()) == 0
+    assert float(carry.critic_mirror_hc[:, :, 1::2].abs().max()) > 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (256, 40, 32, 5)])
+def test_ppo_grad_with_mirror_losses_matches_autograd(H, N, B, T):
+    """Row a10: action/value mirror aux losses (train.py:1463-1481) in loss, metrics and gradient."""
+    m, cfg, ctx, torch, buffers = _setup(N, B, T, H, actor_mirror_loss_scale=1.0, critic_mirror_loss_scale=0.25)
+    from oracle import nn as ON
+    P = ctx.param_count()
+    params = torch.zeros(P, device="cuda:0")
+    ctx.init_params(11, params)
+    tr = _synthetic_traj(torch, buffers, N, T, H, mirror=True)
+    _make_obs_consistent(torch, tr)
+    jb = torch.tensor(list(m.joint_bias), dtype=torch.float64)
+    p64 = params.detach().cpu().double()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    idx = torch.randperm(N, generator=g)[:B].int()
+    ii = idx.long()
+    ao, co = tr.actor_obs[:T].cpu().double(), tr.critic_obs[:T].cpu().double()
+    act, done = tr.action.cpu().double(), tr.done.cpu().double()
+    carry = lambda t: [[t[l, k].cpu().double()[ii] for k in range(2)] for l in range(2)]
+
+    def variables(pd):
+        return ON.ppo_variables_mirror(pd, cfg, m, jb, ao[:, ii], co[:, ii], act[:, ii], done[:, ii], carry(tr.carry0_actor_hc), carry(tr.carry0_critic_hc),
+                                       tr.carry0_lpf.cpu().double()[ii], carry(tr.carry0_actor_mirror_hc), carry(tr.carry0_critic_mirror_hc),
+                                       tr.carry0_lpf_mirror.cpu().double()[ii])
+    with torch.no_grad():
+        lp, v, *_ = variables(ON.unflatten(p64, H))
+    lp_old = torch.zeros(T, N, dtype=torch.float64); v_old = torch.zeros(T, N, dtype=torch.float64)
+    lp_old[:, ii] = lp + 0.3 * torch.randn(T, B, generator=g).double()
+    v_old[:, ii] = v + 0.3 * torch.randn(T, B, generator=g).double()
+    tr.logp.copy_(lp_old.float()); tr.value.copy_(v_old.float())
+    ctx.gae(tr.c, tr.adv, tr.target)
+    grad, metrics = torch.zeros(P, device="cuda:0"), torch.zeros(10, device="cuda:0")
+    ctx.ppo_grad(params, tr.c, idx.cuda(), B, tr.adv, tr.target, grad, metrics)
+    ctx.synchronize()
+    adv_o, tgt_o = ON.gae(tr.value.cpu().double(), tr.reward.cpu().double(), done, cfg.gamma, cfg.lam)
+    pf = p64.clone().requires_grad_(True)
+    lp, v, en, la, lc, *_ = variables(ON.unflatten(pf, H))
+    loss, mt = ON.ppo_loss(cfg, lp, v, en, tr.logp.cpu().double()[:, ii], tr.value.cpu().double()[:, ii], adv_o[:, ii], tgt_o[:, ii])
+    total = loss + la.mean() + lc.mean()
+    total.backward()
+    go, gg, mg = pf.grad, grad.cpu().double(), metrics.cpu().double()
+    assert float(la.mean()) > 1e-4 and float(lc.mean()) > 1e-6                 # the aux terms are live
+    assert abs(mg[8] - float(la.mean())) < 2e-4 * (1 + float(la.mean()))
+    assert abs(mg[9] - float(lc.mean())) < 2e-4 * (1 + float(lc.mean()))
+    assert abs(mg[0] - float(total)) < 2e-4 * (1 + abs(float(total)))
+    off = 0
+    for name, shp in ON.param_shapes(H):
+        n = int(np.prod(shp))
+        a, b = gg[off:off + n], go[off:off + n]
+        err = (a - b).abs().max() / (b.abs().max() + 1e-12)
+        assert err < 2e-3, (name, float(err), float(b.abs().max()))
+        off += n
+    assert (gg - go).norm() / go.norm() < 1e-4
     ctx.close()

@@ -12,7 +12,7 @@ P = ctx.param_count(); params = torch.zeros(P, device="cuda"); ctx.init_params(1
 tr = buffers.TrajBuffers(T, N, H, 2, "cuda")
 tr.actor_obs.normal_(); tr.critic_obs.normal_(); tr.action.normal_(); tr.logp.normal_(); tr.value.normal_(); tr.reward.uniform_()
 ctx.gae(tr.c, tr.adv, tr.target)
-grad, met = torch.zeros(P, device="cuda"), torch.zeros(8, device="cuda")
+grad, met = torch.zeros(P, device="cuda"), torch.zeros(10, device="cuda")
 idx = torch.randperm(N)[:Bs].int().cuda()
 for _ in range(2): ctx.ppo_grad(params, tr.c, idx, Bs, tr.adv, tr.target, grad, met)
 ctx.synchronize()
