@@ -62,6 +62,16 @@ def cpu_baseline(seconds_budget: float = 25.0):
                 sample=f"oracle full iteration on {n_envs} envs x 100 steps, batch {n_envs}, 3 passes, hidden 256 ({dt:.1f} s wall)")
 
 
+def pmc_traffic() -> dict:
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
+    tools/rocprof_summary.py --pmc with the gfx950 FETCH_SIZE correction); {} when no PMC profile is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return {k: v.get("hbm_bytes_per_launch") for k, v in json.load(f).items()}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,16 +136,25 @@ def main():
         steps_gpu = args.envs_per_gpu * task.T
         flops = nn_flops_per_envstep(args.hidden, cfg.num_passes) * steps_gpu
         ach_tf = flops / nn_s / 1e12
-        nn_roof = dict(bound="mfma", kernel="gemm_f32_kernel (fp32 MFMA GEMMs inside kbj_policy_step + kbj_ppo_grad)", achieved=round(ach_tf, 3),
+        nn_roof = dict(bound="mfma", kernel="all fp32-MFMA kernels of kbj_policy_step + kbj_ppo_grad (whole NN path)", achieved=round(ach_tf, 3),
                        peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach_tf / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
                        time_ms_per_iteration=round(prof["nn_ms"], 2), sections=prof["nn_launches"])
         per_launch = env_s / max(prof["env_step_launches"], 1)
         ach_gbs = args.envs_per_gpu * ENV_BYTES_PER_ENVSTEP / per_launch / 1e9
+        traffic = pmc_traffic()
         env_roof = dict(bound="hbm", kernel="env_step_kernel", achieved=round(ach_gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s",
-                        frac=round(ach_gbs / PEAK_HBM_GBS, 5), traffic=None, avg_launch_ms=round(per_launch * 1e3, 4),
-                        launches=prof["env_step_launches"], time_ms_per_iteration=round(prof["env_step_ms"], 2),
+                        frac=round(ach_gbs / PEAK_HBM_GBS, 5), traffic=traffic.get("env_step_kernel"), avg_launch_us=round(per_launch * 1e6, 1),
+                        launches=prof["env_step_launches"], total_ms=round(prof["env_step_ms"], 2),
                         note="latency/issue-bound per-env solver; HBM is not the limiter (DESIGN.md)")
-        roofline, roofline2 = (nn_roof, env_roof) if nn_s >= env_s else (env_roof, nn_roof)
+        kernels = [env_roof]
+        for k in prof["kernels"]:      # every launch bracketed by HIP events on its own stream inside libkbj.so
+            tf = k["flops"] / (k["total_ms"] * 1e-3) / 1e12
+            kernels.append(dict(bound="mfma", kernel=k["name"], achieved=round(tf, 3), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                                frac=round(tf / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic.get(k["name"]),
+                                avg_launch_us=round(k["total_ms"] * 1e3 / k["launches"], 1), launches=k["launches"], total_ms=round(k["total_ms"], 2)))
+        kernels.sort(key=lambda r: -r["total_ms"])
+        roofline = kernels[0]          # the dominant kernel by summed launch time
+        roofline2 = dict(path=nn_roof, kernels=kernels[1:])
 
     if world > 1:
         dist.barrier()

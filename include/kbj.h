@@ -136,6 +136,15 @@ int kbj_set_learning_rate(kbj_ctx* ctx, float learning_rate);
 /* per-launch timing of the dominant kernels, measured with HIP events on the context's stream (bench.py roofline) */
 int kbj_profile_begin(kbj_ctx* ctx);
 int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, float* nn_ms, int* nn_launches);
+/* per-kernel totals of the matrix-core kernels launched between kbj_profile_begin and kbj_profile_end: every launch is
+ * bracketed by two HIP events on the stream it is launched on; flops = algorithmic 2*M*N*K of those launches */
+typedef struct kbj_kernel_stat {
+  char name[96];     /* kernel name as rocprofv3 prints it */
+  int32_t launches;
+  float total_ms;    /* sum of the launch durations */
+  double flops;
+} kbj_kernel_stat;
+int kbj_profile_kernel_stats(kbj_ctx* ctx, kbj_kernel_stat* out, int capacity, int* count);
 
 #ifdef __cplusplus
 }

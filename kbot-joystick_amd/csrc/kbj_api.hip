@@ -4,6 +4,7 @@
 #include "kbj_ctx.h"
 
 thread_local std::string kbj_global_error;
+thread_local kbj_ctx* kbj_prof_ctx = nullptr;
 
 namespace {
 
@@ -119,15 +120,44 @@ int kbj_synchronize(kbj_ctx* ctx) {
 int kbj_profile_begin(kbj_ctx* ctx) {
   if (!ctx) return kbj_fail(nullptr, "kbj_profile_begin: null ctx");
   ctx->profiling = true; ctx->env_ms = ctx->nn_ms = 0; ctx->env_launches = ctx->nn_launches = 0;
+  ctx->krecs.clear();
+  kbj_prof_ctx = ctx;
   return 0;
 }
 int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, float* nn_ms, int* nn_launches) {
   if (!ctx) return kbj_fail(nullptr, "kbj_profile_end: null ctx");
   ctx->profiling = false;
+  kbj_prof_ctx = nullptr;
+  KBJ_HIP(ctx, hipDeviceSynchronize());
+  static const char* const names[KBJ_KIND_COUNT] = {
+      "kbj::gemm_f32_kernel<2, 2, false, false>", "kbj::gemm_f32_kernel<2, 2, false, true>", "kbj::gemm_f32_kernel<2, 2, true, false>",
+      "kbj::gemm_f32_kernel<2, 2, true, true>",   "kbj::gemm_f32_kernel<1, 1, false, false>", "kbj::gemm_f32_kernel<1, 1, false, true>",
+      "kbj::gemm_f32_kernel<1, 1, true, false>",  "kbj::gemm_f32_kernel<1, 1, true, true>",   "kbj::lstm_seq_fwd_kernel", "kbj::lstm_seq_bwd_kernel"};
+  for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
+    kbj_kernel_stat& st = ctx->kstats[k];
+    if (k >= KBJ_KIND_SEQ_FWD) snprintf(st.name, sizeof(st.name), "%s<%d>", names[k], ctx->cfg_h.hidden_size);
+    else snprintf(st.name, sizeof(st.name), "%s", names[k]);
+    st.launches = 0; st.total_ms = 0; st.flops = 0;
+  }
+  for (KbjKernelRec& r : ctx->krecs) {
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { kbj_kernel_stat& st = ctx->kstats[r.kind]; st.launches++; st.total_ms += ms; st.flops += r.flops; }
+    hipEventDestroy(r.a); hipEventDestroy(r.b);
+  }
+  ctx->krecs.clear();
   if (env_step_ms) *env_step_ms = ctx->env_ms;
   if (env_step_launches) *env_step_launches = ctx->env_launches;
   if (nn_ms) *nn_ms = ctx->nn_ms;
   if (nn_launches) *nn_launches = ctx->nn_launches;
+  return 0;
+}
+
+int kbj_profile_kernel_stats(kbj_ctx* ctx, kbj_kernel_stat* out, int capacity, int* count) {
+  if (!ctx || !out || !count) return kbj_fail(ctx, "kbj_profile_kernel_stats: null argument");
+  int n = 0;
+  for (int k = 0; k < KBJ_KIND_COUNT && n < capacity; ++k)
+    if (ctx->kstats[k].launches > 0) out[n++] = ctx->kstats[k];
+  *count = n;
   return 0;
 }
 

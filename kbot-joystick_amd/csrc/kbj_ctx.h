@@ -2,8 +2,13 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <string>
+#include <vector>
 #include <cstdio>
 #include "kbj.h"
+
+// per-launch HIP-event records of the MFMA kernels while kbj_profile_begin/end is active (bench.py roofline)
+struct KbjKernelRec { int kind; double flops; hipEvent_t a, b; };
+enum { KBJ_KIND_GEMM = 0 /* +4 small tile, +2 A k-contiguous, +1 B k-contiguous */, KBJ_KIND_SEQ_FWD = 8, KBJ_KIND_SEQ_BWD = 9, KBJ_KIND_COUNT = 10 };
 
 struct kbj_ctx {
   int device = 0;
@@ -28,6 +33,8 @@ struct kbj_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   float env_ms = 0, nn_ms = 0;
   int env_launches = 0, nn_launches = 0;
+  std::vector<KbjKernelRec> krecs;
+  kbj_kernel_stat kstats[KBJ_KIND_COUNT];
   std::string error;
 };
 
@@ -50,6 +57,22 @@ inline int kbj_fail(kbj_ctx* ctx, const std::string& msg) {
     hipError_t e_ = hipGetLastError();                                                                       \
     if (e_ != hipSuccess) return kbj_fail(ctx, std::string("launch ") + name + ": " + hipGetErrorString(e_)); \
   } while (0)
+
+// the context being profiled on this host thread (nullptr outside kbj_profile_begin/end)
+extern thread_local kbj_ctx* kbj_prof_ctx;
+
+// brackets ONE kernel launch on stream s with two timing events
+struct KbjKernelTimer {
+  kbj_ctx* c; hipStream_t s; hipEvent_t b = nullptr;
+  KbjKernelTimer(hipStream_t st, int kind, double flops) : c(kbj_prof_ctx), s(st) {
+    if (!c) return;
+    hipEvent_t a;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { c = nullptr; return; }
+    c->krecs.push_back(KbjKernelRec{kind, flops, a, b});
+    hipEventRecord(a, s);
+  }
+  ~KbjKernelTimer() { if (c) hipEventRecord(b, s); }
+};
 
 // timed section helpers for bench.py's roofline (HIP events on the context's stream)
 struct KbjTimed {

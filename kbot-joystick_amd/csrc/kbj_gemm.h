@@ -12,6 +12,7 @@
 // matrix pipe).
 #pragma once
 #include <hip/hip_runtime.h>
+#include "kbj_ctx.h"
 
 namespace kbj {
 
@@ -176,6 +177,7 @@ inline void gemm_launch(hipStream_t s, const GemmArgs& g, int force_big = -1) {
   int sk = g.splitk > 1 ? g.splitk : 1;
   long big_blocks = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * sk;
   bool big = force_big >= 0 ? force_big != 0 : big_blocks >= 192;
+  KbjKernelTimer timer(s, KBJ_KIND_GEMM + (big ? 0 : 4) + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);
   if (big) {
     dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, sk);
     hipLaunchKernelGGL((gemm_f32_kernel<2, 2, A_KC, B_KC>), grid, dim3(256), 0, s, g);

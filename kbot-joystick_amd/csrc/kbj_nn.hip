@@ -151,6 +151,7 @@ template <int H> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a) {
 }
 int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {
   hipMemsetAsync(a.counters, 0, 256 * sizeof(unsigned), st);
+  KbjKernelTimer timer(st, KBJ_KIND_SEQ_FWD, 2.0 * a.T * a.B * 4.0 * H * H);
   switch (H) {
     case 64: seq_fwd_launch<64>(st, a); break;
     case 128: seq_fwd_launch<128>(st, a); break;
@@ -161,6 +162,7 @@ int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {
 }
 int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {
   hipMemsetAsync(a.counters, 0, 256 * sizeof(unsigned), st);
+  KbjKernelTimer timer(st, KBJ_KIND_SEQ_BWD, 2.0 * a.T * a.B * 4.0 * H * H);
   switch (H) {
     case 64: seq_bwd_launch<64>(st, a); break;
     case 128: seq_bwd_launch<128>(st, a); break;

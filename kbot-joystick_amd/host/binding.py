@@ -34,6 +34,10 @@ class Traj(C.Structure):
                 ("carry0_lpf_mirror_d", C.c_void_p)]
 
 
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int32), ("total_ms", C.c_float), ("flops", C.c_double)]
+
+
 _vp, _i, _u32, _f, _sz = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t
 _cfgp = C.POINTER(L.Config)
 
@@ -62,6 +66,7 @@ SIGNATURES = {
     "kbj_set_learning_rate": (_i, [_vp, _f]),
     "kbj_profile_begin": (_i, [_vp]),
     "kbj_profile_end": (_i, [_vp, C.POINTER(_f), C.POINTER(_i), C.POINTER(_f), C.POINTER(_i)]),
+    "kbj_profile_kernel_stats": (_i, [_vp, C.POINTER(KernelStat), _i, C.POINTER(_i)]),
 }
 
 
@@ -199,4 +204,7 @@ class Context:
     def profile_end(self):
         a, b, c, d = _f(), _i(), _f(), _i()
         self.call("kbj_profile_end", C.byref(a), C.byref(b), C.byref(c), C.byref(d))
-        return dict(env_step_ms=a.value, env_step_launches=b.value, nn_ms=c.value, nn_launches=d.value)
+        arr, n = (KernelStat * 16)(), _i()
+        self.call("kbj_profile_kernel_stats", arr, 16, C.byref(n))
+        kernels = [dict(name=arr[k].name.decode(), launches=arr[k].launches, total_ms=arr[k].total_ms, flops=arr[k].flops) for k in range(n.value)]
+        return dict(env_step_ms=a.value, env_step_launches=b.value, nn_ms=c.value, nn_launches=d.value, kernels=kernels)
