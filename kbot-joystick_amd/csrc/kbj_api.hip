@@ -132,10 +132,10 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
   static const char* const names[KBJ_KIND_COUNT] = {
       "kbj::gemm_f32_kernel<2, 2, false, false>", "kbj::gemm_f32_kernel<2, 2, false, true>", "kbj::gemm_f32_kernel<2, 2, true, false>",
       "kbj::gemm_f32_kernel<2, 2, true, true>",   "kbj::gemm_f32_kernel<1, 1, false, false>", "kbj::gemm_f32_kernel<1, 1, false, true>",
-      "kbj::gemm_f32_kernel<1, 1, true, false>",  "kbj::gemm_f32_kernel<1, 1, true, true>",   "kbj::lstm_seq_fwd_kernel", "kbj::lstm_seq_bwd_kernel"};
+      "kbj::gemm_f32_kernel<1, 1, true, false>",  "kbj::gemm_f32_kernel<1, 1, true, true>",   "kbj::lstm_seq_fwd_kernel", "kbj::lstm_seq_bwd_kernel", "env_step_kernel"};
   for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
     kbj_kernel_stat& st = ctx->kstats[k];
-    if (k >= KBJ_KIND_SEQ_FWD) snprintf(st.name, sizeof(st.name), "%s<%d>", names[k], ctx->cfg_h.hidden_size);
+    if (k == KBJ_KIND_SEQ_FWD || k == KBJ_KIND_SEQ_BWD) snprintf(st.name, sizeof(st.name), "%s<%d>", names[k], ctx->cfg_h.hidden_size);
     else snprintf(st.name, sizeof(st.name), "%s", names[k]);
     st.launches = 0; st.total_ms = 0; st.flops = 0;
   }
@@ -145,6 +145,8 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
     hipEventDestroy(r.a); hipEventDestroy(r.b);
   }
   ctx->krecs.clear();
+  ctx->env_ms = ctx->kstats[KBJ_KIND_ENV_STEP].total_ms;
+  ctx->env_launches = ctx->kstats[KBJ_KIND_ENV_STEP].launches;
   if (env_step_ms) *env_step_ms = ctx->env_ms;
   if (env_step_launches) *env_step_launches = ctx->env_launches;
   if (nn_ms) *nn_ms = ctx->nn_ms;

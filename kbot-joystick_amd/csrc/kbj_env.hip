@@ -37,9 +37,9 @@ __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restri
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR))) void env_step_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, uint32_t seed,
                                                       float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ action,
-                                                      float* aux_t, float* actor_next, float* critic_next, float* aux_next) {
+                                                      float* aux_t, float* actor_next, float* critic_next, float* aux_next, int env0) {
   __shared__ KbjShared S;
-  const int env = blockIdx.x;
+  const int env = env0 + blockIdx.x;   // a launch covers the env range [env0, env0 + gridDim.x)
   PFOR(k, KBJ_EP_SIZE) S.ep[k] = ep[(size_t)env * KBJ_EP_SIZE + k];
   PFOR(k, KBJ_ES_SIZE) S.es[k] = es[(size_t)env * KBJ_ES_SIZE + k];
   KBJ_SYNC();
@@ -164,6 +164,16 @@ __global__ void init_reward_carry_kernel(float* carry, int N) {
 
 }  // namespace
 
+// one control step of the envs [env0, env0 + count) on stream s; row pointers are those of env 0 (kbj_rollout pipelines two halves)
+int kbj_env_step_range(kbj_ctx* ctx, hipStream_t s, int env0, int count, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d,
+                       float* aux_next_d) {
+  KbjKernelTimer timer(s, KBJ_KIND_ENV_STEP, 0.0);
+  hipLaunchKernelGGL(env_step_kernel, dim3(count), dim3(64), 0, s, ctx->model_d, ctx->cfg_d, ctx->seed, ctx->ep_d, ctx->es_d, action_d, aux_t_d, actor_next_d,
+                     critic_next_d, aux_next_d, env0);
+  KBJ_CHECK_LAUNCH(ctx, "env_step_kernel");
+  return 0;
+}
+
 extern "C" {
 
 int kbj_env_reset_all(kbj_ctx* ctx, uint32_t seed, float* actor0_d, float* critic0_d, float* aux0_d) {
@@ -183,12 +193,7 @@ int kbj_env_reset_all(kbj_ctx* ctx, uint32_t seed, float* actor0_d, float* criti
 int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {
   if (!ctx) return kbj_fail(nullptr, "kbj_env_step: null ctx");
   if (!action_d || !aux_t_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_step: null pointer");
-  int N = ctx->cfg_h.num_envs;
-  KbjTimed timed(ctx, false);
-  hipLaunchKernelGGL(env_step_kernel, dim3(N), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->seed, ctx->ep_d, ctx->es_d, action_d,
-                     aux_t_d, actor_next_d, critic_next_d, aux_next_d);
-  KBJ_CHECK_LAUNCH(ctx, "env_step_kernel");
-  return 0;
+  return kbj_env_step_range(ctx, ctx->stream, 0, ctx->cfg_h.num_envs, action_d, aux_t_d, actor_next_d, critic_next_d, aux_next_d);
 }
 
 int kbj_env_get_state(kbj_ctx* ctx, float* ep_h, float* es_h) {

@@ -28,7 +28,7 @@ struct NnWs {
   NetOff net[2];
   size_t nparams = 0, nactor = 0;
   // rollout scratch
-  float *rX[2] = {nullptr, nullptr}, *rG[2] = {nullptr, nullptr}, *rOut[2] = {nullptr, nullptr};
+  float *rX[4] = {nullptr, nullptr, nullptr, nullptr}, *rG[4] = {nullptr, nullptr, nullptr, nullptr}, *rOut[4] = {nullptr, nullptr, nullptr, nullptr};
   float* joint_bias_d = nullptr;
   // mirror aux losses (nets 2, 3 = actor, critic evaluated on mirrored observations with the SAME weights)
   bool mirror = false;
@@ -200,7 +200,9 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (w->B <= 0 || w->B > w->N) return kbj_fail(ctx, "kbj_create: batch_size must be in [1, num_envs]");
   layout_params(*w, w->H);
   size_t N = w->N, H = w->H, B = w->B, T = w->T;
-  for (int n = 0; n < 2; ++n) {
+  w->mirror = c.actor_mirror_loss_scale != 0.0f || c.critic_mirror_loss_scale != 0.0f;
+  w->nnets = w->mirror ? 4 : 2;
+  for (int n = 0; n < w->nnets; ++n) {
     if (dalloc(ctx, *w, &w->rX[n], N * H)) return -1;
     if (dalloc(ctx, *w, &w->rG[n], N * 4 * H)) return -1;
     if (dalloc(ctx, *w, &w->rOut[n], N * 40)) return -1;
@@ -208,8 +210,6 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->joint_bias_d, KBJ_NU)) return -1;
   if (hipMemcpy(w->joint_bias_d, ctx->model_h.joint_bias, KBJ_NU * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return kbj_fail(ctx, "hipMemcpy joint_bias");
   size_t R = T * B;
-  w->mirror = c.actor_mirror_loss_scale != 0.0f || c.critic_mirror_loss_scale != 0.0f;
-  w->nnets = w->mirror ? 4 : 2;
   if (w->mirror) {
     std::vector<MirrorEntry> ta, tc;
     build_mirror_tables(ctx->model_h, ta, tc);
@@ -267,6 +267,72 @@ void kbj_nn_destroy(kbj_ctx* ctx) {
   ctx->nn_ws = nullptr;
 }
 
+
+int kbj_env_step_range(kbj_ctx* ctx, hipStream_t s, int env0, int count, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d,
+                       float* aux_next_d);   // kbj_env.hip
+
+namespace {
+
+// One control step of the nets [net_lo, net_hi) (0 actor, 1 critic, 2/3 their mirror branches) for the env rows [n0, n0 + cnt) on
+// stream s. All pointers are those of env row 0.
+void policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, int net_hi, int n0, int cnt, const float* actor_obs_d, const float* critic_obs_d,
+                 kbj_carry* carry, uint32_t seed, uint32_t step_index, int argmax, float* action_d, float* logp_d, float* value_d) {
+  NnWs& w = *ws_of(ctx);
+  const kbj_config& c = ctx->cfg_h;
+  const int N = w.N, H = w.H;
+  const float* obs_base[2] = {actor_obs_d, critic_obs_d};
+  float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
+  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
+  for (int n = net_lo; n < net_hi; ++n) {
+    const int k = n & 1;
+    const NetOff& o = w.net[k];
+    const float* obs = obs_base[k] + (size_t)n0 * o.ld_obs;
+    float* obs_m = n >= 2 ? w.rObsM[k] + (size_t)n0 * o.ld_obs : nullptr;
+    // scratch rows are private to (net, env row): lanes and side lanes never share them
+    float* X = w.rX[n] + (size_t)n0 * H;
+    float* G = w.rG[n] + (size_t)n0 * 4 * H;
+    float* Out = w.rOut[n] + (size_t)n0 * 40;
+    if (n >= 2) {  // mirror branches advance their own carries on the mirrored observations (train.py:1463-1481, 1555-1560)
+      hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)cnt * o.ld_obs), dim3(256), 0, s, obs, obs_m, (size_t)cnt, o.ld_obs, w.mtab[k]);
+      obs = obs_m;
+    }
+    linear_fwd(s, obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, X, H, cnt, H, o.nin, 0);
+    const float* x = X;
+    for (int l = 0; l < 2; ++l) {
+      float* h = hc[n] + (size_t)(2 * l) * N * H + (size_t)n0 * H;
+      float* cc = hc[n] + (size_t)(2 * l + 1) * N * H + (size_t)n0 * H;
+      linear_fwd(s, x, H, params_d + o.w_ih[l], H, params_d + o.b[l], G, 4 * H, cnt, 4 * H, H, 0);
+      linear_fwd(s, h, H, params_d + o.w_hh[l], H, nullptr, G, 4 * H, cnt, 4 * H, H, 1);
+      CellFwdArgs2 ca;
+      ca.a[0] = CellFwdArgs{G, cc, h, cc, nullptr, nullptr, nullptr, nullptr, cnt, H};
+      hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((cnt * H + 255) / 256, 1), dim3(256), 0, s, ca);
+      x = h;
+    }
+    if (n == 3) continue;  // the mirrored critic's value is only needed under the gradient; at rollout time only its carry advances
+    linear_fwd(s, x, H, params_d + o.w_out, H, params_d + o.b_out, Out, 40, cnt, o.nout, H, 0);
+    if (n == 0)
+      hipLaunchKernelGGL(actor_head_sample_kernel, g1(cnt, 64), dim3(64), 0, s, Out, obs, carry->lpf_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, hp, seed,
+                         (uint32_t)(c.env_id_offset + n0), step_index, argmax, cnt, action_d + (size_t)n0 * KBJ_NU, logp_d + n0);
+    else if (n == 1)
+      hipLaunchKernelGGL(critic_value_kernel, g1(cnt), dim3(256), 0, s, Out, 40, cnt, value_d + n0);
+    else
+      hipLaunchKernelGGL(actor_head_lpf_kernel, g1((size_t)cnt * KBJ_NU), dim3(256), 0, s, Out, obs, carry->lpf_mirror_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, c.lpf_alpha, cnt);
+  }
+}
+
+// carry <- 0 where done, for the nets [net_lo, net_hi) and env rows [n0, n0 + cnt)
+void carry_reset_nets(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, int n0, int cnt, kbj_carry* carry, const float* done_d, int done_stride) {
+  NnWs& w = *ws_of(ctx);
+  float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
+  float* lpf[4] = {carry->lpf_d, nullptr, carry->lpf_mirror_d, nullptr};
+  size_t n = (size_t)4 * cnt * w.H;
+  for (int k = net_lo; k < net_hi; ++k)
+    hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, s, hc[k] + (size_t)n0 * w.H, 4, (size_t)w.N * w.H, cnt, w.H, lpf[k] ? lpf[k] + (size_t)n0 * KBJ_NU : nullptr,
+                       done_d + (size_t)n0 * done_stride, done_stride);
+}
+
+}  // namespace
+
 extern "C" {
 
 size_t kbj_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size); return w.nparams; }
@@ -294,42 +360,10 @@ int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_
                     uint32_t step_index, int argmax, float* action_d, float* logp_d, float* value_d) {
   if (!ctx || !params_d || !actor_obs_d || !critic_obs_d || !carry || !action_d || !logp_d || !value_d) return kbj_fail(ctx, "kbj_policy_step: null argument");
   NnWs& w = *ws_of(ctx);
-  const kbj_config& c = ctx->cfg_h;
-  hipStream_t s = ctx->stream;
-  int N = w.N, H = w.H;
   KbjTimed timed(ctx, true);
   if (w.mirror && (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d))
     return kbj_fail(ctx, "kbj_policy_step: the mirror losses are enabled, the carry needs the mirror-branch arrays");
-  const float* obs[4] = {actor_obs_d, critic_obs_d, w.rObsM[0], w.rObsM[1]};
-  float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
-  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
-  for (int n = 0; n < w.nnets; ++n) {
-    const NetOff& o = w.net[n & 1];
-    const int k = n & 1;
-    if (n >= 2)  // mirror branches advance their own carries on the mirrored observations (train.py:1463-1481, 1555-1560)
-      hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)N * o.ld_obs), dim3(256), 0, s, obs[k], w.rObsM[k], (size_t)N, o.ld_obs, w.mtab[k]);
-    linear_fwd(s, obs[n], o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, w.rX[k], H, N, H, o.nin, 0);
-    const float* x = w.rX[k];
-    for (int l = 0; l < 2; ++l) {
-      float* h = hc[n] + (size_t)(2 * l) * N * H;
-      float* cc = hc[n] + (size_t)(2 * l + 1) * N * H;
-      linear_fwd(s, x, H, params_d + o.w_ih[l], H, params_d + o.b[l], w.rG[k], 4 * H, N, 4 * H, H, 0);
-      linear_fwd(s, h, H, params_d + o.w_hh[l], H, nullptr, w.rG[k], 4 * H, N, 4 * H, H, 1);
-      CellFwdArgs2 ca;
-      ca.a[0] = CellFwdArgs{w.rG[k], cc, h, cc, nullptr, nullptr, nullptr, nullptr, N, H};
-      hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((N * H + 255) / 256, 1), dim3(256), 0, s, ca);
-      x = h;
-    }
-    if (n == 3) break;  // the mirrored critic's value is only needed under the gradient; at rollout time only its carry advances
-    linear_fwd(s, x, H, params_d + o.w_out, H, params_d + o.b_out, w.rOut[k], 40, N, o.nout, H, 0);
-    if (n == 0)
-      hipLaunchKernelGGL(actor_head_sample_kernel, g1(N, 64), dim3(64), 0, s, w.rOut[0], actor_obs_d, carry->lpf_d, w.joint_bias_d, hp, seed,
-                         (uint32_t)c.env_id_offset, step_index, argmax, N, action_d, logp_d);
-    else if (n == 1)
-      hipLaunchKernelGGL(critic_value_kernel, g1(N), dim3(256), 0, s, w.rOut[1], 40, N, value_d);
-    else
-      hipLaunchKernelGGL(actor_head_lpf_kernel, g1((size_t)N * KBJ_NU), dim3(256), 0, s, w.rOut[0], w.rObsM[0], carry->lpf_mirror_d, w.joint_bias_d, c.lpf_alpha, N);
-  }
+  policy_nets(ctx, ctx->stream, params_d, 0, w.nnets, 0, w.N, actor_obs_d, critic_obs_d, carry, seed, step_index, argmax, action_d, logp_d, value_d);
   KBJ_CHECK_LAUNCH(ctx, "kbj_policy_step");
   return 0;
 }
@@ -337,18 +371,15 @@ int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_
 int kbj_carry_reset(kbj_ctx* ctx, kbj_carry* carry, const float* done_d, int done_stride) {
   if (!ctx || !carry || !done_d) return kbj_fail(ctx, "kbj_carry_reset: null argument");
   NnWs& w = *ws_of(ctx);
-  size_t n = (size_t)4 * w.N * w.H;
-  hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, ctx->stream, carry->actor_hc_d, 4, w.N, w.H, carry->lpf_d, done_d, done_stride);
-  hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, ctx->stream, carry->critic_hc_d, 4, w.N, w.H, (float*)nullptr, done_d, done_stride);
-  if (w.mirror) {
-    if (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d) return kbj_fail(ctx, "kbj_carry_reset: mirror-branch carry arrays are NULL");
-    hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, ctx->stream, carry->actor_mirror_hc_d, 4, w.N, w.H, carry->lpf_mirror_d, done_d, done_stride);
-    hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, ctx->stream, carry->critic_mirror_hc_d, 4, w.N, w.H, (float*)nullptr, done_d, done_stride);
-  }
+  if (w.mirror && (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d)) return kbj_fail(ctx, "kbj_carry_reset: mirror-branch carry arrays are NULL");
+  carry_reset_nets(ctx, ctx->stream, 0, w.nnets, 0, w.N, carry, done_d, done_stride);
   KBJ_CHECK_LAUNCH(ctx, "carry_reset_kernel");
   return 0;
 }
 
+// The rollout is a two-lane software pipeline over env halves: while the env kernel (VALU/latency bound, one wavefront per env)
+// steps one half, the matrix cores run the actor of the other half; the critic (and the mirror branches), which the env
+// never waits for, run on side lanes under the env kernel of their own half. Per-env results do not depend on the split.
 int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t seed, uint32_t first_step_index, kbj_traj* tr) {
   if (!ctx || !params_d || !carry || !tr) return kbj_fail(ctx, "kbj_rollout: null argument");
   NnWs& w = *ws_of(ctx);
@@ -371,15 +402,44 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
     KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_critic_mirror_hc_d, carry->critic_mirror_hc_d, hcb, hipMemcpyDeviceToDevice, s));
     KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_lpf_mirror_d, carry->lpf_mirror_d, (size_t)N * KBJ_NU * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
+  static const bool serial = getenv("KBJ_ROLLOUT_SERIAL") != nullptr;   // diagnostics: one lane, no overlap
+  const int lanes = (!serial && N >= 256 && N % 2 == 0) ? 2 : 1;
+  hipStream_t ls[2] = {ctx->stream, ctx->stream2};                      // actor + env of each half
+  hipStream_t cs[2] = {serial ? ctx->stream : ctx->side[0], serial ? ctx->stream : ctx->side[1]};   // critic + mirror branches of each half
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+  if (lanes == 2) KBJ_HIP(ctx, hipStreamWaitEvent(ls[1], ctx->ev_fork, 0));
+  if (!serial) for (int h = 0; h < lanes; ++h) KBJ_HIP(ctx, hipStreamWaitEvent(cs[h], ctx->ev_fork, 0));
+  const int cnt = N / lanes;
   for (int t = 0; t < T; ++t) {
-    int rc = kbj_policy_step(ctx, params_d, tr->actor_obs_d + (size_t)t * N * la, tr->critic_obs_d + (size_t)t * N * lc, carry, seed,
-                             first_step_index + (uint32_t)t, 0, tr->action_d + (size_t)t * N * KBJ_NU, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N);
-    if (rc) return rc;
-    rc = kbj_env_step(ctx, tr->action_d + (size_t)t * N * KBJ_NU, tr->aux_d + (size_t)t * N * lx, tr->actor_obs_d + (size_t)(t + 1) * N * la,
-                      tr->critic_obs_d + (size_t)(t + 1) * N * lc, tr->aux_d + (size_t)(t + 1) * N * lx);
-    if (rc) return rc;
-    rc = kbj_carry_reset(ctx, carry, tr->aux_d + (size_t)t * N * lx + KBJ_AUX_DONE, KBJ_AUX_SIZE);
-    if (rc) return rc;
+    const float* ao = tr->actor_obs_d + (size_t)t * N * la;
+    const float* co = tr->critic_obs_d + (size_t)t * N * lc;
+    float* aux_t = tr->aux_d + (size_t)t * N * lx;
+    float* act = tr->action_d + (size_t)t * N * KBJ_NU;
+    for (int h = 0; h < lanes; ++h) {
+      const int n0 = h * cnt;
+      policy_nets(ctx, ls[h], params_d, 0, 1, n0, cnt, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N);
+      policy_nets(ctx, cs[h], params_d, 1, w.nnets, n0, cnt, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N);
+      int rc = kbj_env_step_range(ctx, ls[h], n0, cnt, act, aux_t, tr->actor_obs_d + (size_t)(t + 1) * N * la, tr->critic_obs_d + (size_t)(t + 1) * N * lc,
+                                  tr->aux_d + (size_t)(t + 1) * N * lx);
+      if (rc) return rc;
+      carry_reset_nets(ctx, ls[h], 0, 1, n0, cnt, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE);
+      if (!serial) {   // the side lane needs this step's done flags and the next critic observation
+        KBJ_HIP(ctx, hipEventRecord(ctx->ev_side[h], ls[h]));
+        KBJ_HIP(ctx, hipStreamWaitEvent(cs[h], ctx->ev_side[h], 0));
+      }
+      carry_reset_nets(ctx, cs[h], 1, w.nnets, n0, cnt, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE);
+    }
+  }
+  KBJ_CHECK_LAUNCH(ctx, "kbj_rollout");
+  if (!serial) {   // join every lane back into the caller's stream
+    for (int h = 0; h < lanes; ++h) {
+      KBJ_HIP(ctx, hipEventRecord(ctx->ev_side[h], cs[h]));
+      KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_side[h], 0));
+    }
+    if (lanes == 2) {
+      KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ls[1]));
+      KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
+    }
   }
   return kbj_rewards(ctx, tr->aux_d, T, tr->reward_d, nullptr);
 }

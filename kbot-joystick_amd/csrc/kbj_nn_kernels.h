@@ -116,14 +116,15 @@ __global__ void critic_value_kernel(const float* __restrict__ out, int ld, int N
 }
 
 // carry <- carry * (done == 0) (train.py:1502-1506): hc [depth*2][N][H], lpf [N][20]
-__global__ void carry_reset_kernel(float* __restrict__ hc, int planes, int N, int H, float* __restrict__ lpf, const float* __restrict__ done, int stride) {
+__global__ void carry_reset_kernel(float* __restrict__ hc, int planes, size_t plane_stride, int cnt, int H, float* __restrict__ lpf, const float* __restrict__ done,
+                                   int stride) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  int per = N * H;
+  int per = cnt * H;
   if (idx < planes * per) {
-    int n = (idx % per) / H;
-    if (done[(size_t)n * stride] != 0) hc[idx] = 0;
+    int p = idx / per, r = idx % per;
+    if (done[(size_t)(r / H) * stride] != 0) hc[(size_t)p * plane_stride + r] = 0;
   }
-  if (lpf && idx < N * KBJ_NU) { int n = idx / KBJ_NU; if (done[(size_t)n * stride] != 0) lpf[idx] = 0; }
+  if (lpf && idx < cnt * KBJ_NU) { int n = idx / KBJ_NU; if (done[(size_t)n * stride] != 0) lpf[idx] = 0; }
 }
 
 // ---- minibatch gathers ---------------------------------------------------------------------------------------------

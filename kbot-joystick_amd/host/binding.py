@@ -100,8 +100,8 @@ def load_library() -> C.CDLL:
 
 def _ptr(t):
     """Device/host pointer of a torch tensor or numpy array (must be contiguous)."""
-    if t is None:
-        return None
+    if t is None or isinstance(t, int):   # an int is a raw address (e.g. a column inside a row-major tensor)
+        return t
     if hasattr(t, "data_ptr"):
         if not t.is_contiguous():
             raise KbjError("tensor passed to libkbj must be contiguous")

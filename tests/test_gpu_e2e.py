@@ -93,3 +93,44 @@ def test_training_with_mirror_losses_runs():
     assert float(task.carry.actor_mirror_hc.abs().max()) > 0 and float(task.traj.carry0_actor_mirror_hc.abs().max()) > 0
     assert not torch.equal(p0, task.params)
     task.ctx.close()
+
+
+@pytest.mark.parametrize("mirror", [False, True])
+def test_pipelined_rollout_equals_stepwise_calls(mirror):
+    """kbj_rollout runs two env halves as a software pipeline with the critic on side lanes; the trajectory must be bit-identical
+    to driving kbj_policy_step / kbj_env_step / kbj_carry_reset one full-batch call at a time."""
+    import torch
+    from kbot_joystick_amd.host import binding as Bd, buffers
+    from kbot_joystick_amd.spec import compiler, layout as L
+    N, T, H = 512, 6, 64
+    kw = dict(actor_mirror_loss_scale=1.0, critic_mirror_loss_scale=0.01) if mirror else {}
+    m = compiler.load_model("kbot-headless")
+    cfg = L.default_config(num_envs=N, batch_size=64, rollout_len=T, hidden_size=H, **kw)
+    out = []
+    for mode in ("rollout", "stepwise"):
+        ctx = Bd.Context(m, cfg, 0, torch.cuda.current_stream().cuda_stream)
+        params = torch.zeros(ctx.param_count(), device="cuda:0")
+        ctx.init_params(9, params)
+        carry = buffers.CarryBuffers(N, H, 2, "cuda:0", mirror=mirror)
+        tr = buffers.TrajBuffers(T, N, H, 2, "cuda:0", mirror=mirror)
+        ctx.env_reset_all(3, tr.actor_obs[T], tr.critic_obs[T], tr.aux[T])
+        for it in range(2):           # two rollouts: the second starts from carried state and row T -> row 0
+            if mode == "rollout":
+                ctx.rollout(params, carry.c, 3, it * T, tr.c)
+            else:
+                tr.actor_obs[0].copy_(tr.actor_obs[T]); tr.critic_obs[0].copy_(tr.critic_obs[T]); tr.aux[0].copy_(tr.aux[T])
+                for t in range(T):
+                    ctx.policy_step(params, tr.actor_obs[t], tr.critic_obs[t], carry.c, 3, it * T + t, False, tr.action[t], tr.logp[t], tr.value[t])
+                    ctx.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
+                    ctx.carry_reset(carry.c, tr.aux[t].data_ptr() + 4 * L.AUX["DONE"], L.AUX["SIZE"])
+                ctx.rewards(tr.aux, T, tr.reward)
+        ctx.synchronize()
+        got = [tr.actor_obs.clone(), tr.critic_obs.clone(), tr.aux.clone(), tr.action.clone(), tr.logp.clone(), tr.value.clone(), tr.reward.clone(),
+               carry.actor_hc.clone(), carry.critic_hc.clone(), carry.lpf.clone()]
+        if mirror:
+            got += [carry.actor_mirror_hc.clone(), carry.critic_mirror_hc.clone(), carry.lpf_mirror.clone()]
+        out.append(got)
+        ctx.close()
+    for a, b in zip(*out):
+        assert torch.equal(a, b)
+    assert float(out[0][2][:T, :, L.AUX["DONE"]].abs().sum()) >= 0

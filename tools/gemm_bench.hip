@@ -1,0 +1,67 @@
+// Standalone timing of the fp32-MFMA GEMM kernels (kbj_gemm.h) on the shapes of the PPO update / rollout.
+//   hipcc -O3 --offload-arch=gfx950 -Iinclude -Ikbot-joystick_amd/csrc tools/gemm_bench.hip -o tools/gemm_bench && tools/gemm_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+#include "kbj_gemm.h"
+
+thread_local kbj_ctx* kbj_prof_ctx = nullptr;
+thread_local std::string kbj_global_error;
+using namespace kbj;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <bool A_KC, bool B_KC>
+double run(const char* name, int M, int N, int K, int splitk, int force_big, float* A, float* B, float* C, bool check) {
+  GemmArgs g{A, B, C, nullptr, M, N, K, A_KC ? K : M, B_KC ? K : N, N, splitk > 1 ? 1 : 0, splitk, nullptr};
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  if (splitk > 1) CK(hipMemset(C, 0, (size_t)M * N * 4));
+  gemm_launch<A_KC, B_KC>(0, g, force_big);
+  CK(hipDeviceSynchronize());
+  double maxerr = 0;
+  if (check) {
+    std::vector<float> hA((size_t)M * K), hB((size_t)N * K), hC((size_t)M * N);
+    CK(hipMemcpy(hA.data(), A, hA.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hB.data(), B, hB.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+    for (int t = 0; t < 200; ++t) {
+      int m = rand() % M, n = rand() % N;
+      double s = 0;
+      for (int k = 0; k < K; ++k) s += (double)(A_KC ? hA[(size_t)m * K + k] : hA[(size_t)k * M + m]) * (B_KC ? hB[(size_t)n * K + k] : hB[(size_t)k * N + n]);
+      maxerr = std::fmax(maxerr, std::fabs(s - hC[(size_t)m * N + n]) / (1 + std::fabs(s)));
+    }
+  }
+  const int reps = 10;
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) gemm_launch<A_KC, B_KC>(0, g, force_big);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+  printf("%-28s M=%6d N=%5d K=%6d sk=%3d  %8.1f us  %6.1f TF", name, M, N, K, splitk, us, tf);
+  if (check) printf("  maxrelerr %.2e", maxerr);
+  printf("\n");
+  return us;
+}
+
+int main() {
+  size_t big = (size_t)51200 * 1024;
+  float *A, *B, *C;
+  CK(hipMalloc(&A, big * 4)); CK(hipMalloc(&B, big * 4)); CK(hipMalloc(&C, big * 4));
+  std::vector<float> h(big);
+  for (size_t i = 0; i < big; ++i) h[i] = (float)((rand() & 0xFFFF) - 32768) / 32768.0f;
+  CK(hipMemcpy(A, h.data(), big * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B, h.data() + 777, (big - 777) * 4, hipMemcpyHostToDevice));
+  run<true, true>("check fwd small", 300, 200, 100, 1, -1, A, B, C, true);
+  run<true, false>("check dx small", 300, 200, 100, 1, -1, A, B, C, true);
+  run<false, false>("check dW small", 200, 136, 3000, 4, -1, A, B, C, true);
+  run<false, false>("check dW big-tile", 256, 256, 3000, 4, 1, A, B, C, true);
+  run<true, true>("fwd ih (R x 4H x H)", 51200, 1024, 256, 1, -1, A, B, C, false);
+  run<true, true>("fwd in critic (R x H x 475)", 51200, 256, 475, 1, -1, A, B, C, false);
+  run<true, false>("dx (R x H x 4H)", 51200, 256, 1024, 1, -1, A, B, C, false);
+  run<false, false>("dW (4H x H x R) sk96", 1024, 256, 51200, 96, 1, A, B, C, false);
+  run<true, true>("rollout ih (N x 4H x H)", 8192, 1024, 256, 1, -1, A, B, C, false);
+  run<true, true>("rollout half (N/2 x 4H x H)", 4096, 1024, 256, 1, -1, A, B, C, false);
+  run<true, true>("square 4096", 4096, 4096, 4096, 1, -1, A, B, C, false);
+  return 0;
+}
