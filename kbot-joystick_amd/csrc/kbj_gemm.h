@@ -7,11 +7,16 @@
 //   dW = dy^T x       (A: dy [K][M] row-contig, B: x [K][N] row-contig)  weight gradients (split-K + atomics)
 // Tiling: workgroup = 4 wavefronts (2x2), each wavefront owns MT x NT 32x32 accumulator tiles (64 VGPRs at 2x2);
 // K is consumed in 32-wide LDS tiles. k-contiguous operands sit in LDS as [row][36] (ds_read_b128 fragments,
-// conflict-free), row-contiguous ones as [k][row] (4 x ds_read_b32). The global loads of tile k+1 are issued into
-// registers before the MFMAs of tile k and written to LDS after them (software pipelining: HBM/L2 latency behind the
-// matrix pipe).
+// conflict-free), row-contiguous ones as [k][row] (4 x ds_read_b32).
+// Pipeline: two LDS stages and one barrier per k tile — the global loads of tile k+1 are issued into registers before
+// the MFMAs of tile k and written to the other stage after them. A workgroup walks `ipw` consecutive work items
+// (output tile x k slice) and keeps that pipeline running across item boundaries, so the first-tile load latency and the
+// C write-back of the short-K shapes of this path (K = 256) hide behind the next item's loads.
+// Work items are ordered n-tile fastest and handed out so that the workgroups of one XCD (blockIdx % 8) own a contiguous
+// range: the operand panel shared by neighbouring tiles is fetched into one L2, not eight.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "kbj_ctx.h"
 
 namespace kbj {
@@ -24,8 +29,9 @@ struct GemmArgs {
   int M, N, K;          // C is M x N, contraction length K
   int lda, ldb, ldc;    // leading dimensions (elements) of the stored arrays
   int beta;             // 1: C += result, 0: C = result
-  int splitk;           // >1: grid.z slices of K, results atomically added into C
+  int splitk;           // >1: slices of K, results atomically added into C
   const int* a_rows;    // unused (reserved)
+  int ipw = 1;          // work items per workgroup (set by gemm_launch)
 };
 
 constexpr int GEMM_BK = 32;
@@ -36,6 +42,22 @@ template <int ROWS, bool KC>
 struct GemmStage {
   static constexpr int NV = ROWS / 32;
   f32x4 v[NV];
+  // interior tile (all ROWS rows and 32 k in range, 16-byte aligned rows): straight-line vector loads
+  __device__ __forceinline__ void load_fast(const float* __restrict__ P, int ld, int r0, int k0) {
+    const int tid = threadIdx.x;
+    if (KC) {
+      const int kq = tid & 7, rr = tid >> 3;
+      const float* p = P + (size_t)(r0 + rr) * ld + k0 + 4 * kq;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(32 * i) * ld);
+    } else {
+      constexpr int QPR = ROWS / 4, KROWS = 256 / QPR;
+      const int rq = tid % QPR, kr0 = tid / QPR;
+      const float* p = P + (size_t)(k0 + kr0) * ld + r0 + 4 * rq;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(KROWS * i) * ld);
+    }
+  }
   // P: operand base, ld, R: number of valid rows, r0: first row of the tile, k0/kend: k range
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int R, int r0, int k0, int kend, bool vec) {
     const int tid = threadIdx.x;
@@ -83,108 +105,181 @@ struct GemmStage {
   }
 };
 
+// work item -> output tile and k range (n tile fastest, then m tile, then k slice)
+struct GemmItem { int m0, n0, kbeg, kend, ks; };
+template <int BM, int BN>
+__device__ __forceinline__ GemmItem gemm_item(const GemmArgs& g, int item, int tiles_n, int tiles_m, int per) {
+  GemmItem it;
+  int tn = item % tiles_n, r = item / tiles_n;
+  int tm = r % tiles_m;
+  it.ks = r / tiles_m;
+  it.m0 = tm * BM; it.n0 = tn * BN;
+  it.kbeg = it.ks * per;
+  it.kend = min(g.K, it.kbeg + per);
+  return it;
+}
+
+// every k tile of the item is interior: whole tile rows in range, k range a multiple of 32, vector-aligned operands
+template <int BM, int BN>
+__device__ __forceinline__ bool gemm_item_fast(const GemmArgs& g, const GemmItem& it, bool vec) {
+  return vec && it.m0 + BM <= g.M && it.n0 + BN <= g.N && ((it.kend - it.kbeg) % GEMM_BK) == 0;
+}
+
 template <int MT, int NT, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BM = 64 * MT, BN = 64 * NT;
   constexpr int A_ELEMS = A_KC ? BM * GEMM_LDK : GEMM_BK * (BM + 4);
   constexpr int B_ELEMS = B_KC ? BN * GEMM_LDK : GEMM_BK * (BN + 4);
-  __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
-  float* As = lds;
-  float* Bs = lds + A_ELEMS;
+  constexpr int STAGE = A_ELEMS + B_ELEMS;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * STAGE floats (72 KB at 128x128: above the 64 KB static limit)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-  int kbeg = 0, kend = g.K;
-  if (g.splitk > 1) {
-    int per = ((g.K + g.splitk - 1) / g.splitk + GEMM_BK - 1) / GEMM_BK * GEMM_BK;
-    kbeg = blockIdx.z * per;
-    kend = min(g.K, kbeg + per);
-  }
-  f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+  const int sk = g.splitk > 1 ? g.splitk : 1;
+  const int per = sk > 1 ? ((g.K + sk - 1) / sk + GEMM_BK - 1) / GEMM_BK * GEMM_BK : g.K;
+  const int items = tiles_n * tiles_m * sk;
+  // XCD-contiguous hand-out: workgroup b runs on XCD b % 8 and takes logical slot (b % 8) * (G / 8) + b / 8
+  const int logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  int item = logical * g.ipw;
+  const int item_end = min(items, item + g.ipw);
+  if (item >= item_end) return;
 
   const bool a_vec = (g.lda & 3) == 0 && (((size_t)g.A & 15) == 0);
   const bool b_vec = (g.ldb & 3) == 0 && (((size_t)g.B & 15) == 0);
   GemmStage<BM, A_KC> sa;
   GemmStage<BN, B_KC> sb;
-  const int lr = lane & 31, lh = lane >> 5;
-  if (kbeg < kend) {
-    sa.load(g.A, g.lda, g.M, m0, kbeg, kend, a_vec);
-    sb.load(g.B, g.ldb, g.N, n0, kbeg, kend, b_vec);
-    sa.store(As); sb.store(Bs);
-    __syncthreads();
+  GemmItem cur = gemm_item<BM, BN>(g, item, tiles_n, tiles_m, per);
+  while (cur.kbeg >= cur.kend) {   // empty k slice (K not a multiple of the slice length): nothing to add
+    if (++item >= item_end) return;
+    cur = gemm_item<BM, BN>(g, item, tiles_n, tiles_m, per);
   }
-  for (int k0 = kbeg; k0 < kend; k0 += GEMM_BK) {
-    const bool more = k0 + GEMM_BK < kend;
-    if (more) {  // next tile in flight during this tile's MFMAs
-      sa.load(g.A, g.lda, g.M, m0, k0 + GEMM_BK, kend, a_vec);
-      sb.load(g.B, g.ldb, g.N, n0, k0 + GEMM_BK, kend, b_vec);
+  int stage = 0;
+  sa.load(g.A, g.lda, g.M, cur.m0, cur.kbeg, cur.kend, a_vec);
+  sb.load(g.B, g.ldb, g.N, cur.n0, cur.kbeg, cur.kend, b_vec);
+  sa.store(lds); sb.store(lds + A_ELEMS);
+  __syncthreads();
+
+  while (true) {
+    // the item after this one (skipping empty k slices)
+    GemmItem nxt = cur;
+    bool have_next = false;
+    for (int j = item + 1; j < item_end; ++j) {
+      nxt = gemm_item<BM, BN>(g, j, tiles_n, tiles_m, per);
+      if (nxt.kbeg < nxt.kend) { have_next = true; item = j; break; }
     }
-    // MFMA over the 32-wide k tile: 4 groups of 8 k; lane half lh owns k = 8 kk + 4 lh + e
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      f32x4 a[MT], b[NT];
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        int row = wr * 32 * MT + 32 * i + lr;
-        if (A_KC) a[i] = *reinterpret_cast<const f32x4*>(As + row * GEMM_LDK + 8 * kk + 4 * lh);
-        else { for (int e = 0; e < 4; ++e) a[i][e] = As[(8 * kk + 4 * lh + e) * (BM + 4) + row]; }
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    const bool fast_cur = gemm_item_fast<BM, BN>(g, cur, a_vec && b_vec);
+    const bool fast_nxt = have_next && gemm_item_fast<BM, BN>(g, nxt, a_vec && b_vec);
+    for (int k0 = cur.kbeg; k0 < cur.kend; k0 += GEMM_BK) {
+      const bool more = k0 + GEMM_BK < cur.kend;
+      const bool pre = more || have_next;
+      if (more) {  // next k tile of this item in flight during this tile's MFMAs
+        if (fast_cur) { sa.load_fast(g.A, g.lda, cur.m0, k0 + GEMM_BK); sb.load_fast(g.B, g.ldb, cur.n0, k0 + GEMM_BK); }
+        else { sa.load(g.A, g.lda, g.M, cur.m0, k0 + GEMM_BK, cur.kend, a_vec); sb.load(g.B, g.ldb, g.N, cur.n0, k0 + GEMM_BK, cur.kend, b_vec); }
+      } else if (have_next) {  // first k tile of the next item
+        if (fast_nxt) { sa.load_fast(g.A, g.lda, nxt.m0, nxt.kbeg); sb.load_fast(g.B, g.ldb, nxt.n0, nxt.kbeg); }
+        else { sa.load(g.A, g.lda, g.M, nxt.m0, nxt.kbeg, nxt.kend, a_vec); sb.load(g.B, g.ldb, g.N, nxt.n0, nxt.kbeg, nxt.kend, b_vec); }
       }
+      const float* As = lds + stage * STAGE;
+      const float* Bs = As + A_ELEMS;
+      // MFMA over the 32-wide k tile: 4 groups of 8 k; lane half lh owns k = 8 kk + 4 lh + e. The prefetched tile goes to the
+      // other LDS stage half way through (its loads have landed behind the first 32 MFMAs; that stage was last read one k tile
+      // ago, before the barrier every wavefront has passed since).
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int kk = 2 * half; kk < 2 * half + 2; ++kk) {
+          f32x4 a[MT], b[NT];
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            int row = wr * 32 * MT + 32 * i + lr;
+            if (A_KC) a[i] = *reinterpret_cast<const f32x4*>(As + row * GEMM_LDK + 8 * kk + 4 * lh);
+            else { for (int e = 0; e < 4; ++e) a[i][e] = As[(8 * kk + 4 * lh + e) * (BM + 4) + row]; }
+          }
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            int row = wc * 32 * NT + 32 * j + lr;
+            if (B_KC) b[j] = *reinterpret_cast<const f32x4*>(Bs + row * GEMM_LDK + 8 * kk + 4 * lh);
+            else { for (int e = 0; e < 4; ++e) b[j][e] = Bs[(8 * kk + 4 * lh + e) * (BN + 4) + row]; }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (half == 0 && pre) {
+          float* dst = lds + (stage ^ 1) * STAGE;
+          sa.store(dst); sb.store(dst + A_ELEMS);
+        }
+      }
+      __syncthreads();
+      stage ^= 1;
+    }
+    // ---- epilogue: accumulator (col = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)) -> C ----
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        int row = wc * 32 * NT + 32 * j + lr;
-        if (B_KC) b[j] = *reinterpret_cast<const f32x4*>(Bs + row * GEMM_LDK + 8 * kk + 4 * lh);
-        else { for (int e = 0; e < 4; ++e) b[j][e] = Bs[(8 * kk + 4 * lh + e) * (BN + 4) + row]; }
+        int n = cur.n0 + wc * 32 * NT + 32 * j + lr;
+        if (n >= g.N) continue;
+        float bv = (g.bias && cur.ks == 0) ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int m = cur.m0 + wr * 32 * MT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (m >= g.M) continue;
+          float* c = g.C + (size_t)m * g.ldc + n;
+          float v = acc[i][j][r] + bv;
+#ifdef KBJ_GEMM_NOSTORE   // timing experiment only (tools/gemm_bench): keep the MFMAs live, drop the write-back
+          if (v == 1.2345e-30f) *c = v;
+#else
+          if (sk > 1) atomicAdd(c, v);
+          else *c = g.beta ? *c + v : v;
+#endif
+        }
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
-    if (more) { sa.store(As); sb.store(Bs); __syncthreads(); }
+    if (!have_next) break;
+    cur = nxt;
   }
-  // ---- epilogue: accumulator (col = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)) -> C ----
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      int n = n0 + wc * 32 * NT + 32 * j + lr;
-      if (n >= g.N) continue;
-      float bv = (g.bias && (g.splitk <= 1 || blockIdx.z == 0)) ? g.bias[n] : 0.0f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        int m = m0 + wr * 32 * MT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (m >= g.M) continue;
-        float* c = g.C + (size_t)m * g.ldc + n;
-        float v = acc[i][j][r] + bv;
-        if (g.splitk > 1) atomicAdd(c, v);
-        else *c = g.beta ? *c + v : v;
-      }
-    }
 }
 
-// host-side launcher; picks the 128x128 tile for large outputs and 64x64 when that leaves the chip underfilled
+template <int MT, int NT, bool A_KC, bool B_KC>
+inline void gemm_launch_tile(hipStream_t s, const GemmArgs& g, int wgs) {
+  constexpr int BM = 64 * MT, BN = 64 * NT;
+  constexpr size_t bytes = 2 * sizeof(float) * ((A_KC ? BM * GEMM_LDK : GEMM_BK * (BM + 4)) + (B_KC ? BN * GEMM_LDK : GEMM_BK * (BN + 4)));
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<MT, NT, A_KC, B_KC>),
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  (void)attr;
+  hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, A_KC, B_KC>), dim3(wgs), dim3(256), bytes, s, g);
+}
+
+// host-side launcher; picks the 128x128 tile for large outputs and 64x64 when that leaves the chip underfilled, and
+// lets a workgroup walk several work items when there are many more items than workgroup slots
 template <bool A_KC, bool B_KC>
-inline void gemm_launch(hipStream_t s, const GemmArgs& g, int force_big = -1) {
+inline void gemm_launch(hipStream_t s, const GemmArgs& g_in, int force_big = -1) {
+  GemmArgs g = g_in;
   int sk = g.splitk > 1 ? g.splitk : 1;
-  long big_blocks = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * sk;
-  bool big = force_big >= 0 ? force_big != 0 : big_blocks >= 192;
+  long big_items = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * sk;
+  bool big = force_big >= 0 ? force_big != 0 : big_items >= 192;
+  long items = big ? big_items : (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * sk;
+  // 256 CUs x 2 resident workgroups; keep >= ~3 rounds of workgroups for the hardware to balance, at most 4 items each
+  static const int ipw_env = getenv("KBJ_GEMM_IPW") ? atoi(getenv("KBJ_GEMM_IPW")) : 0;   // diagnostics
+  int ipw = ipw_env > 0 ? ipw_env : 1;
+  g.ipw = ipw;
+  int wgs = (int)((items + ipw - 1) / ipw);
+  wgs = (wgs + 7) / 8 * 8;
   KbjKernelTimer timer(s, KBJ_KIND_GEMM + (big ? 0 : 4) + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);
-  if (big) {
-    dim3 grid((g.N + 127) / 128, (g.M + 127) / 128, sk);
-    hipLaunchKernelGGL((gemm_f32_kernel<2, 2, A_KC, B_KC>), grid, dim3(256), 0, s, g);
-  } else {
-    dim3 grid((g.N + 63) / 64, (g.M + 63) / 64, sk);
-    hipLaunchKernelGGL((gemm_f32_kernel<1, 1, A_KC, B_KC>), grid, dim3(256), 0, s, g);
-  }
+  if (big) gemm_launch_tile<2, 2, A_KC, B_KC>(s, g, wgs);
+  else gemm_launch_tile<1, 1, A_KC, B_KC>(s, g, wgs);
 }
 
 }  // namespace kbj

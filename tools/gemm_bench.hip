@@ -56,10 +56,10 @@ int main() {
   run<true, false>("check dx small", 300, 200, 100, 1, -1, A, B, C, true);
   run<false, false>("check dW small", 200, 136, 3000, 4, -1, A, B, C, true);
   run<false, false>("check dW big-tile", 256, 256, 3000, 4, 1, A, B, C, true);
-  run<true, true>("fwd ih (R x 4H x H)", 51200, 1024, 256, 1, -1, A, B, C, false);
+  run<true, true>("fwd ih (R x 4H x H)", 51200, 1024, 256, 1, -1, A, B, C, true);
   run<true, true>("fwd in critic (R x H x 475)", 51200, 256, 475, 1, -1, A, B, C, false);
-  run<true, false>("dx (R x H x 4H)", 51200, 256, 1024, 1, -1, A, B, C, false);
-  run<false, false>("dW (4H x H x R) sk96", 1024, 256, 51200, 96, 1, A, B, C, false);
+  run<true, false>("dx (R x H x 4H)", 51200, 256, 1024, 1, -1, A, B, C, true);
+  run<false, false>("dW (4H x H x R) sk96", 1024, 256, 51200, 96, 1, A, B, C, true);
   run<true, true>("rollout ih (N x 4H x H)", 8192, 1024, 256, 1, -1, A, B, C, false);
   run<true, true>("rollout half (N/2 x 4H x H)", 4096, 1024, 256, 1, -1, A, B, C, false);
   run<true, true>("square 4096", 4096, 4096, 4096, 1, -1, A, B, C, false);
