@@ -489,6 +489,10 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * H), dim3(256), 0, s, carry0[n] + (size_t)(2 * l + 1) * N * H, idx, 1, N, B, H, H, H, w.tb[n].Cm[l]);
     }
   hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * KBJ_NU), dim3(256), 0, s, tr->carry0_lpf_d, idx, 1, N, B, KBJ_NU, KBJ_NU, KBJ_NU, w.lpf0);
+  // nothing on the forward path needs these: the advantage statistics and the cleared accumulators are ready long before the loss
+  KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), s));
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(32), dim3(256), 0, s, w.adv, R, w.stats);
+  KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), s));
   // ---- forward through time: actor on the caller's stream, critic on the context's second stream (the recurrences are
   // latency bound, so the two nets overlap) ----
   static const bool one_stream = getenv("KBJ_ONE_STREAM") != nullptr;   // diagnostics: serialise the two nets
@@ -516,9 +520,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipLaunchKernelGGL(gaussian_logp_kernel, g1(R), dim3(256), 0, s, w.y, w.sd, w.act, R, w.logp, w.ent);
   hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, s, w.tb[1].Out, 40, R, w.value);
   // ---- loss ----
-  KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), s));
   PpoParams pp{c.clip_param, c.value_clip, c.value_loss_coef, c.entropy_coef, c.log_ratio_clip, c.adv_eps};
-  hipLaunchKernelGGL(adv_stats_kernel, dim3(1), dim3(256), 0, s, w.adv, R, w.stats);
   hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, s, w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
                      w.stats + 2);
   if (w.mirror) {   // aux losses between each net and its mirror branch (train.py:1463-1481)
@@ -528,9 +530,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
                        w.dvalue, w.dvalue_m, w.stats + 2);
   }
   hipLaunchKernelGGL(ppo_metrics_kernel, dim3(1), dim3(1), 0, s, w.stats + 2, w.stats, pp, R, metrics_d);
-  // ---- backward ----
-  KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), s));
-  for (int n = 0; n < w.nnets; ++n) KBJ_HIP(ctx, hipMemsetAsync(w.tb[n].dOut, 0, (size_t)R * 40 * sizeof(float), s));
+  // ---- backward ---- (dOut needs no clearing: the actor head writes all 40 columns, the critic's GEMMs read column 0 only)
   hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[0].Out, w.y, w.sd, w.act, w.keep, w.dlogp,
                      w.mirror ? w.dy : (const float*)nullptr, -c.entropy_coef / (float)R, hp, T, B, w.tb[0].dOut);
   KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[1].dOut, 40 * sizeof(float), w.dvalue, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, s));

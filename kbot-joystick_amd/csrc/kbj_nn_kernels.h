@@ -155,13 +155,31 @@ __global__ void actor_head_train_fwd_kernel(const float* __restrict__ out, const
   if (i >= B * KBJ_NU) return;
   int b = i / KBJ_NU, j = i % KBJ_NU;
   float state = lpf0[i];
-  for (int t = 0; t < T; ++t) {
-    size_t r = (size_t)t * B + b;
-    float mean = out[r * 40 + j] + joint_bias[j] + (j >= 10 ? obs[r * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
-    float yy = state + hp.alpha * (mean - state);
-    y[r * KBJ_NU + j] = yy;
-    sd[r * KBJ_NU + j] = fminf((softplusf_(out[r * 40 + KBJ_NU + j]) + hp.min_std) * hp.var_scale, hp.max_std);
-    state = yy * keep[r];
+  const float jb = joint_bias[j];
+  constexpr int U = 8;   // the filter recursion is serial in t, its inputs are not: fetch U steps, then run the U dependent updates
+  for (int t0 = 0; t0 < T; t0 += U) {
+    float mean[U], kp[U], sdv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int t = t0 + u;
+      if (t < T) {
+        size_t r = (size_t)t * B + b;
+        mean[u] = out[r * 40 + j] + jb + (j >= 10 ? obs[r * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
+        kp[u] = keep[r];
+        sdv[u] = out[r * 40 + KBJ_NU + j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int t = t0 + u;
+      if (t < T) {
+        size_t r = (size_t)t * B + b;
+        float yy = state + hp.alpha * (mean[u] - state);
+        y[r * KBJ_NU + j] = yy;
+        sd[r * KBJ_NU + j] = fminf((softplusf_(sdv[u]) + hp.min_std) * hp.var_scale, hp.max_std);
+        state = yy * kp[u];
+      }
+    }
   }
 }
 // logp[r] / entropy[r] from y, sd, act (one thread per (t,b))
@@ -179,15 +197,15 @@ __global__ void gaussian_logp_kernel(const float* __restrict__ y, const float* _
 }
 
 // ---- PPO loss (restated ksim defaults): statistics pass then per-sample gradient coefficients ------------
-// stats[0..1] = sum(adv), sum(adv^2) over the minibatch (double accumulation by one block)
+// stats[0..1] += sum(adv), sum(adv^2) over the minibatch (double accumulation, one atomic pair per block)
 __global__ void adv_stats_kernel(const float* __restrict__ adv, int R, double* __restrict__ stats) {
   __shared__ double s1[256], s2[256];
   double a = 0, b = 0;
-  for (int i = threadIdx.x; i < R; i += 256) { double v = adv[i]; a += v; b += v * v; }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += 256 * gridDim.x) { double v = adv[i]; a += v; b += v * v; }
   s1[threadIdx.x] = a; s2[threadIdx.x] = b;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; } __syncthreads(); }
-  if (threadIdx.x == 0) { stats[0] = s1[0]; stats[1] = s2[0]; }
+  if (threadIdx.x == 0) { atomicAdd(&stats[0], s1[0]); atomicAdd(&stats[1], s2[0]); }   // stats zeroed by the caller
 }
 struct PpoParams { float clip, vclip, vcoef, ecoef, lrclip, adv_eps; };
 // per sample: coefficients dL/dlogp, dL/dvalue, dL/dentropy(const) and metric partial sums (atomics into metrics_acc[8] doubles)
@@ -288,17 +306,34 @@ __global__ void actor_head_train_bwd_kernel(const float* __restrict__ out, const
   if (i >= B * KBJ_NU) return;
   int b = i / KBJ_NU, j = i % KBJ_NU;
   float gcarry = 0;  // gradient wrt the filter state entering step t+1 (before the keep mask of step t)
-  for (int t = T - 1; t >= 0; --t) {
-    size_t r = (size_t)t * B + b;
-    float s = sd[r * KBJ_NU + j], z = (act[r * KBJ_NU + j] - y[r * KBJ_NU + j]) / s;
-    float gl = dlogp[r];
-    float gy = gl * (z / s) + (dy_extra ? dy_extra[r * KBJ_NU + j] : 0.0f) + keep[r] * gcarry;
-    dout[r * 40 + j] = hp.alpha * gy;
-    gcarry = (1 - hp.alpha) * gy;
-    float gs = gl * ((z * z - 1.0f) / s) + dent / s;
-    float raw = out[r * 40 + KBJ_NU + j];
-    float pre = (softplusf_(raw) + hp.min_std) * hp.var_scale;
-    dout[r * 40 + KBJ_NU + j] = pre < hp.max_std ? gs * hp.var_scale * sigmoidf_(raw) : 0.0f;
+  constexpr int U = 8;   // only gcarry is serial in t: everything else of U steps is fetched and evaluated first
+  for (int t1 = T - 1; t1 >= 0; t1 -= U) {
+    float gdir[U], kp[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int t = t1 - u;
+      if (t >= 0) {
+        size_t r = (size_t)t * B + b;
+        float s = sd[r * KBJ_NU + j], z = (act[r * KBJ_NU + j] - y[r * KBJ_NU + j]) / s;
+        float gl = dlogp[r];
+        gdir[u] = gl * (z / s) + (dy_extra ? dy_extra[r * KBJ_NU + j] : 0.0f);
+        kp[u] = keep[r];
+        float gs = gl * ((z * z - 1.0f) / s) + dent / s;
+        float raw = out[r * 40 + KBJ_NU + j];
+        float pre = (softplusf_(raw) + hp.min_std) * hp.var_scale;
+        dout[r * 40 + KBJ_NU + j] = pre < hp.max_std ? gs * hp.var_scale * sigmoidf_(raw) : 0.0f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      int t = t1 - u;
+      if (t >= 0) {
+        size_t r = (size_t)t * B + b;
+        float gy = gdir[u] + kp[u] * gcarry;
+        dout[r * 40 + j] = hp.alpha * gy;
+        gcarry = (1 - hp.alpha) * gy;
+      }
+    }
   }
 }
 

@@ -21,3 +21,8 @@ K = 5; e0.record()
 for _ in range(K): ctx.ppo_grad(params, tr.c, idx, Bs, tr.adv, tr.target, grad, met)
 e1.record(); ctx.synchronize()
 print(f"ppo_grad {e0.elapsed_time(e1)/K:.2f} ms per minibatch (B={Bs}, T={T}, H={H}) -> x48 = {e0.elapsed_time(e1)/K*48:.0f} ms/iteration")
+ctx.profile_begin()
+ctx.ppo_grad(params, tr.c, idx, Bs, tr.adv, tr.target, grad, met)
+ctx.synchronize()
+for k in ctx.profile_end()["kernels"]:
+    print(f"  {k['name']:44s} n={k['launches']:3d} avg={k['total_ms'] * 1e3 / k['launches']:8.1f} us  {k['flops'] / (k['total_ms'] * 1e-3) / 1e12:6.1f} TF")
