@@ -138,7 +138,10 @@ typedef struct kbj_config {
   float value_clip;          /* clipped value loss range */
   float actor_mirror_loss_scale;  /* train.py:115-122 (dataclass defaults 1.0 / 0.01; launch config 0.0 / 0.0, train.py:1771-1772) */
   float critic_mirror_loss_scale;
-  float reserved_f[6];
+  /* terrain ("sine" scene, train.py:1081; the surface is this build's own definition):
+   * z = terrain_amp * sin(2 pi x / terrain_wavelength) * sin(2 pi y / terrain_wavelength); terrain_amp = 0 is the plane z = 0 */
+  float terrain_amp, terrain_wavelength;
+  float reserved_f[4];
 } kbj_config;
 
 /* ---- per-env randomised model parameters ("EP" record, floats, one contiguous row per env) ---- */

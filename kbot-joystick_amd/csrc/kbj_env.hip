@@ -8,11 +8,7 @@ using namespace kbj;
 
 namespace {
 
-__device__ __forceinline__ PhysConst make_pc(const kbj_config& c) {
-  PhysConst pc;
-  pc.dt = c.dt; pc.tolerance = c.solver_tolerance; pc.iterations = c.solver_iterations; pc.ls_iterations = c.ls_iterations;
-  return pc;
-}
+__device__ __forceinline__ PhysConst make_pc(const kbj_config& c) { return phys_const(c); }
 
 // grid = N workgroups of one wavefront; env state rows are read/written lane-contiguously (coalesced)
 __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, uint32_t seed,

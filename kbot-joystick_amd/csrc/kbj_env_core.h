@@ -67,7 +67,7 @@ struct KbjShared {
   float Mc[4][5][11];   // limb c, dof a (hip..ankle): columns 0..5 base dofs, 6..10 the limb's own dofs
   float qfrc_act[NV], qfrc_smooth[NV], qacc_smooth[NV], qacc[NV];
   float Ma[NV], grad[NV], search[NV], mv[NV], vec[NV];
-  float conpos[NCON][3], condist[NCON];
+  float conpos[NCON][3], condist[NCON], connrm[NCON][3];
   int conact[NCON];
   float Jc[32][11];  // contact rows: columns 0..5 base dofs, 6..10 the leg's dofs hip..ankle
   float D[NROW], aref[NROW], jar[NROW], jv[NROW], force[NROW];  // a row is active iff D != 0

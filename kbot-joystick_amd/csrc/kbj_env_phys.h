@@ -17,7 +17,23 @@ namespace kbj {
 struct PhysConst {  // per-launch constants derived from kbj_config
   float dt, tolerance;
   int iterations, ls_iterations;
+  float tamp, tkw;   // terrain z = tamp sin(tkw x) sin(tkw y); tamp = 0: the plane z = 0
 };
+KBJ_DEV PhysConst phys_const(const kbj_config& c) {
+  PhysConst pc;
+  pc.dt = c.dt; pc.tolerance = c.solver_tolerance; pc.iterations = c.solver_iterations; pc.ls_iterations = c.ls_iterations;
+  pc.tamp = c.terrain_amp;
+  pc.tkw = c.terrain_amp != 0 ? (float)(6.283185307179586 / c.terrain_wavelength) : 0.0f;
+  return pc;
+}
+// terrain height and unit normal at (x, y)
+KBJ_DEV void terrain_eval(const PhysConst& pc, float x, float y, float& h, float n[3]) {
+  float sx = sinf(pc.tkw * x), cx = cosf(pc.tkw * x), sy = sinf(pc.tkw * y), cy = cosf(pc.tkw * y);
+  h = pc.tamp * sx * sy;
+  float hx = pc.tamp * pc.tkw * cx * sy, hy = pc.tamp * pc.tkw * sx * cy;
+  float inv = 1 / sqrtf(1 + hx * hx + hy * hy);
+  n[0] = -hx * inv; n[1] = -hy * inv; n[2] = inv;
+}
 
 // ---- position stage ----------------------------------------------------------------------------------------
 KBJ_DEV void phys_kinematics(KbjShared& S, const kbj_model& m) {
@@ -157,7 +173,7 @@ KBJ_DEV void phys_crb_mass(KbjShared& S) {
 }
 
 // ---- contacts + velocity stage -------------------------------------------------------------------------------
-KBJ_DEV void phys_collide_vel(KbjShared& S, const kbj_model& m) {
+KBJ_DEV void phys_collide_vel(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
   const float* qvel = S.es + KBJ_ES_QVEL;
   PFOR(ci, NCON) {  // capsule end ci%2 of capsule ci/2 against the plane z = 0
     int c = ci / 2, b = c < 2 ? 7 : 12;
@@ -168,10 +184,20 @@ KBJ_DEV void phys_collide_vel(KbjShared& S, const kbj_model& m) {
     float sgn = (ci & 1) ? 1.0f : -1.0f, hl = S.ep[KBJ_EP_CAP_HALF + c], rad = S.ep[KBJ_EP_CAP_RAD + c];
     float end[3];
     for (int k = 0; k < 3; ++k) end[k] = S.xpos[b][k] + t[k] + sgn * hl * ax[k];
-    float dist = end[2] - rad;
-    S.condist[ci] = dist;
-    S.conpos[ci][0] = end[0]; S.conpos[ci][1] = end[1]; S.conpos[ci][2] = end[2] - (rad + dist / 2);
-    S.conact[ci] = dist < 0;
+    if (pc.tamp == 0) {
+      float dist = end[2] - rad;
+      S.condist[ci] = dist;
+      S.conpos[ci][0] = end[0]; S.conpos[ci][1] = end[1]; S.conpos[ci][2] = end[2] - (rad + dist / 2);
+      S.connrm[ci][0] = 0; S.connrm[ci][1] = 0; S.connrm[ci][2] = 1;
+      S.conact[ci] = dist < 0;
+    } else {  // sphere (capsule end) against the tangent plane of the sine surface below its centre
+      float h, n[3];
+      terrain_eval(pc, end[0], end[1], h, n);
+      float dist = (end[2] - h) * n[2] - rad;
+      S.condist[ci] = dist;
+      for (int k = 0; k < 3; ++k) { S.conpos[ci][k] = end[k] - n[k] * (rad + dist / 2); S.connrm[ci][k] = n[k]; }
+      S.conact[ci] = dist < 0;
+    }
   }
   PFOR(c, 5) {  // limb walkers: spatial velocity, acceleration bias and body forces (RNE forward pass)
     float v[6] = {0, 0, 0, 0, 0, 0}, a[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
@@ -402,11 +428,25 @@ KBJ_DEV void phys_make_constraints(KbjShared& S, const kbj_model& m, const PhysC
     float mu = S.ep[KBJ_EP_MU];
     int ax = e / 2;
     float sg = (e & 1) ? -mu : mu, vel = 0;
+    float nr[3] = {0, 0, 1}, tg[3] = {ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, 0};
+    if (pc.tamp != 0) {  // contact frame: n = surface normal, t1 = world x made orthogonal to n, t2 = n x t1
+      for (int k = 0; k < 3; ++k) nr[k] = S.connrm[ci][k];
+      float inv = 1 / sqrtf(1 - nr[0] * nr[0]);
+      float t1[3] = {(1 - nr[0] * nr[0]) * inv, -nr[0] * nr[1] * inv, -nr[0] * nr[2] * inv};
+      if (ax == 0) { tg[0] = t1[0]; tg[1] = t1[1]; tg[2] = t1[2]; }
+      else { tg[0] = nr[1] * t1[2] - nr[2] * t1[1]; tg[1] = nr[2] * t1[0] - nr[0] * t1[2]; tg[2] = nr[0] * t1[1] - nr[1] * t1[0]; }
+    }
     for (int k = 0; k < 11; ++k) {
       int dk = k < 6 ? k : 6 + 5 * leg + (k - 6);
       float t[3];
       cross3(S.cdof[dk], off, t);
-      float jn = S.cdof[dk][5] + t[2], jt = S.cdof[dk][3 + ax] + t[ax];
+      float jn, jt;
+      if (pc.tamp == 0) { jn = S.cdof[dk][5] + t[2]; jt = S.cdof[dk][3 + ax] + t[ax]; }
+      else {
+        float jp[3] = {S.cdof[dk][3] + t[0], S.cdof[dk][4] + t[1], S.cdof[dk][5] + t[2]};
+        jn = nr[0] * jp[0] + nr[1] * jp[1] + nr[2] * jp[2];
+        jt = tg[0] * jp[0] + tg[1] * jp[1] + tg[2] * jp[2];
+      }
       float j = jn + sg * jt;
       S.Jc[r][k] = j;
       vel += j * qvel[dk];
@@ -601,7 +641,7 @@ KBJ_DEV void phys_forward(KbjShared& S, const kbj_model& m, const PhysConst& pc)
   phys_kinematics(S, m);
   phys_com(S);
   phys_crb_mass(S);
-  phys_collide_vel(S, m);
+  phys_collide_vel(S, m, pc);
   phys_smooth_forces(S, m);
   phys_make_constraints(S, m, pc);
   phys_solve(S, m, pc);

@@ -110,6 +110,12 @@ KBJ_DEV void task_reset(KbjShared& S, const kbj_model& m, const kbj_config& c, c
     es[KBJ_ES_QPOS + 0] = rng_uniform(rng, KBJ_RNG_RESET, e, 43, -c.reset_xy_range, c.reset_xy_range);
     es[KBJ_ES_QPOS + 1] = rng_uniform(rng, KBJ_RNG_RESET, e, 44, -c.reset_xy_range, c.reset_xy_range);
     es[KBJ_ES_QPOS + 2] = m.qpos0[2];
+    if (pc.tamp != 0) {  // stand on the highest of five terrain samples under the robot (centre, +-0.15 m in x and y)
+      const float sx[5] = {0, 0.15f, -0.15f, 0, 0}, sy[5] = {0, 0, 0, 0.15f, -0.15f};
+      float hmax = 0, nn[3];
+      for (int k = 0; k < 5; ++k) { float h; terrain_eval(pc, es[KBJ_ES_QPOS + 0] + sx[k], es[KBJ_ES_QPOS + 1] + sy[k], h, nn); hmax = k == 0 ? h : fmaxf(hmax, h); }
+      es[KBJ_ES_QPOS + 2] = m.qpos0[2] + hmax;
+    }
     for (int k = 0; k < 6; ++k) es[KBJ_ES_PUSH + k] = 0;
     es[KBJ_ES_PUSH_REM] = 0;
     es[KBJ_ES_PUSH_NXT] = floorf(rng_uniform(rng, KBJ_RNG_RANDOMIZE, e, 310, c.push_int_lo, c.push_int_hi) / c.ctrl_dt);

@@ -59,6 +59,9 @@ class HumanoidWalkingTaskConfig:
     robot: str = "kbot"                # train.py:1080 loads robot/kbot; BASELINE configs use kbot-headless
     seed: int = 0
     fixed_command: Optional[tuple] = None   # BASELINE configs[1]: flat-ground fixed joystick velocity command
+    terrain: str = "flat"                   # "flat" | "sine" (train.py:1081 loads the "sine" scene; BASELINE configs[4])
+    terrain_amplitude: float = 0.05         # metres; the surface definition is this build's own
+    terrain_wavelength: float = 2.0
 
     def to_kbj(self, num_envs_local: int, env_id_offset: int = 0) -> L.Config:
         if self.batch_size <= 0 or num_envs_local % self.batch_size != 0:
@@ -75,6 +78,10 @@ class HumanoidWalkingTaskConfig:
                   lam=self.lam, learning_rate=self.learning_rate, weight_decay=self.adam_weight_decay, switch_prob=self.ctrl_dt / 5,
                   actor_mirror_loss_scale=self.actor_mirror_loss_scale, critic_mirror_loss_scale=self.critic_mirror_loss_scale,
                   lpf_alpha=self.ctrl_dt / (self.ctrl_dt + 1.0 / (2.0 * math.pi * self.cutoff_frequency)))
+        if self.terrain not in ("flat", "sine"):
+            raise ValueError(f"unknown terrain {self.terrain!r} (flat | sine)")
+        if self.terrain == "sine":
+            kw.update(terrain_amp=self.terrain_amplitude, terrain_wavelength=self.terrain_wavelength)
         if self.fixed_command is not None:
             cmd = list(self.fixed_command) + [0.0] * (L.NCMD - len(self.fixed_command))
             kw.update(command_mode=1, fixed_command=cmd)

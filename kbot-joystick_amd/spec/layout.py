@@ -67,7 +67,8 @@ class Config(C.Structure):
         ("gamma", f32), ("lam", f32), ("clip_param", f32), ("value_loss_coef", f32), ("entropy_coef", f32),
         ("log_ratio_clip", f32), ("max_grad_norm", f32),
         ("learning_rate", f32), ("adam_b1", f32), ("adam_b2", f32), ("adam_eps", f32), ("weight_decay", f32),
-        ("adv_eps", f32), ("value_clip", f32), ("actor_mirror_loss_scale", f32), ("critic_mirror_loss_scale", f32), ("reserved_f", f32 * 6),
+        ("adv_eps", f32), ("value_clip", f32), ("actor_mirror_loss_scale", f32), ("critic_mirror_loss_scale", f32),
+        ("terrain_amp", f32), ("terrain_wavelength", f32), ("reserved_f", f32 * 4),
     ]
 
 
@@ -122,6 +123,7 @@ def default_config(**overrides) -> Config:
     c.clip_param, c.value_loss_coef, c.log_ratio_clip, c.max_grad_norm = 0.2, 0.5, 10.0, 2.0
     c.learning_rate, c.weight_decay = 5e-4, 1e-5                                  # train.py:95-102
     c.adam_b1, c.adam_b2, c.adam_eps, c.adv_eps, c.value_clip = 0.9, 0.999, 1e-8, 1e-6, 0.2
+    c.terrain_amp, c.terrain_wavelength = 0.0, 2.0      # flat ground; BASELINE configs[4] sets terrain_amp = 0.05
     for k, v in overrides.items():
         if not hasattr(c, k):
             raise AttributeError(f"kbj_config has no field {k!r}")

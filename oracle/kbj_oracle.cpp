@@ -62,6 +62,7 @@ void forward_dump(const kbj_model* m, const kbj_config* c, const float* ep, cons
                   const double* push, const double* warm, double* out, double* qpos_next, double* qvel_next) {
   Physics<R> phy;
   phy.m = m; phy.dt = c->dt; phy.opt.iterations = c->solver_iterations; phy.opt.ls_iterations = c->ls_iterations; phy.opt.tolerance = c->solver_tolerance; phy.opt.newton = c->solver_newton;
+    phy.terrain_amp = c->terrain_amp; phy.terrain_kw = c->terrain_amp != 0 ? (float)(6.283185307179586 / c->terrain_wavelength) : 0;
   phy.p.load(ep);
   R q[NQ], v[NV], u[NU], w[NV], ps[6];
   for (int i = 0; i < NQ; ++i) q[i] = (R)qpos[i];

@@ -109,6 +109,7 @@ template <class R> struct Derived {
   R M[NV][NV], Lc[NV][NV];              // mass matrix and its Cholesky factor (lower)
   R qfrc_bias[NV], qfrc_actuator[NV], qfrc_applied[NV], qfrc_smooth[NV], qacc_smooth[NV], qacc[NV];
   R con_pos[NCON][3], con_dist[NCON];   // all 8 slots always filled (fixed-size contact array semantics)
+  R con_n[NCON][3];                     // contact normal (terrain surface normal below the capsule end)
   int con_active[NCON];
   R efc_J[NEFC][NV], efc_D[NEFC], efc_R[NEFC], efc_aref[NEFC], efc_floss[NEFC], efc_force[NEFC];
   int efc_active[NEFC];
@@ -124,6 +125,22 @@ template <class R> struct Physics {
   EnvParams<R> p;
   R dt;
   SolverOpts opt;
+  R terrain_amp = 0, terrain_kw = 0;   // z = amp sin(kw x) sin(kw y), kw = 2 pi / wavelength (kbj_config); amp = 0: plane
+
+  // terrain height and unit normal at (x, y)
+  void terrain(R x, R y, R& h, R n[3]) const {
+    R sx = std::sin(terrain_kw * x), cx = std::cos(terrain_kw * x), sy = std::sin(terrain_kw * y), cy = std::cos(terrain_kw * y);
+    h = terrain_amp * sx * sy;
+    R hx = terrain_amp * terrain_kw * cx * sy, hy = terrain_amp * terrain_kw * sx * cy;
+    R inv = 1 / std::sqrt(1 + hx * hx + hy * hy);
+    n[0] = -hx * inv; n[1] = -hy * inv; n[2] = inv;
+  }
+  // tangents of the contact frame: t1 = world x made orthogonal to n, t2 = n x t1 (world x, y on the plane)
+  static void contact_tangents(const R n[3], R t1[3], R t2[3]) {
+    R inv = 1 / std::sqrt(1 - n[0] * n[0]);
+    t1[0] = (1 - n[0] * n[0]) * inv; t1[1] = -n[0] * n[1] * inv; t1[2] = -n[0] * n[2] * inv;
+    t2[0] = n[1] * t1[2] - n[2] * t1[1]; t2[1] = n[2] * t1[0] - n[0] * t1[2]; t2[2] = n[0] * t1[1] - n[1] * t1[0];
+  }
 
   // ---- position-dependent stage -------------------------------------------------------------
   void kinematics(const R* qpos, Derived<R>& d) const {
@@ -342,7 +359,7 @@ template <class R> struct Physics {
     imp = impedance(dist, solimp);
   }
 
-  void collide(Derived<R>& d) const {  // capsule ends against the plane z = 0 (normal +z)
+  void collide(Derived<R>& d) const {  // capsule ends against the plane z = 0 (normal +z) or the sine terrain
     for (int c = 0; c < NCAP; ++c) {
       int b = m->cap_body[c];
       R ctr[3], ax[3], t[3];
@@ -354,10 +371,20 @@ template <class R> struct Physics {
         R sgn = e ? 1 : -1;
         R end[3] = {ctr[0] + sgn * p.cap_half[c] * ax[0], ctr[1] + sgn * p.cap_half[c] * ax[1], ctr[2] + sgn * p.cap_half[c] * ax[2]};
         int ci = 2 * c + e;
-        R dist = end[2] - p.cap_rad[c];
-        d.con_dist[ci] = dist;
-        d.con_pos[ci][0] = end[0]; d.con_pos[ci][1] = end[1]; d.con_pos[ci][2] = end[2] - (p.cap_rad[c] + dist / 2);
-        d.con_active[ci] = dist < 0;
+        if (terrain_amp == 0) {
+          R dist = end[2] - p.cap_rad[c];
+          d.con_dist[ci] = dist;
+          d.con_pos[ci][0] = end[0]; d.con_pos[ci][1] = end[1]; d.con_pos[ci][2] = end[2] - (p.cap_rad[c] + dist / 2);
+          d.con_n[ci][0] = 0; d.con_n[ci][1] = 0; d.con_n[ci][2] = 1;
+          d.con_active[ci] = dist < 0;
+        } else {  // sphere (capsule end) against the tangent plane of the surface below its centre
+          R h, n[3];
+          terrain(end[0], end[1], h, n);
+          R dist = (end[2] - h) * n[2] - p.cap_rad[c];
+          d.con_dist[ci] = dist;
+          for (int k = 0; k < 3; ++k) { d.con_pos[ci][k] = end[k] - n[k] * (p.cap_rad[c] + dist / 2); d.con_n[ci][k] = n[k]; }
+          d.con_active[ci] = dist < 0;
+        }
       }
     }
   }
@@ -406,12 +433,22 @@ template <class R> struct Physics {
       R mu = p.mu;
       R tran = (R)m->body_invweight0[body][0];  // world side contributes 0
       R invw = (tran + mu * mu * tran) * 2 * mu * mu;  // common pyramid-edge weight (impratio = 1)
+      R tg[2][3];
+      if (terrain_amp != 0) contact_tangents(d.con_n[ci], tg[0], tg[1]);
       for (int e = 0; e < 4; ++e) {
         int r = ROW_CON + 4 * ci + e;
         int ax = e / 2;
         R s = (e & 1) ? -mu : mu;
         R vel = 0;
-        for (int i = 0; i < NV; ++i) { d.efc_J[r][i] = Jp[2][i] + s * Jp[ax][i]; vel += d.efc_J[r][i] * qvel[i]; }
+        for (int i = 0; i < NV; ++i) {
+          if (terrain_amp == 0) d.efc_J[r][i] = Jp[2][i] + s * Jp[ax][i];
+          else {
+            R jn = d.con_n[ci][0] * Jp[0][i] + d.con_n[ci][1] * Jp[1][i] + d.con_n[ci][2] * Jp[2][i];
+            R jt = tg[ax][0] * Jp[0][i] + tg[ax][1] * Jp[1][i] + tg[ax][2] * Jp[2][i];
+            d.efc_J[r][i] = jn + s * jt;
+          }
+          vel += d.efc_J[r][i] * qvel[i];
+        }
         d.efc_R[r] = std::max<R>((R)1e-15, (1 - imp) / imp * invw);
         d.efc_D[r] = 1 / d.efc_R[r];
         d.efc_aref[r] = -b * vel - k * imp * d.con_dist[ci];

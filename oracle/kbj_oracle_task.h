@@ -118,6 +118,7 @@ template <class R> struct Env {
   void bind(const kbj_model* m_, const kbj_config* c_, uint32_t seed, int env_gid, float* ep_, float* es_) {
     m = m_; c = c_; rng.seed = seed; rng.env = (uint32_t)env_gid; ep = ep_; es = es_;
     phy.m = m; phy.dt = c->dt; phy.opt.iterations = c->solver_iterations; phy.opt.ls_iterations = c->ls_iterations; phy.opt.tolerance = c->solver_tolerance; phy.opt.newton = c->solver_newton;
+    phy.terrain_amp = c->terrain_amp; phy.terrain_kw = c->terrain_amp != 0 ? (float)(6.283185307179586 / c->terrain_wavelength) : 0;
   }
   uint32_t& episode() { return *reinterpret_cast<uint32_t*>(es + KBJ_ES_EPISODE); }
   uint32_t& stepctr() { return *reinterpret_cast<uint32_t*>(es + KBJ_ES_STEP); }
@@ -211,6 +212,12 @@ template <class R> struct Env {
     float yaw = U(42, 3.14159265358979323846f);
     qpos[3] = (R)std::cos(yaw / 2); qpos[4] = 0; qpos[5] = 0; qpos[6] = (R)std::sin(yaw / 2);
     qpos[0] = (R)U(43, c->reset_xy_range); qpos[1] = (R)U(44, c->reset_xy_range);
+    if (phy.terrain_amp != 0) {  // stand on the highest of five terrain samples under the robot (centre, +-0.15 m in x and y)
+      const R sx[5] = {0, (R)0.15, (R)-0.15, 0, 0}, sy[5] = {0, 0, 0, (R)0.15, (R)-0.15};
+      R hmax = 0, nn[3];
+      for (int k = 0; k < 5; ++k) { R h; phy.terrain(qpos[0] + sx[k], qpos[1] + sy[k], h, nn); hmax = k == 0 ? h : std::max(hmax, h); }
+      qpos[2] = (R)m->qpos0[2] + hmax;
+    }
     for (int u = 0; u < NU; ++u) es[KBJ_ES_ACT_PREV + u] = m->joint_bias[u];
     for (int k = 0; k < 6; ++k) es[KBJ_ES_PUSH + k] = 0;
     es[KBJ_ES_PUSH_REM] = 0;

@@ -10,8 +10,7 @@
 using namespace kbj;
 
 static PhysConst make_pc(const kbj_config* c) {
-  PhysConst pc;
-  pc.dt = c->dt; pc.tolerance = c->solver_tolerance; pc.iterations = c->solver_iterations; pc.ls_iterations = c->ls_iterations;
+  PhysConst pc = phys_const(*c);
   return pc;
 }
 
