@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--hidden", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4],
+                    help="BASELINE.json configs[i] workload: 1 = the metric's (kbot-headless, flat, fixed command); 3 = UnifiedCommand "
+                         "sampler; 4 = full kbot on the sine terrain (extra measurements, not the headline line)")
     args = ap.parse_args()
 
     import torch
@@ -98,8 +101,13 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
-    cfg = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, robot="kbot-headless", seed=0,
-                        fixed_command=(0.5, 0.0, 0.0))
+    wl = {1: dict(robot="kbot-headless", fixed_command=(0.5, 0.0, 0.0)),
+          3: dict(robot="kbot-headless"),
+          4: dict(robot="kbot", terrain="sine")}[args.config]
+    wl_name = {1: "kbot-headless, {n} envs/GPU, flat ground, fixed joystick command (0.5,0,0)",
+               3: "kbot-headless, {n} envs/GPU, flat ground, UnifiedCommand 6-mode sampler",
+               4: "kbot (full), {n} envs/GPU, sine terrain (A 0.05 m, L 2 m), UnifiedCommand sampler, pushes + all randomizers"}[args.config]
+    cfg = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, **wl)
     task = HumanoidWalkingTask(cfg, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     def barrier():
@@ -174,10 +182,10 @@ def main():
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"kbot-headless, {args.envs_per_gpu} envs/GPU, flat ground, fixed joystick command (0.5,0,0), full iteration: "
+        "config": {"workload": wl_name.format(n=args.envs_per_gpu) + ", full iteration: "
                                f"100-step rollout + PPO update (batch 512/GPU, 3 passes, LSTM hidden {args.hidden}, depth 2)",
                    "envs_per_gpu": args.envs_per_gpu, "rollout_steps": task.T, "batch_size_per_gpu": cfg.batch_size, "num_passes": cfg.num_passes,
-                   "hidden_size": args.hidden, "parallelism": f"env-sharded dp{world}, grad all-reduce per optimizer step"},
+                   "hidden_size": args.hidden, "baseline_config": args.config, "parallelism": f"env-sharded dp{world}, grad all-reduce per optimizer step"},
         "roofline": roofline, "roofline_secondary": roofline2, "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)

@@ -119,12 +119,6 @@ __device__ __forceinline__ GemmItem gemm_item(const GemmArgs& g, int item, int t
   return it;
 }
 
-// every k tile of the item is interior: whole tile rows in range, k range a multiple of 32, vector-aligned operands
-template <int BM, int BN>
-__device__ __forceinline__ bool gemm_item_fast(const GemmArgs& g, const GemmItem& it, bool vec) {
-  return vec && it.m0 + BM <= g.M && it.n0 + BN <= g.N && ((it.kend - it.kbeg) % GEMM_BK) == 0;
-}
-
 template <int MT, int NT, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BM = 64 * MT, BN = 64 * NT;
@@ -176,17 +170,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const bool fast_cur = gemm_item_fast<BM, BN>(g, cur, a_vec && b_vec);
-    const bool fast_nxt = have_next && gemm_item_fast<BM, BN>(g, nxt, a_vec && b_vec);
+    // interior tiles take straight-line vector loads, decided per operand and per k tile (a ragged last k tile or an
+    // unaligned operand, e.g. the 475-wide critic input projection, only slows the loads it touches)
+    const bool rows_a_cur = a_vec && cur.m0 + BM <= g.M, rows_b_cur = b_vec && cur.n0 + BN <= g.N;
+    const bool rows_a_nxt = have_next && a_vec && nxt.m0 + BM <= g.M, rows_b_nxt = have_next && b_vec && nxt.n0 + BN <= g.N;
     for (int k0 = cur.kbeg; k0 < cur.kend; k0 += GEMM_BK) {
       const bool more = k0 + GEMM_BK < cur.kend;
       const bool pre = more || have_next;
       if (more) {  // next k tile of this item in flight during this tile's MFMAs
-        if (fast_cur) { sa.load_fast(g.A, g.lda, cur.m0, k0 + GEMM_BK); sb.load_fast(g.B, g.ldb, cur.n0, k0 + GEMM_BK); }
-        else { sa.load(g.A, g.lda, g.M, cur.m0, k0 + GEMM_BK, cur.kend, a_vec); sb.load(g.B, g.ldb, g.N, cur.n0, k0 + GEMM_BK, cur.kend, b_vec); }
+        const bool kfull = k0 + 2 * GEMM_BK <= cur.kend;
+        if (rows_a_cur && kfull) sa.load_fast(g.A, g.lda, cur.m0, k0 + GEMM_BK);
+        else sa.load(g.A, g.lda, g.M, cur.m0, k0 + GEMM_BK, cur.kend, a_vec);
+        if (rows_b_cur && kfull) sb.load_fast(g.B, g.ldb, cur.n0, k0 + GEMM_BK);
+        else sb.load(g.B, g.ldb, g.N, cur.n0, k0 + GEMM_BK, cur.kend, b_vec);
       } else if (have_next) {  // first k tile of the next item
-        if (fast_nxt) { sa.load_fast(g.A, g.lda, nxt.m0, nxt.kbeg); sb.load_fast(g.B, g.ldb, nxt.n0, nxt.kbeg); }
-        else { sa.load(g.A, g.lda, g.M, nxt.m0, nxt.kbeg, nxt.kend, a_vec); sb.load(g.B, g.ldb, g.N, nxt.n0, nxt.kbeg, nxt.kend, b_vec); }
+        const bool kfull = nxt.kbeg + GEMM_BK <= nxt.kend;
+        if (rows_a_nxt && kfull) sa.load_fast(g.A, g.lda, nxt.m0, nxt.kbeg);
+        else sa.load(g.A, g.lda, g.M, nxt.m0, nxt.kbeg, nxt.kend, a_vec);
+        if (rows_b_nxt && kfull) sb.load_fast(g.B, g.ldb, nxt.n0, nxt.kbeg);
+        else sb.load(g.B, g.ldb, g.N, nxt.n0, nxt.kbeg, nxt.kend, b_vec);
       }
       const float* As = lds + stage * STAGE;
       const float* Bs = As + A_ELEMS;
