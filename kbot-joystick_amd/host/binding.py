@@ -13,7 +13,7 @@ import subprocess
 from ..spec import layout as L
 
 _CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libkbj.so")
+LIB_PATH = os.path.join(_CSRC, os.environ.get("KBJ_LIB_NAME", "libkbj.so"))   # KBJ_LIB_NAME: A/B builds of the same ABI (diagnostics)
 
 
 class KbjError(RuntimeError):

@@ -146,4 +146,9 @@ void kbj_cpu_default_params(const kbj_model* m, const kbj_config* c, float* ep) 
   e.randomize();
 }
 
+// diagnostics: copy (and optionally clear) the histogram of solver iterations per forward pass
+void kbj_cpu_solver_hist(long long* out16, int clear) {
+  for (int k = 0; k < 16; ++k) { out16[k] = g_solver_hist[k]; if (clear) g_solver_hist[k] = 0; }
+}
+
 }  // extern "C"

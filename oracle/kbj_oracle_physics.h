@@ -118,6 +118,8 @@ template <class R> struct Derived {
   int solver_iters;
 };
 
+inline long long g_solver_hist[16] = {};   // diagnostics: histogram of solver iterations per forward pass (kbj_cpu_solver_hist)
+
 struct SolverOpts { int iterations = 8, ls_iterations = 8; double tolerance = 1e-8; int newton = 1; };
 
 template <class R> struct Physics {
@@ -602,6 +604,7 @@ template <class R> struct Physics {
     solve_M(d, d.qfrc_smooth, d.qacc_smooth);
     make_constraints(qpos, qvel, d);
     solve(d, warm);
+    __atomic_fetch_add(&g_solver_hist[d.solver_iters < 15 ? d.solver_iters : 15], 1LL, __ATOMIC_RELAXED);
     sensors(d);
   }
 
