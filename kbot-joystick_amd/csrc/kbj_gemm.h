@@ -32,6 +32,9 @@ struct GemmArgs {
   int splitk;           // >1: slices of K, results atomically added into C
   const int* a_rows;    // unused (reserved)
   int ipw = 1;          // work items per workgroup (set by gemm_launch)
+  // optional second source along k (k-contiguous operands only, k1 a multiple of 32, no split-K): for k >= k1 the operands are
+  // A2[m][k - k1], B2[n][k - k1] with the same leading dimensions, i.e. C = [A | A2] [B | B2]^T without materialising the concatenation
+  const float* A2 = nullptr; const float* B2 = nullptr; int k1 = 0;
 };
 
 constexpr int GEMM_BK = 32;
@@ -139,8 +142,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int item_end = min(items, item + g.ipw);
   if (item >= item_end) return;
 
-  const bool a_vec = (g.lda & 3) == 0 && (((size_t)g.A & 15) == 0);
-  const bool b_vec = (g.ldb & 3) == 0 && (((size_t)g.B & 15) == 0);
+  const bool a_vec = (g.lda & 3) == 0 && (((size_t)g.A & 15) == 0) && (((size_t)g.A2 & 15) == 0);
+  const bool b_vec = (g.ldb & 3) == 0 && (((size_t)g.B & 15) == 0) && (((size_t)g.B2 & 15) == 0);
   GemmStage<BM, A_KC> sa;
   GemmStage<BN, B_KC> sb;
   GemmItem cur = gemm_item<BM, BN>(g, item, tiles_n, tiles_m, per);
@@ -149,8 +152,21 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     cur = gemm_item<BM, BN>(g, item, tiles_n, tiles_m, per);
   }
   int stage = 0;
-  sa.load(g.A, g.lda, g.M, cur.m0, cur.kbeg, cur.kend, a_vec);
-  sb.load(g.B, g.ldb, g.N, cur.n0, cur.kbeg, cur.kend, b_vec);
+  // one k tile of both operands into the staging registers; rows_a / rows_b: all tile rows in range and vector-aligned
+  auto load_tile = [&](const GemmItem& it, int k, bool rows_a, bool rows_b) {
+    const float *pa = g.A, *pb = g.B;
+    int kk = k, ke = it.kend;
+    if (g.k1 > 0) {
+      if (k >= g.k1) { pa = g.A2; pb = g.B2; kk = k - g.k1; ke = g.K - g.k1; }
+      else ke = g.k1;
+    }
+    const bool kfull = kk + GEMM_BK <= ke;
+    if (rows_a && kfull) sa.load_fast(pa, g.lda, it.m0, kk);
+    else sa.load(pa, g.lda, g.M, it.m0, kk, ke, a_vec);
+    if (rows_b && kfull) sb.load_fast(pb, g.ldb, it.n0, kk);
+    else sb.load(pb, g.ldb, g.N, it.n0, kk, ke, b_vec);
+  };
+  load_tile(cur, cur.kbeg, false, false);
   sa.store(lds); sb.store(lds + A_ELEMS);
   __syncthreads();
 
@@ -177,19 +193,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     for (int k0 = cur.kbeg; k0 < cur.kend; k0 += GEMM_BK) {
       const bool more = k0 + GEMM_BK < cur.kend;
       const bool pre = more || have_next;
-      if (more) {  // next k tile of this item in flight during this tile's MFMAs
-        const bool kfull = k0 + 2 * GEMM_BK <= cur.kend;
-        if (rows_a_cur && kfull) sa.load_fast(g.A, g.lda, cur.m0, k0 + GEMM_BK);
-        else sa.load(g.A, g.lda, g.M, cur.m0, k0 + GEMM_BK, cur.kend, a_vec);
-        if (rows_b_cur && kfull) sb.load_fast(g.B, g.ldb, cur.n0, k0 + GEMM_BK);
-        else sb.load(g.B, g.ldb, g.N, cur.n0, k0 + GEMM_BK, cur.kend, b_vec);
-      } else if (have_next) {  // first k tile of the next item
-        const bool kfull = nxt.kbeg + GEMM_BK <= nxt.kend;
-        if (rows_a_nxt && kfull) sa.load_fast(g.A, g.lda, nxt.m0, nxt.kbeg);
-        else sa.load(g.A, g.lda, g.M, nxt.m0, nxt.kbeg, nxt.kend, a_vec);
-        if (rows_b_nxt && kfull) sb.load_fast(g.B, g.ldb, nxt.n0, nxt.kbeg);
-        else sb.load(g.B, g.ldb, g.N, nxt.n0, nxt.kbeg, nxt.kend, b_vec);
-      }
+      if (more) load_tile(cur, k0 + GEMM_BK, rows_a_cur, rows_b_cur);        // next k tile of this item in flight during this tile's MFMAs
+      else if (have_next) load_tile(nxt, nxt.kbeg, rows_a_nxt, rows_b_nxt);  // first k tile of the next item
       const float* As = lds + stage * STAGE;
       const float* Bs = As + A_ELEMS;
       // MFMA over the 32-wide k tile: 4 groups of 8 k; lane half lh owns k = 8 kk + 4 lh + e. The prefetched tile goes to the

@@ -301,8 +301,11 @@ void policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo,
     for (int l = 0; l < 2; ++l) {
       float* h = hc[n] + (size_t)(2 * l) * N * H + (size_t)n0 * H;
       float* cc = hc[n] + (size_t)(2 * l + 1) * N * H + (size_t)n0 * H;
-      linear_fwd(s, x, H, params_d + o.w_ih[l], H, params_d + o.b[l], G, 4 * H, cnt, 4 * H, H, 0);
-      linear_fwd(s, h, H, params_d + o.w_hh[l], H, nullptr, G, 4 * H, cnt, 4 * H, H, 1);
+      {  // gates = [x | h] [W_ih | W_hh]^T + b as ONE launch over the concatenated contraction (no read-modify-write of G)
+        GemmArgs g{x, params_d + o.w_ih[l], G, params_d + o.b[l], cnt, 4 * H, 2 * H, H, H, 4 * H, 0, 1, nullptr};
+        g.A2 = h; g.B2 = params_d + o.w_hh[l]; g.k1 = H;
+        gemm_launch<true, true>(s, g);
+      }
       CellFwdArgs2 ca;
       ca.a[0] = CellFwdArgs{G, cc, h, cc, nullptr, nullptr, nullptr, nullptr, cnt, H};
       hipLaunchKernelGGL(lstm_cell_fwd_kernel, dim3((cnt * H + 255) / 256, 1), dim3(256), 0, s, ca);

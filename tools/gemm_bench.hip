@@ -56,6 +56,33 @@ int main() {
   run<true, false>("check dx small", 300, 200, 100, 1, -1, A, B, C, true);
   run<false, false>("check dW small", 200, 136, 3000, 4, -1, A, B, C, true);
   run<false, false>("check dW big-tile", 256, 256, 3000, 4, 1, A, B, C, true);
+  {  // two k sources: C = [A | A2] [B | B2]^T must equal the single-source product over the concatenation
+    int M = 500, N = 300, K1 = 64, K2 = 96;
+    std::vector<float> hA((size_t)M * (K1 + K2)), hB((size_t)N * (K1 + K2)), hC((size_t)M * N);
+    for (auto& v : hA) v = (float)((rand() & 0xFFFF) - 32768) / 32768.0f;
+    for (auto& v : hB) v = (float)((rand() & 0xFFFF) - 32768) / 32768.0f;
+    // device copies: A1 [M][K1] ld 96, A2 [M][K2] ld 96 (same ld), B likewise
+    std::vector<float> a1((size_t)M * 96), a2((size_t)M * 96), b1((size_t)N * 96), b2((size_t)N * 96);
+    for (int m = 0; m < M; ++m) { for (int k = 0; k < K1; ++k) a1[(size_t)m * 96 + k] = hA[(size_t)m * 160 + k]; for (int k = 0; k < K2; ++k) a2[(size_t)m * 96 + k] = hA[(size_t)m * 160 + K1 + k]; }
+    for (int n = 0; n < N; ++n) { for (int k = 0; k < K1; ++k) b1[(size_t)n * 96 + k] = hB[(size_t)n * 160 + k]; for (int k = 0; k < K2; ++k) b2[(size_t)n * 96 + k] = hB[(size_t)n * 160 + K1 + k]; }
+    float *dA1 = A, *dA2 = A + (size_t)M * 96, *dB1 = B, *dB2 = B + (size_t)N * 96;
+    CK(hipMemcpy(dA1, a1.data(), a1.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dA2, a2.data(), a2.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB1, b1.data(), b1.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(dB2, b2.data(), b2.size() * 4, hipMemcpyHostToDevice));
+    GemmArgs g{dA1, dB1, C, nullptr, M, N, K1 + K2, 96, 96, N, 0, 1, nullptr};
+    g.A2 = dA2; g.B2 = dB2; g.k1 = K1;
+    gemm_launch<true, true>(0, g);
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int m = 0; m < M; m += 7) for (int n = 0; n < N; n += 5) {
+      double s = 0;
+      for (int k = 0; k < K1 + K2; ++k) s += (double)hA[(size_t)m * 160 + k] * hB[(size_t)n * 160 + k];
+      maxerr = std::fmax(maxerr, std::fabs(s - hC[(size_t)m * N + n]) / (1 + std::fabs(s)));
+    }
+    printf("check two k sources         M=%6d N=%5d K=%3d+%3d  maxrelerr %.2e\n", M, N, K1, K2, maxerr);
+    for (size_t i = 0; i < big; ++i) h[i] = (float)((rand() & 0xFFFF) - 32768) / 32768.0f;
+    CK(hipMemcpy(A, h.data(), big * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B, h.data() + 777, (big - 777) * 4, hipMemcpyHostToDevice));
+  }
   run<true, true>("fwd ih (R x 4H x H)", 51200, 1024, 256, 1, -1, A, B, C, true);
   run<true, true>("fwd in critic (R x H x 475)", 51200, 256, 475, 1, -1, A, B, C, false);
   run<true, false>("dx (R x H x 4H)", 51200, 256, 1024, 1, -1, A, B, C, true);
