@@ -35,6 +35,9 @@ struct GemmArgs {
   // optional second source along k (k-contiguous operands only, k1 a multiple of 32, no split-K): for k >= k1 the operands are
   // A2[m][k - k1], B2[n][k - k1] with the same leading dimensions, i.e. C = [A | A2] [B | B2]^T without materialising the concatenation
   const float* A2 = nullptr; const float* B2 = nullptr; int k1 = 0;
+  // optional second problem along n (n1 a multiple of the tile width): output columns n >= n1 use B2 (same ldb) and go to
+  // C2[m][n - n1] (same ldc) — two products that share A in one launch, so neighbouring workgroups share the A panel in L2
+  float* C2 = nullptr; int n1 = 0;
 };
 
 constexpr int GEMM_BK = 32;
@@ -109,7 +112,7 @@ struct GemmStage {
 };
 
 // work item -> output tile and k range (n tile fastest, then m tile, then k slice)
-struct GemmItem { int m0, n0, kbeg, kend, ks; };
+struct GemmItem { int m0, n0, kbeg, kend, ks; const float* B; float* C; int ncols; };   // n0, ncols: local to the (B, C) problem
 template <int BM, int BN>
 __device__ __forceinline__ GemmItem gemm_item(const GemmArgs& g, int item, int tiles_n, int tiles_m, int per) {
   GemmItem it;
@@ -117,6 +120,11 @@ __device__ __forceinline__ GemmItem gemm_item(const GemmArgs& g, int item, int t
   int tm = r % tiles_m;
   it.ks = r / tiles_m;
   it.m0 = tm * BM; it.n0 = tn * BN;
+  it.B = g.B; it.C = g.C; it.ncols = g.N;
+  if (g.n1 > 0) {
+    if (it.n0 >= g.n1) { it.B = g.B2; it.C = g.C2; it.n0 -= g.n1; it.ncols = g.N - g.n1; }
+    else it.ncols = g.n1;
+  }
   it.kbeg = it.ks * per;
   it.kend = min(g.K, it.kbeg + per);
   return it;
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   if (item >= item_end) return;
 
   const bool a_vec = (g.lda & 3) == 0 && (((size_t)g.A & 15) == 0) && (((size_t)g.A2 & 15) == 0);
-  const bool b_vec = (g.ldb & 3) == 0 && (((size_t)g.B & 15) == 0) && (((size_t)g.B2 & 15) == 0);
+  const bool b_vec = (g.ldb & 3) == 0 && (((size_t)g.B & 15) == 0) && (((size_t)g.B2 & 15) == 0);   // B2 null or aligned
   GemmStage<BM, A_KC> sa;
   GemmStage<BN, B_KC> sb;
   GemmItem cur = gemm_item<BM, BN>(g, item, tiles_n, tiles_m, per);
@@ -154,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   int stage = 0;
   // one k tile of both operands into the staging registers; rows_a / rows_b: all tile rows in range and vector-aligned
   auto load_tile = [&](const GemmItem& it, int k, bool rows_a, bool rows_b) {
-    const float *pa = g.A, *pb = g.B;
+    const float *pa = g.A, *pb = it.B;
     int kk = k, ke = it.kend;
     if (g.k1 > 0) {
       if (k >= g.k1) { pa = g.A2; pb = g.B2; kk = k - g.k1; ke = g.K - g.k1; }
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     if (rows_a && kfull) sa.load_fast(pa, g.lda, it.m0, kk);
     else sa.load(pa, g.lda, g.M, it.m0, kk, ke, a_vec);
     if (rows_b && kfull) sb.load_fast(pb, g.ldb, it.n0, kk);
-    else sb.load(pb, g.ldb, g.N, it.n0, kk, ke, b_vec);
+    else sb.load(pb, g.ldb, it.ncols, it.n0, kk, ke, b_vec);
   };
   load_tile(cur, cur.kbeg, false, false);
   sa.store(lds); sb.store(lds + A_ELEMS);
@@ -188,8 +196,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
     // interior tiles take straight-line vector loads, decided per operand and per k tile (a ragged last k tile or an
     // unaligned operand, e.g. the 475-wide critic input projection, only slows the loads it touches)
-    const bool rows_a_cur = a_vec && cur.m0 + BM <= g.M, rows_b_cur = b_vec && cur.n0 + BN <= g.N;
-    const bool rows_a_nxt = have_next && a_vec && nxt.m0 + BM <= g.M, rows_b_nxt = have_next && b_vec && nxt.n0 + BN <= g.N;
+    const bool rows_a_cur = a_vec && cur.m0 + BM <= g.M, rows_b_cur = b_vec && cur.n0 + BN <= cur.ncols;
+    const bool rows_a_nxt = have_next && a_vec && nxt.m0 + BM <= g.M, rows_b_nxt = have_next && b_vec && nxt.n0 + BN <= nxt.ncols;
     for (int k0 = cur.kbeg; k0 < cur.kend; k0 += GEMM_BK) {
       const bool more = k0 + GEMM_BK < cur.kend;
       const bool pre = more || have_next;
@@ -238,13 +246,13 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         int n = cur.n0 + wc * 32 * NT + 32 * j + lr;
-        if (n >= g.N) continue;
+        if (n >= cur.ncols) continue;
         float bv = (g.bias && cur.ks == 0) ? g.bias[n] : 0.0f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           int m = cur.m0 + wr * 32 * MT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m >= g.M) continue;
-          float* c = g.C + (size_t)m * g.ldc + n;
+          float* c = cur.C + (size_t)m * g.ldc + n;
           float v = acc[i][j][r] + bv;
 #ifdef KBJ_GEMM_NOSTORE   // timing experiment only (tools/gemm_bench): keep the MFMAs live, drop the write-back
           if (v == 1.2345e-30f) *c = v;

@@ -141,6 +141,23 @@ void linear_bwd_weight(hipStream_t s, const float* dy, int lddy, const float* x,
   gemm_launch<false, false>(s, g, big ? 1 : 0);
 }
 
+// two weight gradients that share dy in one launch: dW1 += dy^T x1, dW2 += dy^T x2 (x1, x2 [R][Nin] with the same ld)
+void linear_bwd_weight2(hipStream_t s, const float* dy, int lddy, const float* x1, const float* x2, int ldx, float* dW1, float* dW2, int lddw, int Nout, int Nin, int R) {
+  bool big = Nout >= 128 && Nin >= 128;
+  int ts = big ? 128 : 64;
+  if (Nin % ts != 0) {  // the column split must fall on a tile boundary
+    linear_bwd_weight(s, dy, lddy, x1, ldx, dW1, lddw, Nout, Nin, R);
+    linear_bwd_weight(s, dy, lddy, x2, ldx, dW2, lddw, Nout, Nin, R);
+    return;
+  }
+  int tiles = ((Nout + ts - 1) / ts) * (2 * Nin / ts);
+  int sk = std::max(2, std::min(256, 768 / std::max(1, tiles)));
+  sk = std::max(2, std::min(sk, (R + 255) / 256));
+  GemmArgs g{dy, x1, dW1, nullptr, Nout, 2 * Nin, R, lddy, ldx, lddw, 1, sk, nullptr};
+  g.B2 = x2; g.C2 = dW2; g.n1 = Nin;
+  gemm_launch<false, false>(s, g, big ? 1 : 0);
+}
+
 template <int H> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a) {
   int grid = (H / SEQ_UNITS) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
   hipLaunchKernelGGL((lstm_seq_fwd_kernel<H>), dim3(grid), dim3(256), 0, s, a);
@@ -569,8 +586,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       if (!one_stream) fork_side();
       const float* xin = l == 0 ? t.X0 : t.Hout[0];
       linear_bwd_input(s, dG, 4 * H, params_d + o.w_ih[l], H, dx_out, H, R, H, 4 * H, 0);
-      linear_bwd_weight(ws, dG, 4 * H, t.Hm[l], H, grad_d + o.w_hh[l], H, 4 * H, H, R);
-      linear_bwd_weight(ws, dG, 4 * H, xin, H, grad_d + o.w_ih[l], H, 4 * H, H, R);
+      linear_bwd_weight2(ws, dG, 4 * H, t.Hm[l], xin, H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
       std::swap(dh_above, dx_out);
     }
     // input projection (dh_above now holds dX0)
