@@ -540,7 +540,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
-  hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[0].Out, w.tb[0].obs, w.keep, w.lpf0, w.joint_bias_d, hp, T, B, w.y, w.sd);
+  hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.tb[0].obs, w.joint_bias_d, hp, R, w.y, w.sd);
+  hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0, hp, T, B, w.y);
   hipLaunchKernelGGL(gaussian_logp_kernel, g1(R), dim3(256), 0, s, w.y, w.sd, w.act, R, w.logp, w.ent);
   hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, s, w.tb[1].Out, 40, R, w.value);
   // ---- loss ----
@@ -548,19 +549,21 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, s, w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
                      w.stats + 2);
   if (w.mirror) {   // aux losses between each net and its mirror branch (train.py:1463-1481)
-    hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[2].Out, w.tb[2].obs, w.keep, w.lpf0_m, w.joint_bias_d, hp, T, B, w.y_m, w.sd_m);
+    hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[2].Out, w.tb[2].obs, w.joint_bias_d, hp, R, w.y_m, w.sd_m);
+    hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0_m, hp, T, B, w.y_m);
     hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, s, w.tb[3].Out, 40, R, w.value_m);
     hipLaunchKernelGGL(mirror_loss_kernel, g1(R), dim3(256), 0, s, w.y, w.y_m, w.value, w.value_m, c.actor_mirror_loss_scale, c.critic_mirror_loss_scale, R, w.dy, w.dy_m,
                        w.dvalue, w.dvalue_m, w.stats + 2);
   }
   hipLaunchKernelGGL(ppo_metrics_kernel, dim3(1), dim3(1), 0, s, w.stats + 2, w.stats, pp, R, metrics_d);
   // ---- backward ---- (dOut needs no clearing: the actor head writes all 40 columns, the critic's GEMMs read column 0 only)
-  hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[0].Out, w.y, w.sd, w.act, w.keep, w.dlogp,
-                     w.mirror ? w.dy : (const float*)nullptr, -c.entropy_coef / (float)R, hp, T, B, w.tb[0].dOut);
+  hipLaunchKernelGGL(actor_head_bwd_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.y, w.sd, w.act, w.dlogp,
+                     w.mirror ? w.dy : (const float*)nullptr, -c.entropy_coef / (float)R, hp, R, w.tb[0].dOut);
+  hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, hp, T, B, w.tb[0].dOut);
   KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[1].dOut, 40 * sizeof(float), w.dvalue, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, s));
   if (w.mirror) {   // the mirror actor only sees the aux gradient on its filtered mean (no log-prob, no entropy term)
-    hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.tb[2].Out, w.y_m, w.sd_m, w.y_m, w.keep, w.zeroR,
-                       w.dy_m, 0.0f, hp, T, B, w.tb[2].dOut);
+    hipLaunchKernelGGL(actor_head_bwd_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[2].Out, w.y_m, w.sd_m, w.y_m, w.zeroR, w.dy_m, 0.0f, hp, R, w.tb[2].dOut);
+    hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, hp, T, B, w.tb[2].dOut);
     KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[3].dOut, 40 * sizeof(float), w.dvalue_m, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, s));
   }
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));

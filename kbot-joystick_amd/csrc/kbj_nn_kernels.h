@@ -148,35 +148,36 @@ __global__ void gather_keep_kernel(const float* __restrict__ aux, const int* __r
 
 // ---- actor head over a minibatch trajectory: per (b, j) thread scans time (low-pass filter recursion) --------------
 // out [T][B][40], obs [T][B][68], act [T][B][20], keep [T][B], lpf0 [B][20] -> y [T][B][20] (filtered mean), std [T][B][20]
-__global__ void actor_head_train_fwd_kernel(const float* __restrict__ out, const float* __restrict__ obs, const float* __restrict__ keep,
-                                            const float* __restrict__ lpf0, const float* __restrict__ joint_bias, HeadParams hp, int T, int B,
-                                            float* __restrict__ y, float* __restrict__ sd) {
+// stage 1 (parallel over all T*B*20 elements): unfiltered mean -> y, std -> sd
+__global__ void actor_head_pre_kernel(const float* __restrict__ out, const float* __restrict__ obs, const float* __restrict__ joint_bias, HeadParams hp,
+                                      int R, float* __restrict__ y, float* __restrict__ sd) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * KBJ_NU) return;
+  size_t r = i / KBJ_NU;
+  int j = (int)(i - r * KBJ_NU);
+  y[i] = out[r * 40 + j] + joint_bias[j] + (j >= 10 ? obs[r * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
+  sd[i] = fminf((softplusf_(out[r * 40 + KBJ_NU + j]) + hp.min_std) * hp.var_scale, hp.max_std);
+}
+// stage 2 (one thread per (b, j), serial in t): one-pole low-pass over the means in place, state reset where done
+__global__ void actor_head_train_fwd_kernel(const float* __restrict__ keep, const float* __restrict__ lpf0, HeadParams hp, int T, int B, float* __restrict__ y) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * KBJ_NU) return;
   int b = i / KBJ_NU, j = i % KBJ_NU;
   float state = lpf0[i];
-  const float jb = joint_bias[j];
-  constexpr int U = 8;   // the filter recursion is serial in t, its inputs are not: fetch U steps, then run the U dependent updates
+  constexpr int U = 10;   // the recursion is serial in t, its inputs are not: fetch U steps, then run the U dependent updates
   for (int t0 = 0; t0 < T; t0 += U) {
-    float mean[U], kp[U], sdv[U];
+    float mean[U], kp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int t = t0 + u;
-      if (t < T) {
-        size_t r = (size_t)t * B + b;
-        mean[u] = out[r * 40 + j] + jb + (j >= 10 ? obs[r * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
-        kp[u] = keep[r];
-        sdv[u] = out[r * 40 + KBJ_NU + j];
-      }
+      if (t < T) { size_t r = (size_t)t * B + b; mean[u] = y[r * KBJ_NU + j]; kp[u] = keep[r]; }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int t = t0 + u;
       if (t < T) {
-        size_t r = (size_t)t * B + b;
         float yy = state + hp.alpha * (mean[u] - state);
-        y[r * KBJ_NU + j] = yy;
-        sd[r * KBJ_NU + j] = fminf((softplusf_(sdv[u]) + hp.min_std) * hp.var_scale, hp.max_std);
+        y[((size_t)t * B + b) * KBJ_NU + j] = yy;
         state = yy * kp[u];
       }
     }
@@ -299,38 +300,43 @@ __global__ void mirror_loss_kernel(const float* __restrict__ y, const float* __r
 
 // actor head backward: per (b, j) thread, reverse scan through the low-pass recursion.
 // dL/dlogp [T][B] and the constant entropy coefficient (+ an optional direct gradient on y) -> dOut [T][B][40]
-__global__ void actor_head_train_bwd_kernel(const float* __restrict__ out, const float* __restrict__ y, const float* __restrict__ sd,
-                                            const float* __restrict__ act, const float* __restrict__ keep, const float* __restrict__ dlogp,
-                                            const float* __restrict__ dy_extra, float dent, HeadParams hp, int T, int B, float* __restrict__ dout) {
+// stage 1 (parallel over all T*B*20 elements): gradient wrt the pre-activation std -> dout[.., 20 + j]; direct gradient wrt the
+// filtered mean y (log-prob term + optional aux term) -> dout[.., j] (turned into the pre-filter gradient by stage 2)
+__global__ void actor_head_bwd_pre_kernel(const float* __restrict__ out, const float* __restrict__ y, const float* __restrict__ sd,
+                                          const float* __restrict__ act, const float* __restrict__ dlogp, const float* __restrict__ dy_extra, float dent,
+                                          HeadParams hp, int R, float* __restrict__ dout) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)R * KBJ_NU) return;
+  size_t r = i / KBJ_NU;
+  int j = (int)(i - r * KBJ_NU);
+  float s = sd[i], z = (act[i] - y[i]) / s;
+  float gl = dlogp[r];
+  dout[r * 40 + j] = gl * (z / s) + (dy_extra ? dy_extra[i] : 0.0f);
+  float gs = gl * ((z * z - 1.0f) / s) + dent / s;
+  float raw = out[r * 40 + KBJ_NU + j];
+  float pre = (softplusf_(raw) + hp.min_std) * hp.var_scale;
+  dout[r * 40 + KBJ_NU + j] = pre < hp.max_std ? gs * hp.var_scale * sigmoidf_(raw) : 0.0f;
+}
+// stage 2 (one thread per (b, j), reverse scan through the low-pass recursion), in place on dout[.., j]
+__global__ void actor_head_train_bwd_kernel(const float* __restrict__ keep, HeadParams hp, int T, int B, float* __restrict__ dout) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * KBJ_NU) return;
   int b = i / KBJ_NU, j = i % KBJ_NU;
   float gcarry = 0;  // gradient wrt the filter state entering step t+1 (before the keep mask of step t)
-  constexpr int U = 8;   // only gcarry is serial in t: everything else of U steps is fetched and evaluated first
+  constexpr int U = 10;
   for (int t1 = T - 1; t1 >= 0; t1 -= U) {
     float gdir[U], kp[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int t = t1 - u;
-      if (t >= 0) {
-        size_t r = (size_t)t * B + b;
-        float s = sd[r * KBJ_NU + j], z = (act[r * KBJ_NU + j] - y[r * KBJ_NU + j]) / s;
-        float gl = dlogp[r];
-        gdir[u] = gl * (z / s) + (dy_extra ? dy_extra[r * KBJ_NU + j] : 0.0f);
-        kp[u] = keep[r];
-        float gs = gl * ((z * z - 1.0f) / s) + dent / s;
-        float raw = out[r * 40 + KBJ_NU + j];
-        float pre = (softplusf_(raw) + hp.min_std) * hp.var_scale;
-        dout[r * 40 + KBJ_NU + j] = pre < hp.max_std ? gs * hp.var_scale * sigmoidf_(raw) : 0.0f;
-      }
+      if (t >= 0) { size_t r = (size_t)t * B + b; gdir[u] = dout[r * 40 + j]; kp[u] = keep[r]; }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       int t = t1 - u;
       if (t >= 0) {
-        size_t r = (size_t)t * B + b;
         float gy = gdir[u] + kp[u] * gcarry;
-        dout[r * 40 + j] = hp.alpha * gy;
+        dout[((size_t)t * B + b) * 40 + j] = hp.alpha * gy;
         gcarry = (1 - hp.alpha) * gy;
       }
     }
