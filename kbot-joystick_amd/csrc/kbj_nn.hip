@@ -488,41 +488,44 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   const int R = T * B;
   KbjTimed timed(ctx, true);
   const int* idx = env_idx_d;
-  // ---- gather the minibatch ----
-  auto gather = [&](const float* src, int wdt, int lds, float* dst, int ldd) {
-    hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)R * wdt), dim3(256), 0, s, src, idx, T, N, B, wdt, lds, ldd, dst);
-  };
-  gather(tr->actor_obs_d, KBJ_LD_ACTOR, KBJ_LD_ACTOR, w.tb[0].obs, KBJ_LD_ACTOR);
-  gather(tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);
-  gather(tr->action_d, KBJ_NU, KBJ_NU, w.act, KBJ_NU);
-  gather(tr->logp_d, 1, 1, w.logp_old, 1);
-  gather(tr->value_d, 1, 1, w.val_old, 1);
-  gather(adv_d, 1, 1, w.adv, 1);
-  gather(target_d, 1, 1, w.target, 1);
-  hipLaunchKernelGGL(gather_keep_kernel, g1(R), dim3(256), 0, s, tr->aux_d, idx, T, N, B, w.keep);
-  const float* carry0[4] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d, tr->carry0_actor_mirror_hc_d, tr->carry0_critic_mirror_hc_d};
-  if (w.mirror) {
-    if (!carry0[2] || !carry0[3] || !tr->carry0_lpf_mirror_d) return kbj_fail(ctx, "kbj_ppo_grad: the mirror losses are enabled, the trajectory needs the mirror-branch carries");
-    for (int k = 0; k < 2; ++k)
-      hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)R * w.net[k].ld_obs), dim3(256), 0, s, w.tb[k].obs, w.tb[2 + k].obs, (size_t)R, w.net[k].ld_obs, w.mtab[k]);
-    hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * KBJ_NU), dim3(256), 0, s, tr->carry0_lpf_mirror_d, idx, 1, N, B, KBJ_NU, KBJ_NU, KBJ_NU, w.lpf0_m);
-  }
-  for (int n = 0; n < w.nnets; ++n)
-    for (int l = 0; l < 2; ++l) {  // carry at the start of the trajectory: T = 1 gather of [N][H] planes
-      hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * H), dim3(256), 0, s, carry0[n] + (size_t)(2 * l) * N * H, idx, 1, N, B, H, H, H, w.tb[n].Hm[l]);
-      hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * H), dim3(256), 0, s, carry0[n] + (size_t)(2 * l + 1) * N * H, idx, 1, N, B, H, H, H, w.tb[n].Cm[l]);
-    }
-  hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)B * KBJ_NU), dim3(256), 0, s, tr->carry0_lpf_d, idx, 1, N, B, KBJ_NU, KBJ_NU, KBJ_NU, w.lpf0);
-  // nothing on the forward path needs these: the advantage statistics and the cleared accumulators are ready long before the loss
-  KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), s));
-  hipLaunchKernelGGL(adv_stats_kernel, dim3(32), dim3(256), 0, s, w.adv, R, w.stats);
-  KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), s));
-  // ---- forward through time: actor on the caller's stream, critic on the context's second stream (the recurrences are
-  // latency bound, so the two nets overlap) ----
+  // ---- gather the minibatch: the large critic observation block on the critic's stream, everything else on the caller's ----
   static const bool one_stream = getenv("KBJ_ONE_STREAM") != nullptr;   // diagnostics: serialise the two nets
   hipStream_t ns[2] = {ctx->stream, one_stream ? ctx->stream : ctx->stream2};
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  auto gather = [&](hipStream_t st, const float* src, int wdt, int lds, float* dst, int ldd) {
+    hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)R * wdt), dim3(256), 0, st, src, idx, T, N, B, wdt, lds, ldd, dst);
+  };
+  gather(ns[1], tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);
+  gather(s, tr->actor_obs_d, KBJ_LD_ACTOR, KBJ_LD_ACTOR, w.tb[0].obs, KBJ_LD_ACTOR);
+  GatherSmallArgs gs{tr->action_d, tr->logp_d, tr->value_d, adv_d, target_d, tr->aux_d, w.act, w.logp_old, w.val_old, w.adv, w.target, w.keep};
+  hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R * (KBJ_NU + 5)), dim3(256), 0, s, gs, idx, T, N, B);
+  const float* carry0[4] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d, tr->carry0_actor_mirror_hc_d, tr->carry0_critic_mirror_hc_d};
+  if (w.mirror && (!carry0[2] || !carry0[3] || !tr->carry0_lpf_mirror_d))
+    return kbj_fail(ctx, "kbj_ppo_grad: the mirror losses are enabled, the trajectory needs the mirror-branch carries");
+  GatherCarryArgs gc;
+  gc.nplanes = 0;
+  for (int n = 0; n < w.nnets; ++n)
+    for (int l = 0; l < 2; ++l) {  // carry at the start of the trajectory: [N][H] planes h, c of every layer
+      gc.src[gc.nplanes] = carry0[n] + (size_t)(2 * l) * N * H; gc.dst[gc.nplanes++] = w.tb[n].Hm[l];
+      gc.src[gc.nplanes] = carry0[n] + (size_t)(2 * l + 1) * N * H; gc.dst[gc.nplanes++] = w.tb[n].Cm[l];
+    }
+  gc.nlpf = 0;
+  gc.src[gc.nplanes] = tr->carry0_lpf_d; gc.dst[gc.nplanes] = w.lpf0; gc.nlpf++;
+  if (w.mirror) { gc.src[gc.nplanes + 1] = tr->carry0_lpf_mirror_d; gc.dst[gc.nplanes + 1] = w.lpf0_m; gc.nlpf++; }
+  hipLaunchKernelGGL(gather_carry_kernel, dim3((B * H + 255) / 256, gc.nplanes + gc.nlpf), dim3(256), 0, s, gc, idx, B, H);
+  // nothing on the forward path needs these: the advantage statistics and the cleared accumulators are ready long before the loss
+  KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), s));
+  hipLaunchKernelGGL(adv_stats_kernel, dim3(32), dim3(256), 0, s, w.adv, R, w.stats);
+  KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), s));
+  // the critic's lane needs keep / carries (gathered above on the caller's stream) before its first recurrence
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream));
+  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));
+  if (w.mirror)   // mirrored observation rows: actor's on the caller's stream, critic's behind its gather
+    for (int k = 0; k < 2; ++k)
+      hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)R * w.net[k].ld_obs), dim3(256), 0, ns[k], w.tb[k].obs, w.tb[2 + k].obs, (size_t)R, w.net[k].ld_obs, w.mtab[k]);
+  // ---- forward through time: actor on the caller's stream, critic on the context's second stream (the recurrences are
+  // latency bound, so the two nets overlap) ----
   for (int n = 0; n < w.nnets; ++n) {   // nets 2, 3: the mirror branches, same weights, queued behind nets 0, 1 on the same two streams
     const NetOff& o = w.net[n & 1];
     TrainBufs& t = w.tb[n];

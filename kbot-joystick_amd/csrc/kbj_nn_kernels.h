@@ -146,6 +146,36 @@ __global__ void gather_keep_kernel(const float* __restrict__ aux, const int* __r
   keep[i] = aux[((size_t)t * N + idx[b]) * KBJ_AUX_SIZE + KBJ_AUX_DONE] != 0 ? 0.0f : 1.0f;
 }
 
+// all per-sample scalars of the minibatch in one launch: action (20 columns), old log-prob, old value, advantage, target, keep
+struct GatherSmallArgs {
+  const float *action, *logp, *value, *adv, *target, *aux;
+  float *action_o, *logp_o, *value_o, *adv_o, *target_o, *keep_o;
+};
+__global__ void gather_small_kernel(GatherSmallArgs a, const int* __restrict__ idx, int T, int N, int B) {
+  constexpr int W = KBJ_NU + 5;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)T * B * W) return;
+  size_t r = i / W;
+  int c = (int)(i - r * W), b = (int)(r % B);
+  size_t src = (r / B) * N + idx[b];
+  if (c < KBJ_NU) a.action_o[r * KBJ_NU + c] = a.action[src * KBJ_NU + c];
+  else if (c == KBJ_NU) a.logp_o[r] = a.logp[src];
+  else if (c == KBJ_NU + 1) a.value_o[r] = a.value[src];
+  else if (c == KBJ_NU + 2) a.adv_o[r] = a.adv[src];
+  else if (c == KBJ_NU + 3) a.target_o[r] = a.target[src];
+  else a.keep_o[r] = a.aux[src * KBJ_AUX_SIZE + KBJ_AUX_DONE] != 0 ? 0.0f : 1.0f;
+}
+// the carries at the start of the trajectory: up to 16 [N][H] planes and 2 [N][20] low-pass states, one launch (blockIdx.y = plane)
+struct GatherCarryArgs { const float* src[18]; float* dst[18]; int nplanes, nlpf; };
+__global__ void gather_carry_kernel(GatherCarryArgs a, const int* __restrict__ idx, int B, int H) {
+  int p = blockIdx.y;
+  int w = p < a.nplanes ? H : KBJ_NU;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * w) return;
+  int b = i / w, k = i - b * w;
+  a.dst[p][i] = a.src[p][(size_t)idx[b] * w + k];
+}
+
 // ---- actor head over a minibatch trajectory: per (b, j) thread scans time (low-pass filter recursion) --------------
 // out [T][B][40], obs [T][B][68], act [T][B][20], keep [T][B], lpf0 [B][20] -> y [T][B][20] (filtered mean), std [T][B][20]
 // stage 1 (parallel over all T*B*20 elements): unfiltered mean -> y, std -> sd
