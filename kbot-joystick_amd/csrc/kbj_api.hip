@@ -130,9 +130,9 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
   kbj_prof_ctx = nullptr;
   KBJ_HIP(ctx, hipDeviceSynchronize());
   static const char* const names[KBJ_KIND_COUNT] = {
-      "kbj::gemm_f32_kernel<2, 2, false, false>", "kbj::gemm_f32_kernel<2, 2, false, true>", "kbj::gemm_f32_kernel<2, 2, true, false>",
-      "kbj::gemm_f32_kernel<2, 2, true, true>",   "kbj::gemm_f32_kernel<1, 1, false, false>", "kbj::gemm_f32_kernel<1, 1, false, true>",
-      "kbj::gemm_f32_kernel<1, 1, true, false>",  "kbj::gemm_f32_kernel<1, 1, true, true>",   "kbj::lstm_seq_fwd_kernel", "kbj::lstm_seq_bwd_kernel", "env_step_kernel"};
+      "kbj::gemm_f32_kernel<2, 1, false, false, 2, 4>", "kbj::gemm_f32_kernel<2, 1, false, true, 2, 4>", "kbj::gemm_f32_kernel<2, 1, true, false, 2, 4>",
+      "kbj::gemm_f32_kernel<2, 1, true, true, 2, 4>",   "kbj::gemm_f32_kernel<1, 1, false, false, 2, 2>", "kbj::gemm_f32_kernel<1, 1, false, true, 2, 2>",
+      "kbj::gemm_f32_kernel<1, 1, true, false, 2, 2>",  "kbj::gemm_f32_kernel<1, 1, true, true, 2, 2>",   "kbj::lstm_seq_fwd_kernel", "kbj::lstm_seq_bwd_kernel", "env_step_kernel"};
   for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
     kbj_kernel_stat& st = ctx->kstats[k];
     if (k == KBJ_KIND_SEQ_FWD || k == KBJ_KIND_SEQ_BWD) snprintf(st.name, sizeof(st.name), "%s<%d>", names[k], ctx->cfg_h.hidden_size);

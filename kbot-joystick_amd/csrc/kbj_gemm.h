@@ -5,7 +5,8 @@
 //   y  = x W^T        (A: x [M][K] k-contig,  B: W [N][K] k-contig)      forward projections
 //   dx = dy W         (A: dy [M][K] k-contig, B: W [K][N] row-contig)    input gradients
 //   dW = dy^T x       (A: dy [K][M] row-contig, B: x [K][N] row-contig)  weight gradients (split-K + atomics)
-// Tiling: workgroup = 4 wavefronts (2x2), each wavefront owns MT x NT 32x32 accumulator tiles (64 VGPRs at 2x2);
+// Tiling: workgroup = WM x WN wavefronts, each owning MT x NT 32x32 accumulator tiles. The 128x128 tile runs on 8 wavefronts
+// (2 x 4, 64x32 each, 99 VGPRs: four waves per SIMD at two workgroups per CU), the 64x64 tile on 4 (2 x 2, 32x32 each);
 // K is consumed in 32-wide LDS tiles. k-contiguous operands sit in LDS as [row][36] (ds_read_b128 fragments,
 // conflict-free), row-contiguous ones as [k][row] (4 x ds_read_b32).
 // Pipeline: two LDS stages and one barrier per k tile — the global loads of tile k+1 are issued into registers before
@@ -43,10 +44,11 @@ struct GemmArgs {
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_LDK = 36;  // padded k stride of a k-contiguous LDS tile
 
-// one operand tile (ROWS rows x 32 k) staged through registers: 256 threads, ROWS/32 float4 each
-template <int ROWS, bool KC>
+// one operand tile (ROWS rows x 32 k) staged through registers: NTH threads, ROWS * 8 / NTH float4 each
+template <int ROWS, bool KC, int NTH>
 struct GemmStage {
-  static constexpr int NV = ROWS / 32;
+  static constexpr int NV = ROWS * 8 / NTH;
+  static constexpr int RPP = NTH / 8;        // rows per pass of a k-contiguous tile (8 threads x float4 per 32-k row)
   f32x4 v[NV];
   // interior tile (all ROWS rows and 32 k in range, 16-byte aligned rows): straight-line vector loads
   __device__ __forceinline__ void load_fast(const float* __restrict__ P, int ld, int r0, int k0) {
@@ -55,9 +57,9 @@ struct GemmStage {
       const int kq = tid & 7, rr = tid >> 3;
       const float* p = P + (size_t)(r0 + rr) * ld + k0 + 4 * kq;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(32 * i) * ld);
+      for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(RPP * i) * ld);
     } else {
-      constexpr int QPR = ROWS / 4, KROWS = 256 / QPR;
+      constexpr int QPR = ROWS / 4, KROWS = NTH / QPR;
       const int rq = tid % QPR, kr0 = tid / QPR;
       const float* p = P + (size_t)(k0 + kr0) * ld + r0 + 4 * rq;
 #pragma unroll
@@ -71,7 +73,7 @@ struct GemmStage {
       const int kq = tid & 7, rr = tid >> 3;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
-        int r = r0 + rr + 32 * i, k = k0 + 4 * kq;
+        int r = r0 + rr + RPP * i, k = k0 + 4 * kq;
         f32x4 x = {0, 0, 0, 0};
         if (r < R) {
           size_t base = (size_t)r * ld;
@@ -81,7 +83,7 @@ struct GemmStage {
         v[i] = x;
       }
     } else {
-      constexpr int QPR = ROWS / 4, KROWS = 256 / QPR;
+      constexpr int QPR = ROWS / 4, KROWS = NTH / QPR;
       const int rq = tid % QPR, kr0 = tid / QPR;
 #pragma unroll
       for (int i = 0; i < NV; ++i) {
@@ -101,9 +103,9 @@ struct GemmStage {
     if (KC) {
       const int kq = tid & 7, rr = tid >> 3;
 #pragma unroll
-      for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(lds + (rr + 32 * i) * GEMM_LDK + 4 * kq) = v[i];
+      for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(lds + (rr + RPP * i) * GEMM_LDK + 4 * kq) = v[i];
     } else {
-      constexpr int QPR = ROWS / 4, KROWS = 256 / QPR;
+      constexpr int QPR = ROWS / 4, KROWS = NTH / QPR;
       const int rq = tid % QPR, kr0 = tid / QPR;
 #pragma unroll
       for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(lds + (kr0 + KROWS * i) * (ROWS + 4) + 4 * rq) = v[i];
@@ -130,15 +132,16 @@ __device__ __forceinline__ GemmItem gemm_item(const GemmArgs& g, int item, int t
   return it;
 }
 
-template <int MT, int NT, bool A_KC, bool B_KC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
-  constexpr int BM = 64 * MT, BN = 64 * NT;
+// WM x WN wavefronts per workgroup, each owning MT x NT 32x32 accumulator tiles
+template <int MT, int NT, bool A_KC, bool B_KC, int WM = 2, int WN = 2>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NTH = 64 * WM * WN;
   constexpr int A_ELEMS = A_KC ? BM * GEMM_LDK : GEMM_BK * (BM + 4);
   constexpr int B_ELEMS = B_KC ? BN * GEMM_LDK : GEMM_BK * (BN + 4);
   constexpr int STAGE = A_ELEMS + B_ELEMS;
   extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 * STAGE floats (72 KB at 128x128: above the 64 KB static limit)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WN, wc = wave % WN;
   const int lr = lane & 31, lh = lane >> 5;
   const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
   const int sk = g.splitk > 1 ? g.splitk : 1;
@@ -152,8 +155,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
   const bool a_vec = (g.lda & 3) == 0 && (((size_t)g.A & 15) == 0) && (((size_t)g.A2 & 15) == 0);
   const bool b_vec = (g.ldb & 3) == 0 && (((size_t)g.B & 15) == 0) && (((size_t)g.B2 & 15) == 0);   // B2 null or aligned
-  GemmStage<BM, A_KC> sa;
-  GemmStage<BN, B_KC> sb;
+  GemmStage<BM, A_KC, NTH> sa;
+  GemmStage<BN, B_KC, NTH> sb;
   GemmItem cur = gemm_item<BM, BN>(g, item, tiles_n, tiles_m, per);
   while (cur.kbeg >= cur.kend) {   // empty k slice (K not a multiple of the slice length): nothing to add
     if (++item >= item_end) return;
@@ -267,14 +270,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   }
 }
 
-template <int MT, int NT, bool A_KC, bool B_KC>
+template <int MT, int NT, bool A_KC, bool B_KC, int WM = 2, int WN = 2>
 inline void gemm_launch_tile(hipStream_t s, const GemmArgs& g, int wgs) {
-  constexpr int BM = 64 * MT, BN = 64 * NT;
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
   constexpr size_t bytes = 2 * sizeof(float) * ((A_KC ? BM * GEMM_LDK : GEMM_BK * (BM + 4)) + (B_KC ? BN * GEMM_LDK : GEMM_BK * (BN + 4)));
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<MT, NT, A_KC, B_KC>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<MT, NT, A_KC, B_KC, WM, WN>),
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   (void)attr;
-  hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, A_KC, B_KC>), dim3(wgs), dim3(256), bytes, s, g);
+  hipLaunchKernelGGL((gemm_f32_kernel<MT, NT, A_KC, B_KC, WM, WN>), dim3(wgs), dim3(64 * WM * WN), bytes, s, g);
 }
 
 // host-side launcher; picks the 128x128 tile for large outputs and 64x64 when that leaves the chip underfilled, and
@@ -293,7 +296,11 @@ inline void gemm_launch(hipStream_t s, const GemmArgs& g_in, int force_big = -1)
   int wgs = (int)((items + ipw - 1) / ipw);
   wgs = (wgs + 7) / 8 * 8;
   KbjKernelTimer timer(s, KBJ_KIND_GEMM + (big ? 0 : 4) + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);
+#ifdef KBJ_GEMM_W4   // 128x128 tile on 4 wavefronts (2 x 2, each 64x64, 207 registers): 2-4 % faster only at K >= 4096
   if (big) gemm_launch_tile<2, 2, A_KC, B_KC>(s, g, wgs);
+#else                // 128x128 tile on 8 wavefronts (2 x 4, each 64x32, 99 registers): 4 waves per SIMD at two workgroups per CU
+  if (big) gemm_launch_tile<2, 1, A_KC, B_KC, 2, 4>(s, g, wgs);
+#endif
   else gemm_launch_tile<1, 1, A_KC, B_KC>(s, g, wgs);
 }
 
