@@ -110,6 +110,7 @@ typedef struct kbj_traj {
   float* carry0_actor_mirror_hc_d;   /* mirror-branch carries at the start of the trajectory (NULL when the mirror losses are off) */
   float* carry0_critic_mirror_hc_d;
   float* carry0_lpf_mirror_d;
+  float* reward_comps_d;     /* optional [T][N][12]: unscaled reward terms of the rollout (logging), or NULL */
 } kbj_traj;
 /* replaces: ksim's jitted rollout scan (vmap over envs, scan over T). Copies observation row T to row 0,
  * snapshots the carry, then T x (policy_step, env_step, carry_reset), then rewards. */

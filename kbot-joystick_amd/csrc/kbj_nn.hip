@@ -465,7 +465,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
       KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     }
   }
-  return kbj_rewards(ctx, tr->aux_d, T, tr->reward_d, nullptr);
+  return kbj_rewards(ctx, tr->aux_d, T, tr->reward_d, tr->reward_comps_d);
 }
 
 int kbj_gae(kbj_ctx* ctx, const kbj_traj* tr, float* adv_d, float* target_d) {

@@ -31,7 +31,7 @@ class Traj(C.Structure):
                 ("action_d", C.c_void_p), ("logp_d", C.c_void_p), ("value_d", C.c_void_p), ("reward_d", C.c_void_p),
                 ("carry0_actor_hc_d", C.c_void_p), ("carry0_critic_hc_d", C.c_void_p), ("carry0_lpf_d", C.c_void_p),
                 ("carry0_actor_mirror_hc_d", C.c_void_p), ("carry0_critic_mirror_hc_d", C.c_void_p),
-                ("carry0_lpf_mirror_d", C.c_void_p)]
+                ("carry0_lpf_mirror_d", C.c_void_p), ("reward_comps_d", C.c_void_p)]
 
 
 class KernelStat(C.Structure):

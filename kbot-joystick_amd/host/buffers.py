@@ -34,7 +34,7 @@ class CarryBuffers:
 class TrajBuffers:
     """One rollout's worth of trajectory arrays ([T(+1)][N][dim], time-major)."""
 
-    def __init__(self, T: int, N: int, H: int, depth: int, device, mirror: bool = False):
+    def __init__(self, T: int, N: int, H: int, depth: int, device, mirror: bool = False, reward_comps: bool = False):
         self.T, self.N = T, N
         z = lambda *s: torch.zeros(*s, device=device)
         self.actor_obs = z(T + 1, N, L.LD_ACTOR)
@@ -49,6 +49,7 @@ class TrajBuffers:
         self.carry0_lpf = z(N, L.NU)
         self.adv = z(T, N)
         self.target = z(T, N)
+        self.comps = z(T, N, 12) if reward_comps else None   # unscaled reward terms (train.py:1224-1256 order)
         mptr = [None, None, None]
         if mirror:
             self.carry0_actor_mirror_hc = z(depth, 2, N, H)
@@ -57,7 +58,7 @@ class TrajBuffers:
             mptr = [self.carry0_actor_mirror_hc.data_ptr(), self.carry0_critic_mirror_hc.data_ptr(), self.carry0_lpf_mirror.data_ptr()]
         self.c = B.Traj(T, N, self.actor_obs.data_ptr(), self.critic_obs.data_ptr(), self.aux.data_ptr(), self.action.data_ptr(),
                         self.logp.data_ptr(), self.value.data_ptr(), self.reward.data_ptr(), self.carry0_actor_hc.data_ptr(),
-                        self.carry0_critic_hc.data_ptr(), self.carry0_lpf.data_ptr(), *mptr)
+                        self.carry0_critic_hc.data_ptr(), self.carry0_lpf.data_ptr(), *mptr, self.comps.data_ptr() if reward_comps else None)
 
     @property
     def done(self) -> torch.Tensor:

@@ -62,6 +62,7 @@ class HumanoidWalkingTaskConfig:
     terrain: str = "flat"                   # "flat" | "sine" (train.py:1081 loads the "sine" scene; BASELINE configs[4])
     terrain_amplitude: float = 0.05         # metres; the surface definition is this build's own
     terrain_wavelength: float = 2.0
+    log_reward_components: bool = False     # keep the 12 unscaled reward terms of every rollout for logging (39 MB at 8192 x 100)
 
     def to_kbj(self, num_envs_local: int, env_id_offset: int = 0) -> L.Config:
         if self.batch_size <= 0 or num_envs_local % self.batch_size != 0:
@@ -131,7 +132,7 @@ class HumanoidWalkingTask:
         self.metrics = torch.zeros(10, device=self.device)
         self.mirror = config.actor_mirror_loss_scale != 0.0 or config.critic_mirror_loss_scale != 0.0
         self.carry = self.get_initial_model_carry()
-        self.traj = TrajBuffers(self.T, self.N, self.H, self.kcfg.depth, self.device, mirror=self.mirror)
+        self.traj = TrajBuffers(self.T, self.N, self.H, self.kcfg.depth, self.device, mirror=self.mirror, reward_comps=config.log_reward_components)
         self.opt_step = 0
         self.iteration = 0
         self._perm_gen = torch.Generator(device="cpu")
@@ -215,6 +216,20 @@ class HumanoidWalkingTask:
             self.carry.actor_mirror_hc.copy_(torch.from_numpy(z["actor_mirror_hc"]))
             self.carry.critic_mirror_hc.copy_(torch.from_numpy(z["critic_mirror_hc"]))
             self.carry.lpf_mirror.copy_(torch.from_numpy(z["lpf_mirror"]))
+
+    def export_actor(self, path: str):
+        """convert.py's input: the actor's leaves, joint/command order and the flat carry size (host/export.py)."""
+        from . import export
+        c = self.kcfg
+        export.export_actor(path, self.params.cpu().numpy(), self.H, c.depth, c.ctrl_dt, self.config.cutoff_frequency, c.min_std, c.max_std,
+                            c.var_scale, list(self.model_blob.joint_bias))
+
+    def reward_components(self):
+        """Mean of every unscaled reward term over the last rollout (train.py:1224-1256 order, spec/constants.REWARD_NAMES);
+        needs `log_reward_components=True` in the config (kbj_rollout then also writes the [T][N][12] terms)."""
+        if self.traj.comps is None:
+            raise B.KbjError("reward_components() needs HumanoidWalkingTaskConfig.log_reward_components=True")
+        return dict(zip(constants.REWARD_NAMES, self.traj.comps.mean(dim=(0, 1)).cpu().tolist()))
 
     @classmethod
     def launch(cls, config: HumanoidWalkingTaskConfig, num_iterations: int = 10, log_every: int = 1):

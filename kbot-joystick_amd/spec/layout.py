@@ -142,3 +142,19 @@ def param_count(hidden: int, depth: int = 2) -> tuple[int, int]:
     actor = NOBS_ACTOR * hidden + hidden + lstm + hidden * 2 * NU + 2 * NU
     critic = NOBS_CRITIC * hidden + hidden + lstm + hidden + 1
     return actor, critic
+
+
+def param_leaves(hidden_size: int, depth: int = 2):
+    """(name, shape) of every leaf of the flat parameter vector, in equinox leaf order of Model(actor, critic)
+    (include/kbj.h; train.py:847-1046; convert.py:44-46 takes `model.actor`)."""
+    H, leaves = hidden_size, []
+    for net, nin, nout in (("actor", NOBS_ACTOR, 2 * NU), ("critic", NOBS_CRITIC, 1)):
+        leaves.append((f"{net}.input_proj.weight", (H, nin)))
+        leaves.append((f"{net}.input_proj.bias", (H,)))
+        for l in range(depth):
+            leaves.append((f"{net}.rnns.{l}.weight_ih", (4 * H, H)))
+            leaves.append((f"{net}.rnns.{l}.weight_hh", (4 * H, H)))
+            leaves.append((f"{net}.rnns.{l}.bias", (4 * H,)))
+        leaves.append((f"{net}.output_proj.weight", (nout, H)))
+        leaves.append((f"{net}.output_proj.bias", (nout,)))
+    return leaves

@@ -136,3 +136,27 @@ def test_pipelined_rollout_equals_stepwise_calls(mirror):
     os.environ.pop("KBJ_ROLLOUT_PIPELINE", None)
     for a, b, c in zip(*out):
         assert torch.equal(a, c) and torch.equal(b, c)
+
+
+def test_reward_components_and_actor_export(tmp_path):
+    """Logging / deployment side of the task: per-term reward means add up to the reward, the exported actor is the parameter prefix."""
+    import numpy as np
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
+    from kbot_joystick_amd.spec import constants
+    cfg = launch_config(num_envs=64, batch_size=32, hidden_size=64, rollout_length_seconds=0.2, robot="kbot-headless", seed=4, num_passes=1,
+                        log_reward_components=True)
+    task = HumanoidWalkingTask(cfg)
+    task.train_iteration()
+    torch.cuda.synchronize()
+    comps = task.reward_components()
+    assert list(comps) == list(constants.REWARD_NAMES) and all(np.isfinite(v) for v in comps.values())
+    scales = torch.tensor([0.2, 0.1, 0.2, 0.2, 0.2, 0.1, 0.1, 1.5, 0.1, 0.05, 0.1, 0.1], device=task.device)     # train.py:1225-1256
+    assert torch.allclose((task.traj.comps * scales).sum(-1), task.traj.reward, atol=1e-5)
+    path = tmp_path / "actor.npz"
+    task.export_actor(str(path))
+    z = np.load(path)
+    n = task.ctx.actor_param_count()
+    flat = np.concatenate([z[k].ravel() for k in z.files if k.startswith("actor.")])
+    assert flat.size == n and np.array_equal(flat, task.params[:n].cpu().numpy())
+    task.ctx.close()

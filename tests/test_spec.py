@@ -38,3 +38,27 @@ def test_blob_roundtrip(model):
     assert compiler.model_to_bytes(m2) == b
     with pytest.raises(ValueError):
         compiler.model_from_bytes(b[:-1])
+
+
+def test_actor_export_contract(tmp_path):
+    """convert.py hand-off: actor leaves in equinox order, carry size depth*2*H + 20, 16 command names."""
+    import numpy as np
+    from kbot_joystick_amd.host import export
+    from kbot_joystick_amd.spec import constants, layout as L
+    H, depth = 64, 2
+    leaves = L.param_leaves(H, depth)
+    P = sum(int(np.prod(s)) for _, s in leaves)
+    flat = np.arange(P, dtype=np.float32)
+    out = export.actor_leaves(flat, H, depth)
+    assert list(out) == [n for n, _ in leaves if n.startswith("actor.")]
+    assert out["actor.input_proj.weight"].shape == (H, 65) and out["actor.output_proj.weight"].shape == (40, H)
+    assert out["actor.input_proj.weight"][0, 0] == 0 and out["actor.input_proj.bias"][0] == H * 65      # contiguous, in order
+    n_actor = sum(v.size for v in out.values())
+    assert n_actor == 65 * H + H + depth * (8 * H * H + 4 * H) + 40 * H + 40
+    p = tmp_path / "actor.npz"
+    export.export_actor(str(p), flat, H, depth, 0.02, 10.0, 0.01, 1.0, 0.5, np.zeros(20))
+    z = np.load(p)
+    assert int(z["meta.carry_size"]) == depth * 2 * H + 20 and len(z["meta.command_names"]) == 16 and len(z["meta.joint_names"]) == 20
+    assert np.array_equal(z["actor.rnns.1.bias"], out["actor.rnns.1.bias"])
+    with pytest.raises(ValueError):
+        export.actor_leaves(flat[:-1], H, depth)
