@@ -135,7 +135,8 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
       "kbj::gemm_f32_kernel<1, 1, true, false, 2, 2>",  "kbj::gemm_f32_kernel<1, 1, true, true, 2, 2>",   "kbj::lstm_seq_fwd_kernel", "kbj::lstm_seq_bwd_kernel", "env_step_kernel"};
   for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
     kbj_kernel_stat& st = ctx->kstats[k];
-    if (k == KBJ_KIND_SEQ_FWD || k == KBJ_KIND_SEQ_BWD) snprintf(st.name, sizeof(st.name), "%s<%d>", names[k], ctx->cfg_h.hidden_size);
+    if (k == KBJ_KIND_SEQ_FWD || k == KBJ_KIND_SEQ_BWD)
+      snprintf(st.name, sizeof(st.name), "%s<%d, %d>", names[k], ctx->cfg_h.hidden_size, getenv("KBJ_SEQ_UW") ? atoi(getenv("KBJ_SEQ_UW")) : 2);
     else snprintf(st.name, sizeof(st.name), "%s", names[k]);
     st.launches = 0; st.total_ms = 0; st.flops = 0;
   }

@@ -89,15 +89,15 @@ __device__ __forceinline__ void seq_publish(unsigned* my_flag, unsigned steps_do
 }
 // payload tile: rows [r0, r0+32) x H floats of a handed-off [B][ld] array, 16-byte buffer loads with the sc1 bit
 // (aux = 16: bypass this CU's L1; counted by the compiler's s_waitcnt), then written to LDS as [32][H+4]
-template <int H> struct SeqTile {
-  static constexpr int NV = SEQ_ROWS * (H / 4) / 256;
+template <int H, int NTH> struct SeqTile {
+  static constexpr int NV = SEQ_ROWS * (H / 4) / NTH;
   f32x4m v[NV];
   __device__ __forceinline__ void load(const float* src, int ld, int r0, int B) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      int q = threadIdx.x + 256 * i, row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
+      int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
       unsigned off = (unsigned)(((size_t)(r < B ? r : 0) * ld + 4 * c4) * sizeof(float));
       u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
       v[i] = __builtin_bit_cast(f32x4m, u);
@@ -107,31 +107,35 @@ template <int H> struct SeqTile {
   __device__ __forceinline__ void to_lds(float* lds) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      int q = threadIdx.x + 256 * i, row = q / (H / 4), c4 = q % (H / 4);
+      int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4);
       *reinterpret_cast<f32x4m*>(lds + row * (H + 4) + 4 * c4) = v[i];
     }
   }
 };
 
-template <int H>
-__global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
+// UW = 1: 4 wavefronts own 16 hidden units; UW = 2: 8 wavefronts own 32 units (two 16-unit halves that share the staged h tile and
+// advance in lock step on the same SIMDs: their matrix phases queue behind each other deterministically instead of colliding at
+// random with another workgroup's, and the row group has half as many partners to wait for)
+template <int H, int UW>
+__global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
+  constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW;
   constexpr int LDH = H + 4;
-  constexpr int NUG = H / SEQ_UNITS;
+  constexpr int NUG = H / UNITS;
   __shared__ __attribute__((aligned(16))) float hs[SEQ_ROWS * LDH];
-  __shared__ float gbuf[4][SEQ_ROWS][SEQ_UNITS + 1];
+  __shared__ float gbuf[4][SEQ_ROWS][UNITS + 1];
   __shared__ int flag;
-  const int tid = threadIdx.x, lane = tid & 63, gate = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, gate = (tid >> 6) & 3, uh = tid >> 8;
   // XCD-aware mapping (speed only, the protocol is placement independent): workgroups b, b+8, b+16, ... share an XCD,
   // so give each XCD whole row groups and the tile hand-off stays inside one L2
   const int nblk = gridDim.x;
   const int lid = (nblk % 8 == 0) ? (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   const int ug = lid % NUG, rg = lid / NUG;
-  const int r0 = rg * SEQ_ROWS, u0 = ug * SEQ_UNITS;
+  const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
   // W_hh rows of this wave's gate for the 16 units, as B operands: B[k][col] = Whh[gate H + u0 + col][k]
   float wreg[H / 4];
   {
-    const float* wrow = a.Whh + (size_t)(gate * H + u0 + (lane & 15)) * H + (lane >> 4);
+    const float* wrow = a.Whh + (size_t)(gate * H + u0 + SEQ_UNITS * uh + (lane & 15)) * H + (lane >> 4);
 #pragma unroll
     for (int s = 0; s < H / 4; ++s) wreg[s] = wrow[4 * s];
   }
@@ -140,8 +144,8 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   float cm[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    int e = tid + 256 * i;
-    erow[i] = e / SEQ_UNITS; eunit[i] = e % SEQ_UNITS;
+    int e = tid + NTH * i;
+    erow[i] = e / UNITS; eunit[i] = e % UNITS;
     int r = r0 + erow[i];
     cm[i] = r < B ? a.Cm[(size_t)r * H + u0 + eunit[i]] : 0.0f;
   }
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     SEQ_STAMP(0);
     if (t > 0) { if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)t, a.err, &flag)) return; }
     SEQ_STAMP(1);
-    SeqTile<H> tile;
+    SeqTile<H, NTH> tile;
     tile.load(a.Hm + (size_t)t * B * H, H, r0, B);
     // behind the payload loads: the next step's own inputs, then the previous step's BPTT stash
     float gx[2][4], kp[2];
@@ -198,8 +202,8 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      gbuf[gate][(lane >> 4) * 4 + r][lane & 15] = acc0[r];
-      gbuf[gate][16 + (lane >> 4) * 4 + r][lane & 15] = acc1[r];
+      gbuf[gate][(lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc0[r];
+      gbuf[gate][16 + (lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc1[r];
     }
     __syncthreads();
     SEQ_STAMP(3);
@@ -230,22 +234,23 @@ __global__ __launch_bounds__(256) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   }
 }
 
-template <int H>
-__global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
+template <int H, int UW>
+__global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
+  constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW;
   constexpr int LDH = H + 4;
-  constexpr int NUG = H / SEQ_UNITS;
+  constexpr int NUG = H / UNITS;
   // one gate chunk of dG_{t+1} at a time: a single 33 KB buffer (plus pbuf) keeps the workgroup at 42 KB of LDS so that two
   // recurrences (actor + critic) AND two GEMM workgroups fit on a CU together (profiles/r01: double buffering starved the GEMMs)
   __shared__ __attribute__((aligned(16))) float ds[SEQ_ROWS * LDH];
-  __shared__ float pbuf[4][SEQ_ROWS][SEQ_UNITS + 1];                     // per-wave partial sums of dh
+  __shared__ float pbuf[4][SEQ_ROWS][UNITS + 1];                     // per-wave partial sums of dh
   __shared__ int flag;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, uh = tid >> 8;   // wave: k quarter, uh: 16-unit half
   // XCD-aware mapping (speed only, the protocol is placement independent): workgroups b, b+8, b+16, ... share an XCD,
   // so give each XCD whole row groups and the tile hand-off stays inside one L2
   const int nblk = gridDim.x;
   const int lid = (nblk % 8 == 0) ? (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
   const int ug = lid % NUG, rg = lid / NUG;
-  const int r0 = rg * SEQ_ROWS, u0 = ug * SEQ_UNITS;
+  const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
   constexpr int KW = H / 4;        // k range of one wave inside a gate chunk
   constexpr int KS = KW / 4;       // k-steps per (wave, gate chunk)
@@ -254,12 +259,12 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) wreg[c][s] = a.Whh[(size_t)(c * H + wave * KW + 4 * s + (lane >> 4)) * H + u0 + (lane & 15)];
+    for (int s = 0; s < KS; ++s) wreg[c][s] = a.Whh[(size_t)(c * H + wave * KW + 4 * s + (lane >> 4)) * H + u0 + SEQ_UNITS * uh + (lane & 15)];
   int erow[2], eunit[2];
   float dcm[2] = {0.0f, 0.0f};
   float bsum[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // running column sums of dG (bias gradient)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) { int e = tid + 256 * i; erow[i] = e / SEQ_UNITS; eunit[i] = e % SEQ_UNITS; }
+  for (int i = 0; i < 2; ++i) { int e = tid + NTH * i; erow[i] = e / UNITS; eunit[i] = e % UNITS; }
   // everything the cell derivative of a step needs (produced by earlier kernels) is fetched ONE STEP AHEAD
   float actn[2][4], tcn[2], cprevn[2], dhan[2], kpn[2];
   auto fetch_inputs = [&](int tt) {
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)(T - 1 - t), a.err, &flag)) return;
       f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
       const float* src = a.dG + (size_t)(t + 1) * B * 4 * H;
-      SeqTile<H> tile;
+      SeqTile<H, NTH> tile;
       tile.load(src, 4 * H, r0, B);
       prefetch();                               // own inputs ride behind the first payload chunk
 #pragma unroll
@@ -312,8 +317,8 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        pbuf[wave][(lane >> 4) * 4 + r][lane & 15] = acc0[r];
-        pbuf[wave][16 + (lane >> 4) * 4 + r][lane & 15] = acc1[r];
+        pbuf[wave][(lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc0[r];
+        pbuf[wave][16 + (lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc1[r];
       }
       __syncthreads();
 #pragma unroll
@@ -346,8 +351,8 @@ __global__ __launch_bounds__(256) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       pbuf[k][erow[1]][eunit[1]] = bsum[1][k];
     }
     __syncthreads();
-    if (tid < 64) {
-      int k = tid / SEQ_UNITS, u = tid % SEQ_UNITS;
+    if (tid < 4 * UNITS) {
+      int k = tid / UNITS, u = tid % UNITS;
       float s = 0;
       for (int r = 0; r < SEQ_ROWS; ++r) s += pbuf[k][r][u];
       atomicAdd(a.db + k * H + u0 + u, s);

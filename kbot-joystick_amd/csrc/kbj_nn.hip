@@ -158,21 +158,26 @@ void linear_bwd_weight2(hipStream_t s, const float* dy, int lddy, const float* x
   gemm_launch<false, false>(s, g, big ? 1 : 0);
 }
 
-template <int H> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a) {
-  int grid = (H / SEQ_UNITS) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
-  hipLaunchKernelGGL((lstm_seq_fwd_kernel<H>), dim3(grid), dim3(256), 0, s, a);
+// wavefronts per recurrence workgroup: 4 (16 hidden units) or 8 (32 units, KBJ_SEQ_UW=2, default) — see kbj_lstm_seq.h
+int g_seq_uw = 2;
+template <int H, int UW> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a) {
+  int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
+  hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
-template <int H> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a) {
-  int grid = (H / SEQ_UNITS) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
-  hipLaunchKernelGGL((lstm_seq_bwd_kernel<H>), dim3(grid), dim3(256), 0, s, a);
+template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a) {
+  int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
+  hipLaunchKernelGGL((lstm_seq_bwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
 int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {
   hipMemsetAsync(a.counters, 0, 256 * sizeof(unsigned), st);
   KbjKernelTimer timer(st, KBJ_KIND_SEQ_FWD, 2.0 * a.T * a.B * 4.0 * H * H);
-  switch (H) {
-    case 64: seq_fwd_launch<64>(st, a); break;
-    case 128: seq_fwd_launch<128>(st, a); break;
-    case 256: seq_fwd_launch<256>(st, a); break;
+  switch (H * 10 + g_seq_uw) {
+    case 641: seq_fwd_launch<64, 1>(st, a); break;
+    case 642: seq_fwd_launch<64, 2>(st, a); break;
+    case 1281: seq_fwd_launch<128, 1>(st, a); break;
+    case 1282: seq_fwd_launch<128, 2>(st, a); break;
+    case 2561: seq_fwd_launch<256, 1>(st, a); break;
+    case 2562: seq_fwd_launch<256, 2>(st, a); break;
     default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 256");
   }
   return 0;
@@ -180,10 +185,13 @@ int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {
 int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {
   hipMemsetAsync(a.counters, 0, 256 * sizeof(unsigned), st);
   KbjKernelTimer timer(st, KBJ_KIND_SEQ_BWD, 2.0 * a.T * a.B * 4.0 * H * H);
-  switch (H) {
-    case 64: seq_bwd_launch<64>(st, a); break;
-    case 128: seq_bwd_launch<128>(st, a); break;
-    case 256: seq_bwd_launch<256>(st, a); break;
+  switch (H * 10 + g_seq_uw) {
+    case 641: seq_bwd_launch<64, 1>(st, a); break;
+    case 642: seq_bwd_launch<64, 2>(st, a); break;
+    case 1281: seq_bwd_launch<128, 1>(st, a); break;
+    case 1282: seq_bwd_launch<128, 2>(st, a); break;
+    case 2561: seq_bwd_launch<256, 1>(st, a); break;
+    case 2562: seq_bwd_launch<256, 2>(st, a); break;
     default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 256");
   }
   return 0;
@@ -272,7 +280,10 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
   if (getenv("KBJ_SEQ_STAMPS")) { if (dalloc(ctx, *w, &w->seq_stamps, (size_t)T * 6)) return -1; }
   if (hipMemset(w->seq_err, 0, 4 * sizeof(unsigned)) != hipSuccess) return kbj_fail(ctx, "hipMemset seq_err");
-  if ((B + SEQ_ROWS - 1) / SEQ_ROWS * (H / SEQ_UNITS) > 256) return kbj_fail(ctx, "kbj_create: (batch_size/32)*(hidden/16) must be <= 256 (persistent LSTM kernel residency)");
+  g_seq_uw = getenv("KBJ_SEQ_UW") ? atoi(getenv("KBJ_SEQ_UW")) : 2;
+  if (g_seq_uw != 1 && g_seq_uw != 2) return kbj_fail(ctx, "KBJ_SEQ_UW must be 1 or 2");
+  if ((B + SEQ_ROWS - 1) / SEQ_ROWS * (H / (SEQ_UNITS * g_seq_uw)) > 256)
+    return kbj_fail(ctx, "kbj_create: (batch_size/32)*(hidden/(16 * wavefront groups)) must be <= 256 (persistent LSTM kernel residency)");
   return 0;
 }
 
