@@ -39,6 +39,8 @@ int kbj_destroy(kbj_ctx* ctx);
 const char* kbj_last_error(const kbj_ctx* ctx); /* ctx may be NULL: error of a failed kbj_create */
 int kbj_sizeof_model(void);
 int kbj_sizeof_config(void);
+int kbj_sizeof_traj(void);    /* sizeof(kbj_traj), sizeof(kbj_carry): let a binding verify its struct mirrors */
+int kbj_sizeof_carry(void);
 int kbj_synchronize(kbj_ctx* ctx);
 
 /* ---- environment (physics + task), SURVEY §8 rows a1-a3, a14-a22 -------------------------- */

@@ -39,6 +39,8 @@ extern "C" {
 
 int kbj_sizeof_model(void) { return (int)sizeof(kbj_model); }
 int kbj_sizeof_config(void) { return (int)sizeof(kbj_config); }
+int kbj_sizeof_traj(void) { return (int)sizeof(kbj_traj); }
+int kbj_sizeof_carry(void) { return (int)sizeof(kbj_carry); }
 
 const char* kbj_last_error(const kbj_ctx* ctx) { return ctx ? ctx->error.c_str() : kbj_global_error.c_str(); }
 

@@ -48,6 +48,8 @@ SIGNATURES = {
     "kbj_last_error": (C.c_char_p, [_vp]),
     "kbj_sizeof_model": (_i, []),
     "kbj_sizeof_config": (_i, []),
+    "kbj_sizeof_traj": (_i, []),
+    "kbj_sizeof_carry": (_i, []),
     "kbj_synchronize": (_i, [_vp]),
     "kbj_env_reset_all": (_i, [_vp, _u32, _vp, _vp, _vp]),
     "kbj_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
@@ -116,6 +118,8 @@ class Context:
         self.lib = load_library()
         if self.lib.kbj_sizeof_model() != C.sizeof(L.Model) or self.lib.kbj_sizeof_config() != C.sizeof(L.Config):
             raise KbjError("struct layout mismatch between spec/layout.py and libkbj.so")
+        if self.lib.kbj_sizeof_traj() != C.sizeof(Traj) or self.lib.kbj_sizeof_carry() != C.sizeof(Carry):
+            raise KbjError("struct layout mismatch between host/binding.py (Traj / Carry) and libkbj.so")
         self.model, self.config = model, config
         self._h = _vp()
         blob = C.string_at(C.addressof(model), C.sizeof(model))

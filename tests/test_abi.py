@@ -33,6 +33,8 @@ def test_every_declared_symbol_is_exported(lib):
 def test_struct_sizes(lib):
     assert lib.kbj_sizeof_model() == ctypes.sizeof(L.Model)
     assert lib.kbj_sizeof_config() == ctypes.sizeof(L.Config)
+    from kbot_joystick_amd.host import binding
+    assert lib.kbj_sizeof_traj() == ctypes.sizeof(binding.Traj) and lib.kbj_sizeof_carry() == ctypes.sizeof(binding.Carry)
 
 
 def test_param_counts_match_survey(lib):
