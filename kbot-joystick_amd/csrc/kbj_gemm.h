@@ -36,9 +36,10 @@ struct GemmArgs {
   // optional second source along k (k-contiguous operands only, k1 a multiple of 32, no split-K): for k >= k1 the operands are
   // A2[m][k - k1], B2[n][k - k1] with the same leading dimensions, i.e. C = [A | A2] [B | B2]^T without materialising the concatenation
   const float* A2 = nullptr; const float* B2 = nullptr; int k1 = 0;
-  // optional second problem along n (n1 a multiple of the tile width): output columns n >= n1 use B2 (same ldb) and go to
-  // C2[m][n - n1] (same ldc) — two products that share A in one launch, so neighbouring workgroups share the A panel in L2
-  float* C2 = nullptr; int n1 = 0;
+  // optional second problem along n (n1 a multiple of the tile width): output columns n >= n1 use B2 (leading dimension ldb2,
+  // 0 = ldb) and go to C2[m][n - n1] (ldc2, 0 = ldc) — two products that share A in one launch, so neighbouring workgroups share
+  // the A panel in L2
+  float* C2 = nullptr; int n1 = 0, ldb2 = 0, ldc2 = 0;
 };
 
 constexpr int GEMM_BK = 32;
@@ -114,7 +115,7 @@ struct GemmStage {
 };
 
 // work item -> output tile and k range (n tile fastest, then m tile, then k slice)
-struct GemmItem { int m0, n0, kbeg, kend, ks; const float* B; float* C; int ncols; };   // n0, ncols: local to the (B, C) problem
+struct GemmItem { int m0, n0, kbeg, kend, ks; const float* B; float* C; int ncols, ldb, ldc; };   // n0, ncols: local to the (B, C) problem
 template <int BM, int BN>
 __device__ __forceinline__ GemmItem gemm_item(const GemmArgs& g, int item, int tiles_n, int tiles_m, int per) {
   GemmItem it;
@@ -122,9 +123,13 @@ __device__ __forceinline__ GemmItem gemm_item(const GemmArgs& g, int item, int t
   int tm = r % tiles_m;
   it.ks = r / tiles_m;
   it.m0 = tm * BM; it.n0 = tn * BN;
-  it.B = g.B; it.C = g.C; it.ncols = g.N;
+  it.B = g.B; it.C = g.C; it.ncols = g.N; it.ldb = g.ldb; it.ldc = g.ldc;
   if (g.n1 > 0) {
-    if (it.n0 >= g.n1) { it.B = g.B2; it.C = g.C2; it.n0 -= g.n1; it.ncols = g.N - g.n1; }
+    if (it.n0 >= g.n1) {
+      it.B = g.B2; it.C = g.C2; it.n0 -= g.n1; it.ncols = g.N - g.n1;
+      if (g.ldb2 > 0) it.ldb = g.ldb2;
+      if (g.ldc2 > 0) it.ldc = g.ldc2;
+    }
     else it.ncols = g.n1;
   }
   it.kbeg = it.ks * per;
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
   if (item >= item_end) return;
 
   const bool a_vec = (g.lda & 3) == 0 && (((size_t)g.A & 15) == 0) && (((size_t)g.A2 & 15) == 0);
-  const bool b_vec = (g.ldb & 3) == 0 && (((size_t)g.B & 15) == 0) && (((size_t)g.B2 & 15) == 0);   // B2 null or aligned
+  const bool b_vec = (g.ldb & 3) == 0 && (g.ldb2 & 3) == 0 && (((size_t)g.B & 15) == 0) && (((size_t)g.B2 & 15) == 0);   // B2 null or aligned
   GemmStage<BM, A_KC, NTH> sa;
   GemmStage<BN, B_KC, NTH> sb;
   GemmItem cur = gemm_item<BM, BN>(g, item, tiles_n, tiles_m, per);
@@ -174,8 +179,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
     const bool kfull = kk + GEMM_BK <= ke;
     if (rows_a && kfull) sa.load_fast(pa, g.lda, it.m0, kk);
     else sa.load(pa, g.lda, g.M, it.m0, kk, ke, a_vec);
-    if (rows_b && kfull) sb.load_fast(pb, g.ldb, it.n0, kk);
-    else sb.load(pb, g.ldb, it.ncols, it.n0, kk, ke, b_vec);
+    if (rows_b && kfull) sb.load_fast(pb, it.ldb, it.n0, kk);
+    else sb.load(pb, it.ldb, it.ncols, it.n0, kk, ke, b_vec);
   };
   load_tile(cur, cur.kbeg, false, false);
   sa.store(lds); sb.store(lds + A_ELEMS);
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
         for (int r = 0; r < 16; ++r) {
           int m = cur.m0 + wr * 32 * MT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
           if (m >= g.M) continue;
-          float* c = cur.C + (size_t)m * g.ldc + n;
+          float* c = cur.C + (size_t)m * cur.ldc + n;
           float v = acc[i][j][r] + bv;
 #ifdef KBJ_GEMM_NOSTORE   // timing experiment only (tools/gemm_bench): keep the MFMAs live, drop the write-back
           if (v == 1.2345e-30f) *c = v;

@@ -373,6 +373,30 @@ __global__ void actor_head_train_bwd_kernel(const float* __restrict__ keep, Head
   }
 }
 
+// y[m] = sum_k W[m][k] x[k] + add[m]   (W [M][K] row-major; one thread per row)
+__global__ void matvec_kernel(const float* __restrict__ W, const float* __restrict__ x, const float* __restrict__ add, int M, int K, float* __restrict__ y) {
+  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= M) return;
+  float s = 0;
+  for (int k = 0; k < K; ++k) s += W[(size_t)m * K + k] * x[k];
+  y[m] = s + (add ? add[m] : 0.0f);
+}
+// y[n] += sum_k W[k][n] x[k]   (W [K][N] row-major; one thread per column, coalesced over n)
+__global__ void matvec_t_acc_kernel(const float* __restrict__ W, const float* __restrict__ x, int K, int N, float* __restrict__ y) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0;
+  for (int k = 0; k < K; ++k) s += W[(size_t)k * N + n] * x[k];
+  y[n] += s;
+}
+
+// C[m][n] += u[m] v[n]   (rank-1 update, C [M][N] row-major)
+__global__ void outer_acc_kernel(float* __restrict__ C, const float* __restrict__ u, const float* __restrict__ v, int M, int N) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)M * N) return;
+  C[i] += u[i / N] * v[i % N];
+}
+
 // column sums: out[n] (+)= sum_m X[m][n]  (bias gradients); one block per 64 columns, 256 threads = 4 row phases
 __global__ void colsum_kernel(const float* __restrict__ X, int M, int N, int ld, float* __restrict__ out) {
   __shared__ float red[4][64];
