@@ -42,7 +42,7 @@ struct NnWs {
   float *y = nullptr, *sd = nullptr, *logp = nullptr, *ent = nullptr, *value = nullptr, *dlogp = nullptr, *dvalue = nullptr, *lpf0 = nullptr;
   // actor layer 0 with the input projection folded in (the projection has no activation and 65 < H inputs):
   // W_eff = W_ih0 W_in [4H][68 (65 used)], b_eff = W_ih0 b_in + b_0; Zeff[n] = dG0^T obs of actor-type net n (n = 0, 2)
-  float *Weff = nullptr, *beff = nullptr, *Zeff[2] = {nullptr, nullptr};
+  float *Weff = nullptr, *beff = nullptr, *Zeff[4] = {nullptr, nullptr, nullptr, nullptr};
   double* stats = nullptr;  // [0..1] adv stats, [2..9] metric accumulators, [10] grad sumsq
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
@@ -280,7 +280,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->lpf0, B * KBJ_NU)) return -1;
   if (dalloc(ctx, *w, &w->stats, 16)) return -1;
   if (dalloc(ctx, *w, &w->Weff, 4 * H * KBJ_LD_ACTOR) || dalloc(ctx, *w, &w->beff, 4 * H)) return -1;
-  for (int k = 0; k < (w->mirror ? 2 : 1); ++k) if (dalloc(ctx, *w, &w->Zeff[k], 4 * H * KBJ_LD_ACTOR)) return -1;
+  for (int n = 0; n < w->nnets; ++n) if (dalloc(ctx, *w, &w->Zeff[n], 4 * H * w->net[n & 1].ld_obs)) return -1;
   if (hipMemset(w->Weff, 0, 4 * H * KBJ_LD_ACTOR * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset Weff");
   if (dalloc(ctx, *w, &w->seq_counters, 1024)) return -1;
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
@@ -544,6 +544,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // ---- forward through time: actor on the caller's stream, critic on the context's second stream (the recurrences are
   // latency bound, so the two nets overlap) ----
   static const bool fold_actor = getenv("KBJ_FOLD_ACTOR") ? atoi(getenv("KBJ_FOLD_ACTOR")) != 0 : true;
+  static const bool fold_critic = getenv("KBJ_FOLD_CRITIC") ? atoi(getenv("KBJ_FOLD_CRITIC")) != 0 : false;   // backward only (475 > H inputs)
   if (fold_actor) {
     // The actor's input projection (65 -> H, no activation) feeds only layer 0's input GEMM, so gates_0 = obs (W_ih0 W_in)^T +
     // (W_ih0 b_in + b_0): a 65-deep contraction instead of 65 -> H -> 4H (6.8 instead of 28.5 GFLOP per minibatch forward, and
@@ -552,7 +553,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, KBJ_LD_ACTOR, 0, 1, nullptr};
     gemm_launch<true, false>(s, g);
     hipLaunchKernelGGL(matvec_kernel, g1(4 * H), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
-    for (int k = 0; k < (w.mirror ? 2 : 1); ++k) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[k], 0, (size_t)4 * H * KBJ_LD_ACTOR * sizeof(float), s));
+    for (int n = 0; n < w.nnets; ++n) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), s));
   }
   for (int n = 0; n < w.nnets; ++n) {   // nets 2, 3: the mirror branches, same weights, queued behind nets 0, 1 on the same two streams
     const NetOff& o = w.net[n & 1];
@@ -621,17 +622,19 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       if (seq_bwd(ctx, s, H, ba)) return -1;
       if (!one_stream) fork_side();
       const float* xin = l == 0 ? t.X0 : t.Hout[0];
-      if (fold_actor && (n & 1) == 0 && l == 0) {
-        // folded layer 0: dW_hh0 += dG0^T Hm and Z = dG0^T obs in one launch, then the two small products that carry Z back to the
-        // stored parameters: dW_in += W_ih0^T Z, dW_ih0 += Z W_in^T (db_in follows from db_0 at the end). No dX0.
-        float* Z = w.Zeff[n >> 1];
-        int sk = std::max(2, std::min(768 / ((4 * H / 128) * (H / 128 + 1)), (R + 255) / 256));
+      if (fold_actor && l == 0 && ((n & 1) == 0 || fold_critic)) {
+        // layer 0 backwards through the (activation-free) input projection without dX0: dW_hh0 += dG0^T Hm and Z = dG0^T obs in
+        // one launch, then two small products carry Z back to the stored parameters: dW_in += W_ih0^T Z, dW_ih0 += Z W_in^T
+        // (the bias terms follow from db_0 at the end). Critic: 50 instead of 66 GFLOP and no dX0 GEMM on the critical path.
+        float* Z = w.Zeff[n];
+        const int ts = H >= 128 ? 128 : 64;
+        int sk = std::max(2, std::min(768 / ((4 * H / ts) * (H / ts + (o.nin + ts - 1) / ts)), (R + 255) / 256));
         GemmArgs g{dG, t.Hm[0], grad_d + o.w_hh[0], nullptr, 4 * H, H + o.nin, R, 4 * H, H, H, 1, sk, nullptr};
-        g.B2 = t.obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = KBJ_LD_ACTOR;
+        g.B2 = t.obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = o.ld_obs;
         gemm_launch<false, false>(ws, g, H >= 128 ? 1 : 0);
-        GemmArgs g1a{params_d + o.w_ih[0], Z, grad_d + o.w_in, nullptr, H, o.nin, 4 * H, H, KBJ_LD_ACTOR, o.nin, 1, 1, nullptr};
+        GemmArgs g1a{params_d + o.w_ih[0], Z, grad_d + o.w_in, nullptr, H, o.nin, 4 * H, H, o.ld_obs, o.nin, 1, 1, nullptr};
         gemm_launch<false, false>(ws, g1a);
-        GemmArgs g2a{Z, params_d + o.w_in, grad_d + o.w_ih[0], nullptr, 4 * H, H, o.nin, KBJ_LD_ACTOR, o.nin, H, 1, 1, nullptr};
+        GemmArgs g2a{Z, params_d + o.w_in, grad_d + o.w_ih[0], nullptr, 4 * H, H, o.nin, o.ld_obs, o.nin, H, 1, 1, nullptr};
         gemm_launch<true, true>(ws, g2a);
         continue;
       }
@@ -639,7 +642,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       linear_bwd_weight2(ws, dG, 4 * H, t.Hm[l], xin, H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
       std::swap(dh_above, dx_out);
     }
-    if (!(fold_actor && (n & 1) == 0)) {   // input projection (dh_above now holds dX0)
+    if (!(fold_actor && ((n & 1) == 0 || fold_critic))) {   // input projection (dh_above now holds dX0)
       linear_bwd_weight(s, dh_above, H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
       hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, 64), dim3(256), 0, s, dh_above, R, H, H, grad_d + o.b_in);
     }
@@ -647,11 +650,12 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   }
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-  if (fold_actor) {   // the bias terms of the folded layer (db_0 of the actor-type nets is complete now):
-    const NetOff& oa = w.net[0];   // db_in = W_ih0^T db_0, and dW_ih0 += db_0 b_in^T (X0 = obs W_in^T + b_in)
-    hipLaunchKernelGGL(matvec_t_acc_kernel, g1(H), dim3(256), 0, ctx->stream, params_d + oa.w_ih[0], grad_d + oa.b[0], 4 * H, H, grad_d + oa.b_in);
-    hipLaunchKernelGGL(outer_acc_kernel, g1((size_t)4 * H * H), dim3(256), 0, ctx->stream, grad_d + oa.w_ih[0], grad_d + oa.b[0], params_d + oa.b_in, 4 * H, H);
-  }
+  if (fold_actor)   // the bias terms of layer 0 (db_0 is complete now): db_in = W_ih0^T db_0, dW_ih0 += db_0 b_in^T (X0 = obs W_in^T + b_in)
+    for (int k = 0; k < (fold_critic ? 2 : 1); ++k) {
+      const NetOff& oa = w.net[k];
+      hipLaunchKernelGGL(matvec_t_acc_kernel, g1(H), dim3(256), 0, ctx->stream, params_d + oa.w_ih[0], grad_d + oa.b[0], 4 * H, H, grad_d + oa.b_in);
+      hipLaunchKernelGGL(outer_acc_kernel, g1((size_t)4 * H * H), dim3(256), 0, ctx->stream, grad_d + oa.w_ih[0], grad_d + oa.b[0], params_d + oa.b_in, 4 * H, H);
+    }
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_grad");
   return 0;
 }
