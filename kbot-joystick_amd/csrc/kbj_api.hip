@@ -83,6 +83,7 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
     KBJ_TRY(hipStreamCreateWithFlags(&ctx->side[n], hipStreamNonBlocking));
     KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_side[n], hipEventDisableTiming));
   }
+  for (int k = 0; k < 32; ++k) KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_pool[k], hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
 #undef KBJ_TRY
@@ -102,6 +103,7 @@ int kbj_destroy(kbj_ctx* ctx) {
   if (ctx->rcarry_d) hipFree(ctx->rcarry_d);
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
+  for (int k = 0; k < 32; ++k) if (ctx->ev_pool[k]) hipEventDestroy(ctx->ev_pool[k]);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);

@@ -17,6 +17,8 @@ struct kbj_ctx {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t side[2] = {nullptr, nullptr};   // per-net side lanes for weight-gradient GEMMs
   hipEvent_t ev_side[2] = {nullptr, nullptr};
+  hipEvent_t ev_pool[32] = {};                // lane-alignment events of kbj_ppo_grad
+  int ev_next = 0;
   kbj_model model_h;
   kbj_config cfg_h;
   kbj_model* model_d = nullptr;

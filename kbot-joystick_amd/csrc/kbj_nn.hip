@@ -555,21 +555,39 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     hipLaunchKernelGGL(matvec_kernel, g1(4 * H), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
     for (int n = 0; n < w.nnets; ++n) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), s));
   }
-  for (int n = 0; n < w.nnets; ++n) {   // nets 2, 3: the mirror branches, same weights, queued behind nets 0, 1 on the same two streams
+  // Launch order is layer-major over the nets (nets 2, 3 = mirror branches, same weights, queued behind nets 0, 1 on the same two
+  // streams). KBJ_ALIGN=1 makes the two lanes wait for each other before every recurrence phase, so that recurrences only ever
+  // run next to recurrences and GEMMs next to GEMMs (diagnostic; no measurable difference).
+  static const bool align_on = getenv("KBJ_ALIGN") ? atoi(getenv("KBJ_ALIGN")) != 0 : false;   // measured neutral (7.92 vs 7.91 ms): off
+  auto align = [&]() {
+    if (!align_on || one_stream) return;
+    hipEvent_t ea = ctx->ev_pool[ctx->ev_next++ & 31], eb = ctx->ev_pool[ctx->ev_next++ & 31];
+    hipEventRecord(ea, ns[0]); hipEventRecord(eb, ns[1]);
+    hipStreamWaitEvent(ns[0], eb, 0); hipStreamWaitEvent(ns[1], ea, 0);
+  };
+  for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
-    TrainBufs& t = w.tb[n];
-    hipStream_t s = ns[n & 1];
-    const bool folded = fold_actor && (n & 1) == 0;   // actor-type net: layer-0 gates straight from the observations
-    if (!folded) linear_fwd(s, t.obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, t.X0, H, R, H, o.nin, 0);
-    const float* xin = t.X0;
-    for (int l = 0; l < 2; ++l) {
-      if (folded && l == 0) linear_fwd(s, t.obs, o.ld_obs, w.Weff, KBJ_LD_ACTOR, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0);
-      else linear_fwd(s, xin, H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
-      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * n, w.seq_err, T, B, (n == 0 && l == 0) ? w.seq_stamps : nullptr};
-      if (seq_fwd(ctx, s, H, fa)) return -1;
-      xin = t.Hout[l];
+    if (!(fold_actor && (n & 1) == 0))   // actor-type nets: layer-0 gates come straight from the observations
+      linear_fwd(ns[n & 1], w.tb[n].obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, w.tb[n].X0, H, R, H, o.nin, 0);
+  }
+  for (int l = 0; l < 2; ++l) {
+    for (int n = 0; n < w.nnets; ++n) {
+      const NetOff& o = w.net[n & 1];
+      TrainBufs& t = w.tb[n];
+      if (fold_actor && (n & 1) == 0 && l == 0) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, KBJ_LD_ACTOR, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0);
+      else linear_fwd(ns[n & 1], l == 0 ? t.X0 : t.Hout[0], H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
     }
-    linear_fwd(s, xin, H, params_d + o.w_out, H, params_d + o.b_out, t.Out, 40, R, o.nout, H, 0);
+    align();
+    for (int n = 0; n < w.nnets; ++n) {
+      const NetOff& o = w.net[n & 1];
+      TrainBufs& t = w.tb[n];
+      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * n, w.seq_err, T, B, (n == 0 && l == 0) ? w.seq_stamps : nullptr};
+      if (seq_fwd(ctx, ns[n & 1], H, fa)) return -1;
+    }
+  }
+  for (int n = 0; n < w.nnets; ++n) {
+    const NetOff& o = w.net[n & 1];
+    linear_fwd(ns[n & 1], w.tb[n].Hout[1], H, params_d + o.w_out, H, params_d + o.b_out, w.tb[n].Out, 40, R, o.nout, H, 0);
   }
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
@@ -602,30 +620,38 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   }
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  // The critical path of a net is dOut -> dH -> (recurrence, dX) per layer. Weight/bias gradients hang off it: they go to the
+  // net's side stream so the throughput-bound split-K GEMMs run beside the dX GEMMs in the GEMM phases.
+  auto side_of = [&](int n) { return one_stream ? ns[n & 1] : ctx->side[n & 1]; };
+  auto fork_side = [&](int n) { if (!one_stream) { hipEventRecord(ctx->ev_side[n & 1], ns[n & 1]); hipStreamWaitEvent(ctx->side[n & 1], ctx->ev_side[n & 1], 0); } };
+  float *dh_above[4], *dx_out[4];
   for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
     TrainBufs& t = w.tb[n];
-    hipStream_t s = ns[n & 1];
-    // The critical path of a net is dOut -> dH -> (recurrence, dX) per layer. Weight/bias gradients hang off it: they go to a
-    // side stream (ws) so the throughput-bound split-K GEMMs fill the chip under the latency-bound recurrences.
-    hipStream_t ws = one_stream ? s : ctx->side[n & 1];
-    auto fork_side = [&]() { hipEventRecord(ctx->ev_side[n & 1], s); hipStreamWaitEvent(ws, ctx->ev_side[n & 1], 0); };
-    linear_bwd_input(s, t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
-    if (!one_stream) fork_side();
-    linear_bwd_weight(ws, t.dOut, 40, t.Hout[1], H, grad_d + o.w_out, H, o.nout, H, R);
-    hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 64), dim3(256), 0, ws, t.dOut, R, o.nout, 40, grad_d + o.b_out);
-    float* dh_above = t.dHa;
-    float* dx_out = t.dHb;
-    for (int l = 1; l >= 0; --l) {
+    linear_bwd_input(ns[n & 1], t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
+    fork_side(n);
+    linear_bwd_weight(side_of(n), t.dOut, 40, t.Hout[1], H, grad_d + o.w_out, H, o.nout, H, R);
+    hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 64), dim3(256), 0, side_of(n), t.dOut, R, o.nout, 40, grad_d + o.b_out);
+    dh_above[n] = t.dHa; dx_out[n] = t.dHb;
+  }
+  for (int l = 1; l >= 0; --l) {
+    align();
+    for (int n = 0; n < w.nnets; ++n) {
+      const NetOff& o = w.net[n & 1];
+      TrainBufs& t = w.tb[n];
+      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + 256 * n, w.seq_err, T, B, grad_d + o.b[l]};
+      if (seq_bwd(ctx, ns[n & 1], H, ba)) return -1;
+    }
+    for (int n = 0; n < w.nnets; ++n) {
+      const NetOff& o = w.net[n & 1];
+      TrainBufs& t = w.tb[n];
+      hipStream_t s = ns[n & 1], ws = side_of(n);
       float* dG = t.dGl[l];
-      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above, w.keep, params_d + o.w_hh[l], dG, w.seq_counters + 256 * n, w.seq_err, T, B, grad_d + o.b[l]};
-      if (seq_bwd(ctx, s, H, ba)) return -1;
-      if (!one_stream) fork_side();
-      const float* xin = l == 0 ? t.X0 : t.Hout[0];
+      fork_side(n);
       if (fold_actor && l == 0 && ((n & 1) == 0 || fold_critic)) {
         // layer 0 backwards through the (activation-free) input projection without dX0: dW_hh0 += dG0^T Hm and Z = dG0^T obs in
         // one launch, then two small products carry Z back to the stored parameters: dW_in += W_ih0^T Z, dW_ih0 += Z W_in^T
-        // (the bias terms follow from db_0 at the end). Critic: 50 instead of 66 GFLOP and no dX0 GEMM on the critical path.
+        // (the bias terms follow from db_0 at the end).
         float* Z = w.Zeff[n];
         const int ts = H >= 128 ? 128 : 64;
         int sk = std::max(2, std::min(768 / ((4 * H / ts) * (H / ts + (o.nin + ts - 1) / ts)), (R + 255) / 256));
@@ -638,15 +664,20 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
         gemm_launch<true, true>(ws, g2a);
         continue;
       }
-      linear_bwd_input(s, dG, 4 * H, params_d + o.w_ih[l], H, dx_out, H, R, H, 4 * H, 0);
-      linear_bwd_weight2(ws, dG, 4 * H, t.Hm[l], xin, H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
-      std::swap(dh_above, dx_out);
+      linear_bwd_input(s, dG, 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
+      linear_bwd_weight2(ws, dG, 4 * H, t.Hm[l], l == 0 ? t.X0 : t.Hout[0], H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
+      std::swap(dh_above[n], dx_out[n]);
     }
+  }
+  for (int n = 0; n < w.nnets; ++n) {
+    const NetOff& o = w.net[n & 1];
+    TrainBufs& t = w.tb[n];
+    hipStream_t s = ns[n & 1];
     if (!(fold_actor && ((n & 1) == 0 || fold_critic))) {   // input projection (dh_above now holds dX0)
-      linear_bwd_weight(s, dh_above, H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
-      hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, 64), dim3(256), 0, s, dh_above, R, H, H, grad_d + o.b_in);
+      linear_bwd_weight(s, dh_above[n], H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
+      hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, 64), dim3(256), 0, s, dh_above[n], R, H, H, grad_d + o.b_in);
     }
-    if (!one_stream) { hipEventRecord(ctx->ev_side[n & 1], ws); hipStreamWaitEvent(s, ctx->ev_side[n & 1], 0); }
+    if (!one_stream) { hipEventRecord(ctx->ev_side[n & 1], ctx->side[n & 1]); hipStreamWaitEvent(s, ctx->ev_side[n & 1], 0); }
   }
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
