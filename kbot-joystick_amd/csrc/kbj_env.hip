@@ -26,10 +26,12 @@ __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restri
 }
 
 // register budget of the step kernel: 13.4 KB of LDS lets 12 single-wavefront workgroups share a CU (3 waves/SIMD), which
-// needs <= 168 VGPRs; this cap makes hipcc allocate 129 and spill ~90 values of the long serial phases to scratch.
-// Measured (8192 envs): 3.26 ms/step at 2 waves/SIMD without spills vs 2.83 ms at 3 waves/SIMD with them.
+// needs <= 168 VGPRs. `amdgpu_num_vgpr(N)` makes hipcc allocate 2 N registers for this wave64 kernel (floor 129): N = 84 gives
+// exactly 168 with 61 spilled values. Measured (8192 envs, ms/step): no cap (2 waves/SIMD, no spills) 3.26 -> N = 62 (129 VGPRs,
+// 90 spills) 1.98 -> N = 72 (144, 70 spills) 1.83 -> N = 84 (168, 61 spills) 1.80. `amdgpu_waves_per_eu(3,3)` also lands on 168
+// registers but schedules worse (2.15).
 #ifndef KBJ_ENV_NUM_VGPR
-#define KBJ_ENV_NUM_VGPR 62
+#define KBJ_ENV_NUM_VGPR 84
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR))) void env_step_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, uint32_t seed,
                                                       float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ action,
