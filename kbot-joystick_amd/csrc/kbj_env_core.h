@@ -7,7 +7,7 @@
 // and push events (train.py:1134-1144).
 //
 // Execution model: a workgroup is ONE 64-lane wavefront and owns one environment. All per-body / per-dof /
-// per-constraint-row state of that env is staged in LDS (struct KbjShared, ~20 KB); the code is a sequence
+// per-constraint-row state of that env is staged in LDS (struct KbjShared, 13.4 KB); the code is a sequence
 // of "phases": `PFOR(i, n)` spreads n independent work items over the 64 lanes, `KBJ_SYNC()` separates
 // phases that communicate through LDS, `wsum*()` are butterfly wave reductions. HBM traffic is only the
 // env's parameter/state rows at entry/exit and the observation rows, all lane-contiguous (coalesced).

@@ -20,7 +20,7 @@ struct NetOff {  // float offsets into the flat parameter vector (kbj.h layout =
 };
 
 struct TrainBufs {  // per net, minibatch-sized
-  float *obs, *X0, *G[2], *Hm[2], *Hout[2], *Cm[2], *TanhC[2], *Out, *dOut, *dHa, *dHb, *dGl[2], *dhm, *dcm[2];
+  float *obs, *X0, *G[2], *Hm[2], *Hout[2], *Cm[2], *TanhC[2], *Out, *dOut, *dHa, *dHb, *dGl[2];
 };
 
 struct NnWs {
@@ -262,7 +262,6 @@ int kbj_nn_create(kbj_ctx* ctx) {
       if (dalloc(ctx, *w, &t.Hout[l], R * H)) return -1;
       if (dalloc(ctx, *w, &t.Cm[l], (T + 1) * B * H)) return -1;
       if (dalloc(ctx, *w, &t.TanhC[l], R * H)) return -1;
-      if (dalloc(ctx, *w, &t.dcm[l], B * H)) return -1;
     }
     if (dalloc(ctx, *w, &t.Out, R * 40)) return -1;
     if (dalloc(ctx, *w, &t.dOut, R * 40)) return -1;
@@ -270,7 +269,6 @@ int kbj_nn_create(kbj_ctx* ctx) {
     if (dalloc(ctx, *w, &t.dHb, R * H)) return -1;
     if (dalloc(ctx, *w, &t.dGl[0], R * 4 * H)) return -1;
     if (dalloc(ctx, *w, &t.dGl[1], R * 4 * H)) return -1;
-    if (dalloc(ctx, *w, &t.dhm, B * H)) return -1;
   }
   float** small[] = {&w->keep, &w->logp_old, &w->val_old, &w->adv, &w->target, &w->logp, &w->ent, &w->value, &w->dlogp, &w->dvalue};
   for (float** p : small) if (dalloc(ctx, *w, p, R)) return -1;

@@ -39,33 +39,6 @@ __global__ void lstm_cell_fwd_kernel(CellFwdArgs2 args) {
   if (a.hm_next) { float k = a.keep[m]; a.hm_next[idx] = h * k; a.cm_next[idx] = c * k; a.tanhc[idx] = tc; }
 }
 
-// ---- LSTM cell, backward (one time step) -------------------------------------------------------------------------
-// inputs: dh_above [M][H] (grad wrt the layer output h_t), dhm_next / dcm_next [M][H] (grads wrt the masked carries
-// h_t*keep_t, c_t*keep_t consumed by step t+1; null at the last step), activations Gact, tanhc, cm_prev = masked c_{t-1}.
-// outputs: dG [M][4H] (grad wrt pre-activations), dcm_prev [M][H] (grad wrt masked c_{t-1}).
-struct CellBwdArgs {
-  const float* Gact; const float* tanhc; const float* cm_prev; const float* dh_above; const float* dhm_next; const float* dcm_next;
-  const float* keep; float* dG; float* dcm_prev; int M, H;
-};
-struct CellBwdArgs2 { CellBwdArgs a[2]; };
-__global__ void lstm_cell_bwd_kernel(CellBwdArgs2 args) {
-  const CellBwdArgs& a = args.a[blockIdx.y];
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= a.M * a.H) return;
-  int m = idx / a.H, u = idx - m * a.H;
-  const float* g = a.Gact + (size_t)m * 4 * a.H;
-  float i = g[u], f = g[a.H + u], gg = g[2 * a.H + u], o = g[3 * a.H + u], tc = a.tanhc[idx];
-  float k = a.keep[m];
-  float dh = a.dh_above[idx] + (a.dhm_next ? k * a.dhm_next[idx] : 0.0f);
-  float dc = (a.dcm_next ? k * a.dcm_next[idx] : 0.0f) + dh * o * (1 - tc * tc);
-  float* dg = a.dG + (size_t)m * 4 * a.H;
-  dg[u] = dc * gg * i * (1 - i);
-  dg[a.H + u] = dc * a.cm_prev[idx] * f * (1 - f);
-  dg[2 * a.H + u] = dc * i * (1 - gg * gg);
-  dg[3 * a.H + u] = dh * tc * o * (1 - o);
-  a.dcm_prev[idx] = dc * f;
-}
-
 // ---- threefry (same generator as the env kernels; RNG stream KBJ_RNG_ACTION / KBJ_RNG_INIT) ---------------------
 __device__ __forceinline__ uint32_t nn_rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
 __device__ __forceinline__ void nn_threefry(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
