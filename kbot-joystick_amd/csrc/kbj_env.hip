@@ -43,11 +43,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR
   KBJ_SYNC();
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
   PhysConst pc = make_pc(*c);
+  KBJ_STAMP(18);
   task_step(S, *m, *c, pc, rng, action + (size_t)env * KBJ_NU, aux_t + (size_t)env * KBJ_AUX_SIZE, actor_next + (size_t)env * KBJ_LD_ACTOR,
             critic_next + (size_t)env * KBJ_LD_CRITIC, aux_next + (size_t)env * KBJ_AUX_SIZE);
   if (S.done) PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
   PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
+  KBJ_STAMP(19);
 }
+
+#ifdef KBJ_ENV_STAMPS
+extern "C" int kbj_debug_env_stamps(unsigned long long* out32, int clear) {   // diagnostics build only (tools/env_stamps.py)
+  if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(kbj_env_stamp_acc), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  if (clear) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(kbj_env_stamp_acc), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 
 // ---- reward stack (train.py:125-506, weights train.py:1225-1256): one thread scans one env's trajectory ----
 __global__ void rewards_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ aux, int T, int N,

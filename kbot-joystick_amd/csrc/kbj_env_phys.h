@@ -12,6 +12,15 @@
 #pragma once
 #include "kbj_env_core.h"
 
+// diagnostics (tools/env_stamps.py, -DKBJ_ENV_STAMPS): shader-clock cycles of env 0 per phase, accumulated in a device array
+#if defined(KBJ_ENV_STAMPS) && !defined(KBJ_EMU)
+__device__ unsigned long long kbj_env_stamp_acc[32];
+__device__ unsigned long long kbj_env_stamp_last;
+#define KBJ_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); kbj_env_stamp_acc[k] += t_ - kbj_env_stamp_last; kbj_env_stamp_last = t_; } } while (0)
+#else
+#define KBJ_STAMP(k) ((void)0)
+#endif
+
 namespace kbj {
 
 struct PhysConst {  // per-launch constants derived from kbj_config
@@ -536,6 +545,7 @@ KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
   arrow_solve(S, S.qfrc_smooth, false);
   PFOR(i, NV) S.qacc_smooth[i] = S.vec[i];
   KBJ_SYNC();
+  KBJ_STAMP(7);
   // warm-start selection: the cheaper of the previous step's acceleration and the unconstrained one
   rows_residual(S, S.qacc_smooth);
   float cs = total_cost(S, S.qacc_smooth);
@@ -547,6 +557,7 @@ KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
   PFOR(i, NV) S.qacc[i] = use_warm ? warm[i] : S.qacc_smooth[i];
   KBJ_SYNC();
   if (!use_warm) rows_residual(S, S.qacc);
+  KBJ_STAMP(8);
   float scale = 1.0f / (m.meaninertia * NV);
   int iters = 0;
   for (int it = 0; it < pc.iterations; ++it) {
@@ -564,13 +575,16 @@ KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
     }
     KBJ_SYNC();
     float gg = wsum(NV, [&](int l) { return S.grad[l] * S.grad[l]; });
+    KBJ_STAMP(9);
     if (scale * sqrtf(gg) < pc.tolerance) break;
     arrow_solve(S, S.mv, true);
+    KBJ_STAMP(10);
     PFOR(i, NV) S.search[i] = S.vec[i];
     KBJ_SYNC();
     PFOR(i, NV) S.mv[i] = mul_M_row(S, i, S.search);
     PFOR(r, NROW) S.jv[r] = S.D[r] != 0 ? row_dot(S, r, S.search) : 0.0f;
     KBJ_SYNC();
+    KBJ_STAMP(11);
     float g1, g2;
     wsum2(NV, [&](int l, float& a, float& b) { a = S.search[l] * (S.Ma[l] - S.qfrc_smooth[l]); b = S.search[l] * S.mv[l]; }, g1, g2);
     auto eval = [&](float a, float& d1, float& d2) {
@@ -597,9 +611,11 @@ KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
       }
       alpha = a;
     }
+    KBJ_STAMP(12);
     PFOR(i, NV) { S.qacc[i] += alpha * S.search[i]; S.Ma[i] += alpha * S.mv[i]; }
     PFOR(r, NROW) S.jar[r] += alpha * S.jv[r];
     KBJ_SYNC();
+    KBJ_STAMP(13);
     iters = it + 1;
     if (alpha == 0) break;
   }
@@ -638,14 +654,15 @@ KBJ_DEV void phys_sensors(KbjShared& S, const kbj_model& m) {
 
 // full forward pass on the state in S.es with torques S.ctrl and (if S.pushing) wrench S.push
 KBJ_DEV void phys_forward(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
-  phys_kinematics(S, m);
-  phys_com(S);
-  phys_crb_mass(S);
-  phys_collide_vel(S, m, pc);
-  phys_smooth_forces(S, m);
-  phys_make_constraints(S, m, pc);
-  phys_solve(S, m, pc);
-  phys_sensors(S, m);
+  KBJ_STAMP(0);
+  phys_kinematics(S, m); KBJ_STAMP(1);
+  phys_com(S); KBJ_STAMP(2);
+  phys_crb_mass(S); KBJ_STAMP(3);
+  phys_collide_vel(S, m, pc); KBJ_STAMP(4);
+  phys_smooth_forces(S, m); KBJ_STAMP(5);
+  phys_make_constraints(S, m, pc); KBJ_STAMP(6);
+  phys_solve(S, m, pc); KBJ_STAMP(15);
+  phys_sensors(S, m); KBJ_STAMP(16);
 }
 
 // semi-implicit Euler; also refreshes the warm start (kept in the state row)

@@ -274,6 +274,7 @@ KBJ_DEV void task_step(KbjShared& S, const kbj_model& m, const kbj_config& c, co
     task_pd(S, s >= lat ? S.act_eff : es + KBJ_ES_ACT_PREV);
     phys_forward(S, m, pc);
     phys_integrate(S, pc);
+    KBJ_STAMP(17);
   }
   PFOR(u, NU) { es[KBJ_ES_ACT_PREV + u] = S.act_eff[u]; aux_t[KBJ_AUX_CTRL + u] = S.ctrl[u]; }
   PFOR(w, 1) {
