@@ -160,3 +160,31 @@ def test_reward_components_and_actor_export(tmp_path):
     flat = np.concatenate([z[k].ravel() for k in z.files if k.startswith("actor.")])
     assert flat.size == n and np.array_equal(flat, task.params[:n].cpu().numpy())
     task.ctx.close()
+
+
+def test_full_size_rollout_is_independent_of_the_batch():
+    """BASELINE size property (8192 envs, launch networks): an env's trajectory does not depend on how many other envs share
+    the launch — RNG streams are keyed by global env id, the env kernel is per-env, and a GEMM output row is the same fp32 MFMA
+    chain whatever the tile shape. The first 256 envs of an 8192-env rollout equal a 256-env rollout bit for bit."""
+    import torch
+    from kbot_joystick_amd.host import binding as Bd, buffers
+    from kbot_joystick_amd.spec import compiler, layout as L
+    T, H = 6, 256
+    m = compiler.load_model("kbot-headless")
+    got = {}
+    for N in (8192, 256):
+        cfg = L.default_config(num_envs=N, batch_size=256, rollout_len=T, hidden_size=H)
+        ctx = Bd.Context(m, cfg, 0, torch.cuda.current_stream().cuda_stream)
+        params = torch.zeros(ctx.param_count(), device="cuda:0")
+        ctx.init_params(21, params)
+        carry = buffers.CarryBuffers(N, H, 2, "cuda:0")
+        tr = buffers.TrajBuffers(T, N, H, 2, "cuda:0")
+        ctx.env_reset_all(8, tr.actor_obs[T], tr.critic_obs[T], tr.aux[T])
+        ctx.rollout(params, carry.c, 8, 0, tr.c)
+        ctx.synchronize()
+        got[N] = [t[:, :256].clone() for t in (tr.actor_obs, tr.critic_obs, tr.aux, tr.action, tr.logp, tr.value, tr.reward)]
+        got[N] += [carry.actor_hc[:, :, :256].clone(), carry.critic_hc[:, :, :256].clone(), carry.lpf[:256].clone()]
+        assert torch.isfinite(tr.critic_obs).all() and torch.isfinite(tr.logp).all()
+        ctx.close()
+    for a, b in zip(got[8192], got[256]):
+        assert torch.equal(a, b)
