@@ -255,3 +255,31 @@ def test_ppo_grad_with_mirror_losses_matches_autograd(H, N, B, T):
         off += n
     assert (gg - go).norm() / go.norm() < 1e-4
     ctx.close()
+
+
+def test_full_size_minibatch_gradient_is_permutation_invariant():
+    """BASELINE minibatch (512 envs x 100 steps, H = 256): reordering the envs inside the minibatch changes row-group membership,
+    tile assignment and atomic accumulation order but not the loss or the gradient (beyond fp32 summation order)."""
+    N, B, T, H = 1024, 512, 100, 256
+    m, cfg, ctx, torch, buffers = _setup(N, B, T, H)
+    P = ctx.param_count()
+    params = torch.zeros(P, device="cuda:0")
+    ctx.init_params(2, params)
+    tr = _synthetic_traj(torch, buffers, N, T, H, seed=3)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    tr.logp.copy_(torch.randn(T, N, generator=g) * 0.3 - 20.0)
+    tr.value.copy_(torch.randn(T, N, generator=g) * 0.3)
+    ctx.gae(tr.c, tr.adv, tr.target)
+    idx = torch.randperm(N, generator=g)[:B].int()
+    perm = idx[torch.randperm(B, generator=g)]
+    out = []
+    for ii in (idx, perm):
+        grad, metrics = torch.zeros(P, device="cuda:0"), torch.zeros(10, device="cuda:0")
+        ctx.ppo_grad(params, tr.c, ii.cuda(), B, tr.adv, tr.target, grad, metrics)
+        ctx.synchronize()
+        out.append((grad.cpu().double(), metrics.cpu().double()))
+    (g0, m0), (g1, m1) = out
+    assert torch.isfinite(g0).all() and float(g0.norm()) > 0
+    assert (g0 - g1).norm() / g0.norm() < 1e-4
+    assert (m0 - m1).abs().max() < 1e-4 * (1 + m0.abs().max())
+    ctx.close()
