@@ -90,7 +90,7 @@ def _synthetic_traj(torch, buffers, N, T, H, seed=0, mirror=False):
     return tr
 
 
-@pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (256, 40, 32, 9)])
+@pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (256, 40, 32, 9), (256, 512, 512, 100)])   # the last one = the BASELINE minibatch
 def test_ppo_grad_matches_autograd(H, N, B, T):
     m, cfg, ctx, torch, buffers = _setup(N, B, T, H)
     from oracle import nn as ON
