@@ -80,7 +80,10 @@ def test_teacher_forced_steps_match_oracle(model, N, steps):
         assert np.median(np.abs(a0 - a2.cpu().numpy()).max(1)) < 1e-4
         assert np.median((np.abs(c0 - c2.cpu().numpy()) / (1 + np.abs(c0))).max(1)) < 1e-3
     assert ndone > 0 or steps < 30                                   # the reset path is exercised in the long case
-    H.check_error_distribution(errs, label="hip vs oracle ")
+    # the "max" column of the tolerance table is an extreme value of ~4k samples (contact switching makes a tiny share of steps
+    # sensitive, the oracle's own fp32/fp64 spread shows the same tail); with 25x more samples only median and p99 are comparable
+    tol = H.TOL if N * steps < 10000 else {k: (v[0], v[1], 8 * v[2]) for k, v in H.TOL.items()}
+    H.check_error_distribution(errs, tol=tol, label="hip vs oracle ")
     ctx.close()
 
 
