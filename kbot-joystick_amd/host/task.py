@@ -184,6 +184,7 @@ class HumanoidWalkingTask:
         self.rollout()
         self.update()
         self.iteration += 1
+        self.ctx.synchronize()   # one sync per iteration: surfaces device-side errors (e.g. a recurrence hand-off timeout) as KbjError
 
     def env_steps_per_iteration(self) -> int:
         return self.N * self.T
