@@ -437,12 +437,14 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
     KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_critic_mirror_hc_d, carry->critic_mirror_hc_d, hcb, hipMemcpyDeviceToDevice, s));
     KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_lpf_mirror_d, carry->lpf_mirror_d, (size_t)N * KBJ_NU * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
-  // KBJ_ROLLOUT_PIPELINE=1 (read per call) switches the two-lane schedule on. Default off: with 12 env wavefronts per CU no GEMM
-  // workgroup can be co-resident, the lanes only alternate (same wall time) and every GEMM launch then
-  // spends most of its duration waiting for a CU, which blurs the per-kernel timings the roofline is computed from.
+  // KBJ_ROLLOUT_PIPELINE (read per call): 2 (default) = one lane for actor -> env -> carry reset, the critic (and mirror branches),
+  // which the env never waits for, on a side lane: its small kernels and GEMMs slip into the env kernel's ramp-up / tail
+  // (-8.5 ms per iteration); 1 = additionally two env halves on two lanes (no further gain: with 12 env wavefronts per CU no GEMM
+  // workgroup can be co-resident, the lanes only alternate); 0 = strictly serial on the caller's stream.
   const char* pipe_env = getenv("KBJ_ROLLOUT_PIPELINE");
-  const bool serial = !(pipe_env && atoi(pipe_env) != 0);
-  const int lanes = (!serial && N >= 256 && N % 2 == 0) ? 2 : 1;
+  const int pipe_mode = pipe_env ? atoi(pipe_env) : 2;
+  const bool serial = pipe_mode == 0;
+  const int lanes = (pipe_mode == 1 && N >= 256 && N % 2 == 0) ? 2 : 1;
   hipStream_t ls[2] = {ctx->stream, ctx->stream2};                      // actor + env of each half
   hipStream_t cs[2] = {serial ? ctx->stream : ctx->side[0], serial ? ctx->stream : ctx->side[1]};   // critic + mirror branches of each half
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, s));

@@ -108,8 +108,8 @@ def test_pipelined_rollout_equals_stepwise_calls(mirror):
     cfg = L.default_config(num_envs=N, batch_size=64, rollout_len=T, hidden_size=H, **kw)
     import os
     out = []
-    for mode in ("rollout", "pipelined", "stepwise"):
-        os.environ["KBJ_ROLLOUT_PIPELINE"] = "1" if mode == "pipelined" else "0"
+    for mode in ("serial", "side lane (default)", "two lanes", "stepwise"):
+        os.environ["KBJ_ROLLOUT_PIPELINE"] = {"serial": "0", "side lane (default)": "2", "two lanes": "1", "stepwise": "0"}[mode]
         ctx = Bd.Context(m, cfg, 0, torch.cuda.current_stream().cuda_stream)
         params = torch.zeros(ctx.param_count(), device="cuda:0")
         ctx.init_params(9, params)
@@ -134,8 +134,8 @@ def test_pipelined_rollout_equals_stepwise_calls(mirror):
         out.append(got)
         ctx.close()
     os.environ.pop("KBJ_ROLLOUT_PIPELINE", None)
-    for a, b, c in zip(*out):
-        assert torch.equal(a, c) and torch.equal(b, c)
+    for a, b, c, d in zip(*out):
+        assert torch.equal(a, d) and torch.equal(b, d) and torch.equal(c, d)
 
 
 def test_reward_components_and_actor_export(tmp_path):
