@@ -2,7 +2,9 @@
 """Headline benchmark: env-steps/sec of the full K-Bot joystick training iteration (rollout + PPO update).
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 launch with:  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+For N > 1 either launch it under torchrun (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+... bench.py --gpus N ...) or call it directly: it then starts its N ranks itself (a torch.distributed.run child process,
+before this process touches the GPU) and exits with the child's status. Ranks talk over RCCL (backend "nccl").
 
 One "step" = one training iteration over 8192 envs per GPU (BASELINE.json configs[1]; weak scaling): a 100-control-step
 rollout (policy forward, 5 physics substeps, observations, terminations/resets, rewards) followed by GAE and
@@ -36,40 +38,90 @@ def nn_flops_per_envstep(H: int, num_passes: int) -> float:
     return fwd * (1 + 3 * num_passes)
 
 
-def cpu_baseline(seconds_budget: float = 25.0):
-    """The CPU oracle (C++ env + torch actor-critic, a *port*: the JAX reference cannot run offline) on a bounded sample
-    of the same workload: a scaled-down full iteration (64 envs x 100 steps, batch 64, 3 passes, hidden 256)."""
+def cpu_baseline(repeats: int = 3):
+    """The CPU oracle (C++ OpenMP env + torch actor-critic, a *port*: the JAX reference cannot run offline) on a bounded
+    sample of the same workload: a full iteration of configs[1] scaled down to 256 envs x 100 steps
+    (batch 256, 3 passes, hidden 256), median of `repeats` after one warm-up, with a pinned thread count; plus the configs[0]
+    plumbing line (4 envs x 64 steps, batch 4)."""
     import numpy as np
     import torch
     from kbot_joystick_amd.spec import compiler, layout as L
     from oracle import nn as ON
     from oracle.trainer import OracleTrainer
     from oracle import oracle as O
-    n_envs = 64
-    cfg = L.default_config(num_envs=n_envs, batch_size=n_envs, rollout_len=100, hidden_size=256, num_passes=3, command_mode=1)
-    cfg.fixed_command[0] = 0.5
+    threads = max(1, min(16, os.cpu_count() or 1))     # small matrices: more threads only add synchronisation noise
+    torch.set_num_threads(threads)
+    O.lib().kbj_cpu_set_num_threads(threads)
     model = compiler.load_model("kbot-headless")
-    rng = np.random.default_rng(0)
-    P = ON.param_count(256)
-    params = (rng.uniform(-1, 1, P) / 16).astype(np.float32)
-    tr = OracleTrainer(model, cfg, seed=0, params=params)
-    tr._normal = lambda step: rng.standard_normal((n_envs, 20)).astype(np.float32)   # python threefry loop is not the thing timed
-    t0 = time.time()
-    tr.train_iteration()
-    dt = time.time() - t0
-    cores = max(int(O.lib().kbj_cpu_num_threads()), torch.get_num_threads())
-    return dict(value=n_envs * 100 / dt, unit="env-steps/s", cores=cores, kind="port",
-                sample=f"oracle full iteration on {n_envs} envs x 100 steps, batch {n_envs}, 3 passes, hidden 256 ({dt:.1f} s wall)")
+
+    def run(n_envs, T, reps):
+        cfg = L.default_config(num_envs=n_envs, batch_size=n_envs, rollout_len=T, hidden_size=256, num_passes=3, command_mode=1)
+        cfg.fixed_command[0] = 0.5
+        rng = np.random.default_rng(0)
+        params = (rng.uniform(-1, 1, ON.param_count(256)) / 16).astype(np.float32)
+        tr = OracleTrainer(model, cfg, seed=0, params=params)
+        tr._normal = lambda step: rng.standard_normal((n_envs, 20)).astype(np.float32)   # python threefry loop is not the thing timed
+        tr.train_iteration()   # warm-up (allocator, thread pools)
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            tr.train_iteration()
+            ts.append(time.perf_counter() - t0)
+        return float(np.median(ts)), ts
+
+    t1, ts1 = run(256, 100, repeats)
+    t0, _ = run(4, 64, 3)
+    return dict(value=256 * 100 / t1, unit="env-steps/s", cores=threads, kind="port",
+                sample=f"oracle full iteration (rollout + GAE + 3 passes) on 256 envs x 100 steps, batch 256, hidden 256: median of {repeats} "
+                       f"= {t1:.2f} s (runs {', '.join('%.2f' % t for t in ts1)}), {threads} threads of {os.cpu_count()} host cores",
+                config0=dict(value=4 * 64 / t0, unit="env-steps/s", sample=f"configs[0]: 4 envs x 64 steps, batch 4, 3 passes, hidden 256: median of 3 = {t0:.2f} s"))
 
 
-def pmc_traffic() -> dict:
+def source_fingerprint() -> str:
+    """sha256 over the kernel sources (csrc/*.hip, csrc/*.h, include/*.h): ties a committed PMC profile to the code it measured."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "kbot-joystick_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h")))
+    files += sorted(os.path.join(ROOT, "include", f) for f in os.listdir(os.path.join(ROOT, "include")) if f.endswith(".h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic() -> tuple[dict, dict]:
     """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, written by
-    tools/rocprof_summary.py --pmc with the gfx950 FETCH_SIZE correction); {} when no PMC profile is committed."""
+    tools/pmc_traffic.py with the gfx950 FETCH_SIZE correction) and the profile's provenance. The bytes are only reported
+    when the profile was taken on the kernel sources this run was built from (source fingerprint); otherwise traffic is null."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return {}
+        return {}, dict(status="no committed PMC profile")
     with open(path) as f:
-        return {k: v.get("hbm_bytes_per_launch") for k, v in json.load(f).items()}
+        doc = json.load(f)
+    meta = doc.pop("_meta", {})
+    fp = source_fingerprint()
+    if meta.get("source_fingerprint") != fp:
+        print(f"bench.py: profiles/pmc_traffic.json was taken on other kernel sources ({meta.get('source_fingerprint')} != {fp}): "
+              "roofline.traffic = null (re-run tools/pmc_traffic.py)", file=sys.stderr)
+        return {}, dict(status="stale", profile_fingerprint=meta.get("source_fingerprint"), source_fingerprint=fp, git=meta.get("git"))
+    return {k: v.get("hbm_bytes_per_launch") for k, v in doc.items()}, dict(status="current", source_fingerprint=fp, git=meta.get("git"))
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` outside torchrun: start the N ranks as a torch.distributed.run child BEFORE this process
+    makes any GPU call (never exec from a GPU-initialised process) and hand back the child's exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC (RCCL across processes)
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -83,22 +135,36 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4],
                     help="BASELINE.json configs[i] workload: 1 = the metric's (kbot-headless, flat, fixed command); 3 = UnifiedCommand "
                          "sampler; 4 = full kbot on the sine terrain (extra measurements, not the headline line)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the gradient all-reduce (nccl = RCCL over xGMI)")
+    ap.add_argument("--share-gpu", action="store_true", help="diagnostic: every rank on GPU 0 (rehearses the N-rank flow on a 1-GPU box; use with --backend gloo)")
+    ap.add_argument("--allreduce", default=os.environ.get("KBJ_ALLREDUCE", "per_step"), choices=["per_step", "per_pass"],
+                    help="per_step (default): all-reduce before every optimizer step; per_pass: accumulate a pass, one all-reduce + one step per pass")
     args = ap.parse_args()
 
-    import torch
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))          # nothing has touched the GPU in this process
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if args.gpus > 1:
-            sys.exit(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}")
+        sys.exit(f"bench.py: --gpus {args.gpus} does not match WORLD_SIZE {world}")
+    import torch
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs a HIP device")
+        sys.exit(f"bench.py needs a HIP device (rank {rank} of {world})")
+    if args.share_gpu:
+        local_rank = 0
+    if torch.cuda.device_count() <= local_rank:
+        sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
     wl = {1: dict(robot="kbot-headless", fixed_command=(0.5, 0.0, 0.0)),
@@ -107,7 +173,7 @@ def main():
     wl_name = {1: "kbot-headless, {n} envs/GPU, flat ground, fixed joystick command (0.5,0,0)",
                3: "kbot-headless, {n} envs/GPU, flat ground, UnifiedCommand 6-mode sampler",
                4: "kbot (full), {n} envs/GPU, sine terrain (A 0.05 m, L 2 m), UnifiedCommand sampler, pushes + all randomizers"}[args.config]
-    cfg = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, **wl)
+    cfg = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, allreduce=args.allreduce, **wl)
     task = HumanoidWalkingTask(cfg, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     def barrier():
@@ -151,7 +217,7 @@ def main():
         per_launch = env_s / max(prof["env_step_launches"], 1)
         envs_per_launch = args.envs_per_gpu * task.T / max(prof["env_step_launches"], 1)
         ach_gbs = envs_per_launch * ENV_BYTES_PER_ENVSTEP / per_launch / 1e9
-        traffic = pmc_traffic()
+        traffic, traffic_src = pmc_traffic()
         env_roof = dict(bound="hbm", kernel="env_step_kernel", achieved=round(ach_gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s",
                         frac=round(ach_gbs / PEAK_HBM_GBS, 5), traffic=traffic.get("env_step_kernel"), avg_launch_us=round(per_launch * 1e6, 1),
                         launches=prof["env_step_launches"], envs_per_launch=int(envs_per_launch), total_ms=round(prof["env_step_ms"], 2),
@@ -166,6 +232,7 @@ def main():
                                 avg_launch_us=round(k["total_ms"] * 1e3 / k["launches"], 1), launches=k["launches"], total_ms=round(k["total_ms"], 2)))
         kernels.sort(key=lambda r: -r["total_ms"])
         roofline = kernels[0]          # the dominant kernel by summed launch time
+        roofline["traffic_profile"] = traffic_src
         roofline2 = dict(path=nn_roof, kernels=kernels[1:])
 
     if world > 1:
@@ -185,7 +252,8 @@ def main():
         "config": {"workload": wl_name.format(n=args.envs_per_gpu) + ", full iteration: "
                                f"100-step rollout + PPO update (batch 512/GPU, 3 passes, LSTM hidden {args.hidden}, depth 2)",
                    "envs_per_gpu": args.envs_per_gpu, "rollout_steps": task.T, "batch_size_per_gpu": cfg.batch_size, "num_passes": cfg.num_passes,
-                   "hidden_size": args.hidden, "baseline_config": args.config, "parallelism": f"env-sharded dp{world}, grad all-reduce per optimizer step"},
+                   "hidden_size": args.hidden, "baseline_config": args.config, "parallelism": f"env-sharded dp{world}, grad all-reduce {'per optimizer step' if args.allreduce == 'per_step' else 'once per pass (accumulated)'}"
+                                  + (f" [{args.backend}{', ranks share GPU 0' if args.share_gpu else ''}]" if world > 1 else "")},
         "roofline": roofline, "roofline_secondary": roofline2, "cpu_baseline": cpu,
     }
     print(json.dumps(out), flush=True)

@@ -55,6 +55,10 @@ int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* act
 /* state save/restore (checkpointing, tests): ep [N][KBJ_EP_SIZE], es [N][KBJ_ES_SIZE]; synchronous */
 int kbj_env_get_state(kbj_ctx* ctx, float* ep_h, float* es_h);
 int kbj_env_set_state(kbj_ctx* ctx, const float* ep_h, const float* es_h);
+/* StatefulReward carries (train.py:135-136, 175-178: single-contact timer, feet airtime, previous contact flags) that kbj_rewards
+ * keeps inside the context between rollouts: rc [N][KBJ_RC_SIZE]; synchronous. A resumed run needs them with ep/es. */
+int kbj_env_get_reward_carry(kbj_ctx* ctx, float* rc_h);
+int kbj_env_set_reward_carry(kbj_ctx* ctx, const float* rc_h);
 
 /* ---- rewards, row a23 --------------------------------------------------------------------- */
 /* replaces: get_rewards() stack evaluated over the trajectory (train.py:125-506, 1224-1256).

@@ -142,6 +142,15 @@ typedef struct kbj_config {
    * z = terrain_amp * sin(2 pi x / terrain_wavelength) * sin(2 pi y / terrain_wavelength); terrain_amp = 0 is the plane z = 0 */
   float terrain_amp, terrain_wavelength;
   float reserved_f[4];
+  /* reward stack (train.py:1224-1256): the scale of every term in KBJ_REW_* order, then the constructor arguments the reference
+   * passes to its reward classes (error scales, heights, grace period, touchdown penalty). User-editable like the reference's
+   * get_rewards(); a scale of 0 switches a term off. */
+  float reward_scale[12];
+  float rew_linvel_err, rew_angvel_err, rew_rollpitch_err, rew_rollpitch_err_zero;   /* train.py:1227-1229 */
+  float rew_height_err, rew_standard_height, rew_foot_origin_height;                 /* train.py:1230-1239 */
+  float rew_armpos_err, rew_grace_period, rew_touchdown_penalty;                     /* train.py:1240-1244 */
+  float rew_feetorient_err, rew_comdist_err, rew_baseaccel_err, rew_torque_err;      /* train.py:1245-1255 */
+  float reserved_r[2];
 } kbj_config;
 
 /* ---- per-env randomised model parameters ("EP" record, floats, one contiguous row per env) ---- */

@@ -55,7 +55,10 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   if (!topology_ok(ctx->model_h, why)) { delete ctx; return kbj_fail(nullptr, "kbj_create: " + why); }
   if (cfg->num_envs <= 0 || cfg->substeps <= 0 || cfg->rollout_len <= 0) { delete ctx; return kbj_fail(nullptr, "kbj_create: bad config sizes"); }
   if (cfg->solver_newton != 1) { delete ctx; return kbj_fail(nullptr, "kbj_create: only the Newton solver is implemented on the GPU (solver_newton = 1)"); }
-  if (cfg->hidden_size % 64 != 0 || cfg->depth != 2) { delete ctx; return kbj_fail(nullptr, "kbj_create: hidden_size must be a multiple of 64 and depth 2"); }
+  if ((cfg->hidden_size != 64 && cfg->hidden_size != 128 && cfg->hidden_size != 256) || cfg->depth != 2) {
+    delete ctx;
+    return kbj_fail(nullptr, "kbj_create: the kernels are built for hidden_size 64, 128 or 256 and depth 2 (train.py:78-85 defaults 128 / 2, launch 256)");
+  }
   ctx->device = device;
   ctx->stream = (hipStream_t)hip_stream;
   int ndev = 0;
@@ -117,6 +120,7 @@ int kbj_destroy(kbj_ctx* ctx) {
 
 int kbj_synchronize(kbj_ctx* ctx) {
   if (!ctx) return kbj_fail(nullptr, "kbj_synchronize: null ctx");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   KBJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return kbj_nn_check_errors(ctx);
 }

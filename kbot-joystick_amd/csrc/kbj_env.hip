@@ -64,7 +64,7 @@ __global__ void rewards_kernel(const kbj_model* __restrict__ m, const kbj_config
                                float* __restrict__ carry, float* __restrict__ reward, float* __restrict__ comps) {
   int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= N) return;
-  const float scales[KBJ_NREW] = {0.2f, 0.1f, 0.2f, 0.2f, 0.2f, 0.1f, 0.1f, 1.5f, 0.1f, 0.05f, 0.1f, 0.1f};
+  const float* scales = c->reward_scale;   // user-editable like the reference's get_rewards() (train.py:1224-1256)
   const float ctrl_dt = c->ctrl_dt;
   float* rc = carry + (size_t)env * KBJ_RC_SIZE;
   float tsingle = rc[KBJ_RC_TSINGLE], air[2] = {rc[KBJ_RC_AIRTIME], rc[KBJ_RC_AIRTIME + 1]};
@@ -83,31 +83,31 @@ __global__ void rewards_kernel(const kbj_model* __restrict__ m, const kbj_config
       float ye[3] = {0, 0, be[2]}, yq[4], v[3] = {cmd[0], cmd[1], 0}, g[3];
       euler_to_quat(ye, yq); rotate_by_quat(v, yq, false, g);
       float ex = a[KBJ_AUX_QVEL] - g[0], ey = a[KBJ_AUX_QVEL + 1] - g[1], err = sqrtf(ex * ex + ey * ey);
-      r[KBJ_REW_LINVEL] = expf(-(zc ? err : err * err) / 0.2f);
+      r[KBJ_REW_LINVEL] = expf(-(zc ? err : err * err) / c->rew_linvel_err);
     }
-    r[KBJ_REW_ANGVEL] = expf(-fabsf(a[KBJ_AUX_QVEL + 5] - cmd[2]) / 0.2f);  // train.py:301-306
+    r[KBJ_REW_ANGVEL] = expf(-fabsf(a[KBJ_AUX_QVEL + 5] - cmd[2]) / c->rew_angvel_err);  // train.py:301-306
     {  // roll_pitch (train.py:316-334)
       float e1[3] = {be[0], be[1], 0}, q1[4], e2[3] = {cmd[4], cmd[5], 0}, q2[4];
       euler_to_quat(e1, q1); euler_to_quat(e2, q2);
       float d_ = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
-      r[KBJ_REW_ROLL_PITCH] = expf(-(1 - d_ * d_) / (zc ? 0.01f : 0.03f));
+      r[KBJ_REW_ROLL_PITCH] = expf(-(1 - d_ * d_) / (zc ? c->rew_rollpitch_err_zero : c->rew_rollpitch_err));
     }
     {  // base_height (train.py:377-388)
-      float low = fminf(a[KBJ_AUX_LFZ] - 0.06f, a[KBJ_AUX_RFZ] - 0.06f);
+      float low = fminf(a[KBJ_AUX_LFZ] - c->rew_foot_origin_height, a[KBJ_AUX_RFZ] - c->rew_foot_origin_height);
       float h = a[KBJ_AUX_BASEZ] - low;
-      r[KBJ_REW_BASE_HEIGHT] = expf(-fabsf(h - (cmd[3] + 0.80f)) / 0.02f);
+      r[KBJ_REW_BASE_HEIGHT] = expf(-fabsf(h - (cmd[3] + c->rew_standard_height)) / c->rew_height_err);
     }
     {  // arm_pos (train.py:261-265)
       float e = 0;
       for (int j = 0; j < 10; ++j) { float dq = a[KBJ_AUX_ARMQ + j] - (cmd[6 + j] + m->joint_bias[10 + j]); e += dq * dq; }
-      r[KBJ_REW_ARM_POS] = expf(-e / 0.1f);
+      r[KBJ_REW_ARM_POS] = expf(-e / c->rew_armpos_err);
     }
     bool cl = a[KBJ_AUX_TOUCH] > 0.1f, cr = a[KBJ_AUX_TOUCH + 1] > 0.1f;
     {  // single_contact (train.py:138-154), grace period 2.0 s
       float ts = (cl != cr) ? 0.0f : tsingle + ctrl_dt;
-      if (zc) ts = 2.0f;
+      if (zc) ts = c->rew_grace_period;
       tsingle = ts;
-      r[KBJ_REW_SINGLE_CONTACT] = zc ? 1.0f : (ts < 2.0f ? 1.0f : 0.0f);
+      r[KBJ_REW_SINGLE_CONTACT] = zc ? 1.0f : (ts < c->rew_grace_period ? 1.0f : 0.0f);
     }
     r[KBJ_REW_NO_CONTACT] = zc ? 0.0f : ((cl || cr) ? 0.0f : 1.0f);  // train.py:161-165
     {  // feet_airtime (train.py:197-213)
@@ -115,7 +115,7 @@ __global__ void rewards_kernel(const kbj_model* __restrict__ m, const kbj_config
       float rew = 0;
       for (int f = 0; f < 2; ++f) {
         bool first = con[f] && !pcon[f] && !done;
-        rew += (air[f] - 0.4f) * (first ? 1.0f : 0.0f);
+        rew += (air[f] - c->rew_touchdown_penalty) * (first ? 1.0f : 0.0f);
         air[f] = (con[f] || done) ? 0.0f : air[f] + ctrl_dt;
         pcon[f] = con[f];
       }
@@ -136,22 +136,22 @@ __global__ void rewards_kernel(const kbj_model* __restrict__ m, const kbj_config
         float d2 = tq[0] * fq0[0] + tq[1] * fq0[1] + tq[2] * fq0[2] + tq[3] * fq0[3];
         rp += 1 - d2 * d2;
       }
-      r[KBJ_REW_FEET_ORIENT] = expf(-(fabsf(cmd[2]) > 1e-3f ? rp : rpy) / 0.02f);
+      r[KBJ_REW_FEET_ORIENT] = expf(-(fabsf(cmd[2]) > 1e-3f ? rp : rpy) / c->rew_feetorient_err);
     }
     {  // com_distance (train.py:466-478)
       float cd = a[KBJ_AUX_COMDIST];
-      r[KBJ_REW_COM_DISTANCE] = (cd >= 0 && zc) ? expf(-cd / 0.04f) : 0.0f;
+      r[KBJ_REW_COM_DISTANCE] = (cd >= 0 && zc) ? expf(-cd / c->rew_comdist_err) : 0.0f;
     }
     {  // base_accel (train.py:487-494)
       float e = 0;
       if (t > 0 && !pdone) for (int k = 0; k < 6; ++k) e += fabsf(a[KBJ_AUX_QVEL + k] - pq[k]);
       for (int k = 0; k < 6; ++k) pq[k] = a[KBJ_AUX_QVEL + k];
       pdone = done;
-      r[KBJ_REW_BASE_ACCEL] = expf(-e / 5.0f);
+      r[KBJ_REW_BASE_ACCEL] = expf(-e / c->rew_baseaccel_err);
     }
     {  // torque (train.py:503-506)
       float s = 0;
-      for (int u = 0; u < KBJ_NU; ++u) s += expf(-fabsf(a[KBJ_AUX_CTRL + u]) / 5.0f);
+      for (int u = 0; u < KBJ_NU; ++u) s += expf(-fabsf(a[KBJ_AUX_CTRL + u]) / c->rew_torque_err);
       r[KBJ_REW_TORQUE] = zc ? s / KBJ_NU : 1.0f;
     }
     float tot = 0;
@@ -201,12 +201,14 @@ int kbj_env_reset_all(kbj_ctx* ctx, uint32_t seed, float* actor0_d, float* criti
 int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {
   if (!ctx) return kbj_fail(nullptr, "kbj_env_step: null ctx");
   if (!action_d || !aux_t_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_step: null pointer");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   return kbj_env_step_range(ctx, ctx->stream, 0, ctx->cfg_h.num_envs, action_d, aux_t_d, actor_next_d, critic_next_d, aux_next_d);
 }
 
 int kbj_env_get_state(kbj_ctx* ctx, float* ep_h, float* es_h) {
   if (!ctx) return kbj_fail(nullptr, "kbj_env_get_state: null ctx");
   size_t N = ctx->cfg_h.num_envs;
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   KBJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ep_h) KBJ_HIP(ctx, hipMemcpy(ep_h, ctx->ep_d, N * KBJ_EP_SIZE * sizeof(float), hipMemcpyDeviceToHost));
   if (es_h) KBJ_HIP(ctx, hipMemcpy(es_h, ctx->es_d, N * KBJ_ES_SIZE * sizeof(float), hipMemcpyDeviceToHost));
@@ -216,15 +218,33 @@ int kbj_env_get_state(kbj_ctx* ctx, float* ep_h, float* es_h) {
 int kbj_env_set_state(kbj_ctx* ctx, const float* ep_h, const float* es_h) {
   if (!ctx) return kbj_fail(nullptr, "kbj_env_set_state: null ctx");
   size_t N = ctx->cfg_h.num_envs;
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   KBJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
   if (ep_h) KBJ_HIP(ctx, hipMemcpy(ctx->ep_d, ep_h, N * KBJ_EP_SIZE * sizeof(float), hipMemcpyHostToDevice));
   if (es_h) KBJ_HIP(ctx, hipMemcpy(ctx->es_d, es_h, N * KBJ_ES_SIZE * sizeof(float), hipMemcpyHostToDevice));
   return 0;
 }
 
+int kbj_env_get_reward_carry(kbj_ctx* ctx, float* rc_h) {
+  if (!ctx || !rc_h) return kbj_fail(ctx, "kbj_env_get_reward_carry: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  KBJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KBJ_HIP(ctx, hipMemcpy(rc_h, ctx->rcarry_d, (size_t)ctx->cfg_h.num_envs * KBJ_RC_SIZE * sizeof(float), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+int kbj_env_set_reward_carry(kbj_ctx* ctx, const float* rc_h) {
+  if (!ctx || !rc_h) return kbj_fail(ctx, "kbj_env_set_reward_carry: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  KBJ_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  KBJ_HIP(ctx, hipMemcpy(ctx->rcarry_d, rc_h, (size_t)ctx->cfg_h.num_envs * KBJ_RC_SIZE * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
 int kbj_rewards(kbj_ctx* ctx, const float* aux_d, int T, float* reward_d, float* comps_d) {
   if (!ctx) return kbj_fail(nullptr, "kbj_rewards: null ctx");
   if (!aux_d || !reward_d || T <= 0) return kbj_fail(ctx, "kbj_rewards: bad arguments");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   int N = ctx->cfg_h.num_envs;
   hipLaunchKernelGGL(rewards_kernel, dim3((N + 63) / 64), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, aux_d, T, N, ctx->rcarry_d,
                      reward_d, comps_d);

@@ -14,9 +14,10 @@
 
 // diagnostics (tools/env_stamps.py, -DKBJ_ENV_STAMPS): shader-clock cycles of env 0 per phase, accumulated in a device array
 #if defined(KBJ_ENV_STAMPS) && !defined(KBJ_EMU)
+// every 32nd env (256 of 8192) adds its per-phase cycles, so the profile averages over easy and hard envs alike
 __device__ unsigned long long kbj_env_stamp_acc[32];
-__device__ unsigned long long kbj_env_stamp_last;
-#define KBJ_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); kbj_env_stamp_acc[k] += t_ - kbj_env_stamp_last; kbj_env_stamp_last = t_; } } while (0)
+__shared__ unsigned long long kbj_env_stamp_last;
+#define KBJ_STAMP(k) do { if ((blockIdx.x & 31) == 0 && threadIdx.x == 0) { unsigned long long t_ = clock64(); if ((k) != 18) atomicAdd(&kbj_env_stamp_acc[k], t_ - kbj_env_stamp_last); kbj_env_stamp_last = clock64(); } } while (0)
 #else
 #define KBJ_STAMP(k) ((void)0)
 #endif

@@ -163,8 +163,12 @@ void linear_bwd_weight2(hipStream_t s, const float* dy, int lddy, const float* x
 
 // wavefronts per recurrence workgroup: 4 (16 hidden units) or 8 (32 units, KBJ_SEQ_UW=2, default) — see kbj_lstm_seq.h
 int g_seq_uw = 2;
+// fault injection for the tests (KBJ_DEBUG_DROP_SEQ_WG = n at kbj_create): the next n forward-recurrence launches run with one
+// workgroup missing, so its partners' bounded spins expire and the timeout / fail-stop path is exercised on real hardware
+int g_seq_drop = 0;
 template <int H, int UW> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a) {
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
+  if (g_seq_drop > 0 && grid > 1) { --g_seq_drop; --grid; }
   hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
 template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a) {
@@ -214,9 +218,13 @@ int kbj_nn_check_errors(kbj_ctx* ctx) {
               d[0] / (w->T - 2), d[1] / (w->T - 2), d[2] / (w->T - 2), d[3] / (w->T - 2), d[4] / (w->T - 2), d[5] / (w->T - 2));
     }
   }
-  unsigned e = 0;
-  if (hipMemcpy(&e, w->seq_err, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return kbj_fail(ctx, "hipMemcpy seq_err");
-  if (e) return kbj_fail(ctx, "persistent LSTM kernel: inter-workgroup wait timed out (grid not fully resident?)");
+  unsigned e[2] = {0, 0};
+  if (hipMemcpy(e, w->seq_err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return kbj_fail(ctx, "hipMemcpy seq_err");
+  if (e[0] || e[1]) {   // sticky until acknowledged here: clear, so the context stays usable (and destroyable) after the report
+    hipMemset(w->seq_err, 0, sizeof(e));
+    if (e[0]) return kbj_fail(ctx, "persistent LSTM kernel: inter-workgroup wait timed out (grid not fully resident?); the optimizer steps fed by it were skipped");
+    return kbj_fail(ctx, "non-finite gradient norm: the optimizer step was skipped (parameters and moments unchanged)");
+  }
   return 0;
 }
 
@@ -286,8 +294,37 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (hipMemset(w->seq_err, 0, 4 * sizeof(unsigned)) != hipSuccess) return kbj_fail(ctx, "hipMemset seq_err");
   g_seq_uw = getenv("KBJ_SEQ_UW") ? atoi(getenv("KBJ_SEQ_UW")) : 2;
   if (g_seq_uw != 1 && g_seq_uw != 2) return kbj_fail(ctx, "KBJ_SEQ_UW must be 1 or 2");
-  if ((B + SEQ_ROWS - 1) / SEQ_ROWS * (H / (SEQ_UNITS * g_seq_uw)) > 256)
-    return kbj_fail(ctx, "kbj_create: (batch_size/32)*(hidden/(16 * wavefront groups)) must be <= 256 (persistent LSTM kernel residency)");
+  g_seq_drop = getenv("KBJ_DEBUG_DROP_SEQ_WG") ? atoi(getenv("KBJ_DEBUG_DROP_SEQ_WG")) : 0;
+  // Residency of the persistent recurrences: the workgroups of one launch spin on each other, and kbj_ppo_grad keeps TWO launches
+  // (actor-type and critic-type net, one per stream; the mirror branches queue behind them on the same two streams) in flight, so
+  // 2 x grid workgroups must be resident at once. Every other kernel of the schedule (GEMMs, heads) terminates on its own, so it can
+  // only delay a recurrence workgroup, never starve it. Slots = what the occupancy query says for the slower-to-fit (backward) kernel.
+  {
+    const int grid = (int)((B + SEQ_ROWS - 1) / SEQ_ROWS) * (int)(H / (SEQ_UNITS * g_seq_uw));
+    int per_cu = 0, cus = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return kbj_fail(ctx, "hipGetDeviceProperties");
+    cus = prop.multiProcessorCount;
+    hipError_t oe = hipSuccess;
+    const int threads = 256 * g_seq_uw;
+    switch ((int)H * 10 + g_seq_uw) {
+      case 641: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<64, 1>, threads, 0); break;
+      case 642: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<64, 2>, threads, 0); break;
+      case 1281: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<128, 1>, threads, 0); break;
+      case 1282: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<128, 2>, threads, 0); break;
+      case 2561: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 1>, threads, 0); break;
+      case 2562: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 2>, threads, 0); break;
+      default: return kbj_fail(ctx, "kbj_create: hidden_size must be 64, 128 or 256 (persistent LSTM kernels)");
+    }
+    if (oe != hipSuccess || per_cu < 1) return kbj_fail(ctx, "kbj_create: occupancy query of the persistent LSTM kernel failed");
+    const long slots = (long)per_cu * cus;
+    if (2L * grid > slots) {
+      char msg[256];
+      snprintf(msg, sizeof(msg), "kbj_create: two concurrent persistent LSTM launches need 2 x %d resident workgroups, the device holds %ld "
+               "(%d per CU x %d CUs): lower batch_size", grid, slots, per_cu, cus);
+      return kbj_fail(ctx, msg);
+    }
+  }
   return 0;
 }
 
@@ -375,6 +412,7 @@ size_t kbj_actor_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, c
 
 int kbj_init_params(kbj_ctx* ctx, uint32_t seed, float* params_d) {
   if (!ctx || !params_d) return kbj_fail(ctx, "kbj_init_params: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
   int H = w.H;
   uint32_t leaf = 0;
@@ -394,6 +432,7 @@ int kbj_init_params(kbj_ctx* ctx, uint32_t seed, float* params_d) {
 int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_d, const float* critic_obs_d, kbj_carry* carry, uint32_t seed,
                     uint32_t step_index, int argmax, float* action_d, float* logp_d, float* value_d) {
   if (!ctx || !params_d || !actor_obs_d || !critic_obs_d || !carry || !action_d || !logp_d || !value_d) return kbj_fail(ctx, "kbj_policy_step: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
   KbjTimed timed(ctx, true);
   if (w.mirror && (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d))
@@ -405,6 +444,7 @@ int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_
 
 int kbj_carry_reset(kbj_ctx* ctx, kbj_carry* carry, const float* done_d, int done_stride) {
   if (!ctx || !carry || !done_d) return kbj_fail(ctx, "kbj_carry_reset: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
   if (w.mirror && (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d)) return kbj_fail(ctx, "kbj_carry_reset: mirror-branch carry arrays are NULL");
   carry_reset_nets(ctx, ctx->stream, 0, w.nnets, 0, w.N, carry, done_d, done_stride);
@@ -417,6 +457,7 @@ int kbj_carry_reset(kbj_ctx* ctx, kbj_carry* carry, const float* done_d, int don
 // never waits for, run on side lanes under the env kernel of their own half. Per-env results do not depend on the split.
 int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t seed, uint32_t first_step_index, kbj_traj* tr) {
   if (!ctx || !params_d || !carry || !tr) return kbj_fail(ctx, "kbj_rollout: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
   int N = w.N, H = w.H, T = tr->T;
   if (tr->N != N || T <= 0) return kbj_fail(ctx, "kbj_rollout: trajectory shape does not match the context");
@@ -487,6 +528,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
 
 int kbj_gae(kbj_ctx* ctx, const kbj_traj* tr, float* adv_d, float* target_d) {
   if (!ctx || !tr || !adv_d || !target_d) return kbj_fail(ctx, "kbj_gae: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   const kbj_config& c = ctx->cfg_h;
   hipLaunchKernelGGL(gae_kernel, g1(tr->N, 64), dim3(64), 0, ctx->stream, tr->value_d, tr->reward_d, tr->aux_d, tr->T, tr->N, c.gamma, c.lam, adv_d, target_d);
   KBJ_CHECK_LAUNCH(ctx, "gae_kernel");
@@ -496,6 +538,7 @@ int kbj_gae(kbj_ctx* ctx, const kbj_traj* tr, float* adv_d, float* target_d) {
 int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const int32_t* env_idx_d, int B, const float* adv_d, const float* target_d,
                  float* grad_d, float* metrics_d) {
   if (!ctx || !params_d || !tr || !env_idx_d || !adv_d || !target_d || !grad_d || !metrics_d) return kbj_fail(ctx, "kbj_ppo_grad: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
   const kbj_config& c = ctx->cfg_h;
   if (B != w.B) return kbj_fail(ctx, "kbj_ppo_grad: B must equal config.batch_size");
@@ -553,7 +596,9 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, KBJ_LD_ACTOR, 0, 1, nullptr};
     gemm_launch<true, false>(s, g);
     hipLaunchKernelGGL(matvec_kernel, g1(4 * H), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
-    for (int n = 0; n < w.nnets; ++n) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), s));
+    // each accumulator is cleared on the lane whose side stream later accumulates into it (actor-type nets: the caller's stream,
+    // critic-type nets with KBJ_FOLD_CRITIC: the second stream), so the clear is always ordered before the split-K atomics
+    for (int n = 0; n < w.nnets; ++n) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), ns[n & 1]));
   }
   // Launch order is layer-major over the nets (nets 2, 3 = mirror branches, same weights, queued behind nets 0, 1 on the same two
   // streams). KBJ_ALIGN=1 makes the two lanes wait for each other before every recurrence phase, so that recurrences only ever
@@ -687,7 +732,11 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       hipLaunchKernelGGL(matvec_t_acc_kernel, g1(H), dim3(256), 0, ctx->stream, params_d + oa.w_ih[0], grad_d + oa.b[0], 4 * H, H, grad_d + oa.b_in);
       hipLaunchKernelGGL(outer_acc_kernel, g1((size_t)4 * H * H), dim3(256), 0, ctx->stream, grad_d + oa.w_ih[0], grad_d + oa.b[0], params_d + oa.b_in, 4 * H, H);
     }
+  // a recurrence that timed out left a truncated gradient: poison it so that every data-parallel rank skips the optimizer step
+  hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d);
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_grad");
+  static const bool debug_sync = getenv("KBJ_DEBUG") && atoi(getenv("KBJ_DEBUG")) != 0;
+  if (debug_sync) return kbj_synchronize(ctx);   // KBJ_DEBUG=1: surface a hand-off timeout at the call that caused it
   return 0;
 }
 
@@ -699,6 +748,7 @@ int kbj_set_learning_rate(kbj_ctx* ctx, float learning_rate) {
 
 int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const float* grad_d, int64_t step, float grad_scale) {
   if (!ctx || !params_d || !m_d || !v_d || !grad_d || step < 1) return kbj_fail(ctx, "kbj_adamw_step: bad argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
   const kbj_config& c = ctx->cfg_h;
   hipStream_t s = ctx->stream;
@@ -707,7 +757,7 @@ int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const 
   hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, s, grad_d, w.nparams, grad_scale, sumsq);
   AdamParams ap{c.learning_rate, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay, c.max_grad_norm,
                 (float)(1.0 - std::pow((double)c.adam_b1, (double)step)), (float)(1.0 - std::pow((double)c.adam_b2, (double)step)), grad_scale};
-  hipLaunchKernelGGL(adamw_kernel, g1(w.nparams), dim3(256), 0, s, params_d, m_d, v_d, grad_d, w.nparams, sumsq, ap);
+  hipLaunchKernelGGL(adamw_kernel, g1(w.nparams), dim3(256), 0, s, params_d, m_d, v_d, grad_d, w.nparams, sumsq, ap, w.seq_err);
   KBJ_CHECK_LAUNCH(ctx, "adamw_kernel");
   return 0;
 }

@@ -408,11 +408,23 @@ __global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float scale,
   if (threadIdx.x == 0) atomicAdd(out, red[0]);
 }
 struct AdamParams { float lr, b1, b2, eps, wd, max_norm, bc1, bc2, gscale; };
+// Fail-stop: a gradient whose global norm is not finite leaves parameters and moments untouched and raises err[1]; err[0] is the
+// hand-off timeout flag of the persistent recurrences (kbj_lstm_seq.h), which also poisons the gradient (poison_grad_kernel) so that
+// after the data-parallel all-reduce EVERY rank skips the step instead of applying a truncated gradient. Both are reported by
+// kbj_synchronize.
+__global__ void poison_grad_kernel(const unsigned* __restrict__ err, float* __restrict__ g) {
+  if (err[0]) g[0] = __int_as_float(0x7FC00000);
+}
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g, size_t n,
-                             const double* __restrict__ sumsq, AdamParams ap) {
+                             const double* __restrict__ sumsq, AdamParams ap, unsigned* __restrict__ err) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  float norm = (float)sqrt(*sumsq);
+  const double ss = *sumsq;
+  if (!(ss <= 1.0e300) || err[0]) {   // NaN / inf norm, or a recurrence timed out on this rank
+    if (i == 0) err[1] = 1u;
+    return;
+  }
+  float norm = (float)sqrt(ss);
   float clip = fminf(ap.max_norm / (norm + 1e-6f), 1.0f);
   float gi = g[i] * ap.gscale * clip;
   float mi = ap.b1 * m[i] + (1 - ap.b1) * gi, vi = ap.b2 * v[i] + (1 - ap.b2) * gi * gi;

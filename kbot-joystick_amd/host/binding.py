@@ -55,6 +55,8 @@ SIGNATURES = {
     "kbj_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "kbj_env_get_state": (_i, [_vp, _vp, _vp]),
     "kbj_env_set_state": (_i, [_vp, _vp, _vp]),
+    "kbj_env_get_reward_carry": (_i, [_vp, _vp]),
+    "kbj_env_set_reward_carry": (_i, [_vp, _vp]),
     "kbj_rewards": (_i, [_vp, _vp, _i, _vp, _vp]),
     "kbj_param_count": (_sz, [_cfgp]),
     "kbj_actor_param_count": (_sz, [_cfgp]),
@@ -166,6 +168,19 @@ class Context:
         ep = None if ep is None else np.ascontiguousarray(ep, np.float32)
         es = None if es is None else np.ascontiguousarray(es, np.float32)
         self.call("kbj_env_set_state", _ptr(ep), _ptr(es))
+
+    def env_get_reward_carry(self):
+        import numpy as np
+        rc = np.zeros((self.config.num_envs, L.RC["SIZE"]), np.float32)
+        self.call("kbj_env_get_reward_carry", _ptr(rc))
+        return rc
+
+    def env_set_reward_carry(self, rc):
+        import numpy as np
+        rc = np.ascontiguousarray(rc, np.float32)
+        if rc.shape != (self.config.num_envs, L.RC["SIZE"]):
+            raise KbjError(f"reward carry must be [{self.config.num_envs}][{L.RC['SIZE']}], got {rc.shape}")
+        self.call("kbj_env_set_reward_carry", _ptr(rc))
 
     def rewards(self, aux, T, reward, comps=None):
         self.call("kbj_rewards", _ptr(aux), T, _ptr(reward), _ptr(comps))

@@ -19,7 +19,9 @@ import torch
 
 from ..spec import compiler, constants, layout as L
 from . import binding as B
+from . import ckpt as ckpt_io
 from . import dist as dist_util
+from . import wiring
 from .buffers import CarryBuffers, TrajBuffers
 
 
@@ -55,6 +57,15 @@ class HumanoidWalkingTaskConfig:
     action_latency_range: tuple = (0.003, 0.01)
     drop_action_prob: float = 0.05
     save_every_n_seconds: Optional[float] = 60
+    valid_every_n_steps: Optional[int] = 100      # train.py:1789: deterministic (argmax) validation rollout every n iterations
+    valid_every_n_seconds: Optional[float] = None # train.py:1790
+    render_length_seconds: float = 10.0           # train.py:1785: length of a validation rollout (nothing is rendered here)
+    max_values_per_plot: int = 50                 # train.py:1783 (plot thinning of the reference's logger; kept for name compatibility)
+    render_track_body_id: int = 0                 # train.py:1784 (viewer only; unused)
+    # the editable part of get_rewards() / get_commands() (train.py:1206-1256): overrides by reward name
+    reward_scales: Optional[dict] = None          # e.g. {"feet_airtime": 2.0, "torque": 0.0}
+    reward_params: Optional[dict] = None          # e.g. {"base_height": {"standard_height": 0.85}}
+    command_ranges: Optional[dict] = None         # e.g. {"vx_range": (-0.5, 1.5)}; keys as UnifiedCommand's (train.py:1211-1217)
     # build-specific
     robot: str = "kbot"                # train.py:1080 loads robot/kbot; BASELINE configs use kbot-headless
     seed: int = 0
@@ -63,6 +74,11 @@ class HumanoidWalkingTaskConfig:
     terrain_amplitude: float = 0.05         # metres; the surface definition is this build's own
     terrain_wavelength: float = 2.0
     log_reward_components: bool = False     # keep the 12 unscaled reward terms of every rollout for logging (39 MB at 8192 x 100)
+    # data-parallel exchange: "per_step" = all-reduce the gradient before every optimizer step (the
+    # single-GPU-equivalent default); "per_pass" = north_star's "once per update" variant: accumulate the minibatch gradients of
+    # a pass locally, ONE all-reduce and ONE optimizer step per pass (fewer, larger steps - a different algorithm). KBJ_ALLREDUCE
+    # in the environment overrides the default.
+    allreduce: str = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_ALLREDUCE", "per_step"))
 
     def to_kbj(self, num_envs_local: int, env_id_offset: int = 0) -> L.Config:
         if self.batch_size <= 0 or num_envs_local % self.batch_size != 0:
@@ -79,6 +95,8 @@ class HumanoidWalkingTaskConfig:
                   lam=self.lam, learning_rate=self.learning_rate, weight_decay=self.adam_weight_decay, switch_prob=self.ctrl_dt / 5,
                   actor_mirror_loss_scale=self.actor_mirror_loss_scale, critic_mirror_loss_scale=self.critic_mirror_loss_scale,
                   lpf_alpha=self.ctrl_dt / (self.ctrl_dt + 1.0 / (2.0 * math.pi * self.cutoff_frequency)))
+        if self.allreduce not in ("per_step", "per_pass"):
+            raise ValueError(f"unknown allreduce mode {self.allreduce!r} (per_step | per_pass)")
         if self.terrain not in ("flat", "sine"):
             raise ValueError(f"unknown terrain {self.terrain!r} (flat | sine)")
         if self.terrain == "sine":
@@ -86,7 +104,13 @@ class HumanoidWalkingTaskConfig:
         if self.fixed_command is not None:
             cmd = list(self.fixed_command) + [0.0] * (L.NCMD - len(self.fixed_command))
             kw.update(command_mode=1, fixed_command=cmd)
-        return L.default_config(**kw)
+        for k, (lo, hi) in (self.command_ranges or {}).items():
+            if k not in ("vx_range", "vy_range", "wz_range", "bh_range", "rx_range", "ry_range"):
+                raise KeyError(f"unknown command range {k!r}")
+            kw[k[:2] + "_lo"], kw[k[:2] + "_hi"] = float(lo), float(hi)
+        kcfg = L.default_config(**kw)
+        wiring.apply_reward_overrides(kcfg, self.reward_scales, self.reward_params)
+        return kcfg
 
 
 def cosine_decay_lr(config: HumanoidWalkingTaskConfig, count: int) -> float:
@@ -100,7 +124,8 @@ def launch_config(**overrides) -> HumanoidWalkingTaskConfig:
     """The reference's launch block (train.py:1761-1791)."""
     kw = dict(num_envs=4096, batch_size=512, num_passes=3, rollout_length_seconds=2.0, entropy_coef=0.004, learning_rate=5e-4, gamma=0.94,
               lam=0.94, actor_mirror_loss_scale=0.0, critic_mirror_loss_scale=0.0, hidden_size=256, dt=0.004, ctrl_dt=0.02, iterations=8,
-              ls_iterations=8, action_latency_range=(0.003, 0.01), drop_action_prob=0.05, save_every_n_seconds=60)
+              ls_iterations=8, action_latency_range=(0.003, 0.01), drop_action_prob=0.05, render_track_body_id=0, render_length_seconds=10,
+              max_values_per_plot=50, save_every_n_seconds=60, valid_every_n_steps=100, valid_every_n_seconds=None)
     kw.update(overrides)
     return HumanoidWalkingTaskConfig(**kw)
 
@@ -122,13 +147,14 @@ class HumanoidWalkingTask:
         self.kcfg = config.to_kbj(self.N, env_id_offset=env_off)
         self.T, self.H, self.B = self.kcfg.rollout_len, self.kcfg.hidden_size, self.kcfg.batch_size
         self.model_blob = self.get_mujoco_model()
-        with torch.cuda.device(self.device):
-            self.ctx = B.Context(self.model_blob, self.kcfg, self.device.index or 0, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.set_device(self.device)     # torch ops of this task and the library's launches must target the same GPU
+        self.ctx = B.Context(self.model_blob, self.kcfg, self.device.index or 0, torch.cuda.current_stream().cuda_stream)
         self.P = self.ctx.param_count()
         self.params = self.get_model(config.seed)
         self.opt_m = torch.zeros_like(self.params)
         self.opt_v = torch.zeros_like(self.params)
         self.grad = torch.zeros_like(self.params)
+        self.grad_acc = torch.zeros_like(self.params) if config.allreduce == "per_pass" else None
         self.metrics = torch.zeros(10, device=self.device)
         self.mirror = config.actor_mirror_loss_scale != 0.0 or config.critic_mirror_loss_scale != 0.0
         self.carry = self.get_initial_model_carry()
@@ -171,14 +197,25 @@ class HumanoidWalkingTask:
         for p in range(self.kcfg.num_passes):
             self._perm_gen.manual_seed((self.config.seed * 1000003 + self.iteration * 97 + p) & 0x7FFFFFFF)
             perm = torch.randperm(self.N, generator=self._perm_gen).int().to(self.device)
-            for mb in range(self.N // self.B):
+            nmb = self.N // self.B
+            per_pass = self.config.allreduce == "per_pass"
+            if per_pass:
+                self.grad_acc.zero_()
+            for mb in range(nmb):
                 idx = perm[mb * self.B:(mb + 1) * self.B].contiguous()
                 self.ctx.ppo_grad(self.params, self.traj.c, idx, self.B, self.traj.adv, self.traj.target, self.grad, self.metrics)
-                scale = dist_util.allreduce_grad_(self.grad, self.world_size)   # RCCL over xGMI: the one exchange step
+                if per_pass:
+                    self.grad_acc.add_(self.grad)          # kbj_ppo_grad overwrites `grad`; the pass total lives in grad_acc
+                    if mb + 1 < nmb:
+                        continue
+                g = self.grad_acc if per_pass else self.grad
+                scale = dist_util.allreduce_grad_(g, self.world_size)   # RCCL over xGMI: the one exchange step
+                if per_pass:
+                    scale /= nmb                                     # mean over the pass's minibatches (and ranks)
                 if self.config.use_lr_decay:
                     self.ctx.set_learning_rate(cosine_decay_lr(self.config, self.opt_step))
                 self.opt_step += 1
-                self.ctx.adamw_step(self.params, self.opt_m, self.opt_v, self.grad, self.opt_step, scale)
+                self.ctx.adamw_step(self.params, self.opt_m, self.opt_v, g, self.opt_step, scale)
 
     def train_iteration(self):
         self.rollout()
@@ -189,34 +226,172 @@ class HumanoidWalkingTask:
     def env_steps_per_iteration(self) -> int:
         return self.N * self.T
 
-    # ---- checkpointing: numpy archive of params/optimizer/env state (xax ckpt.bin layout is "next") ----
+    # ---- read-only views of the compiled task wiring, under the reference's method names (train.py:1059-1276) ----
+    def get_optimizer(self) -> wiring.OptimizerSpec:
+        """train.py:1059-1077: adam / adamw, optionally under a cosine decay schedule; executed by kbj_adamw_step."""
+        return wiring.optimizer(self.config, self.kcfg)
+
+    def get_mujoco_model_metadata(self, mj_model: Optional[L.Model] = None) -> dict:
+        """train.py:1083-1089: per-joint kp / kd / soft torque limit of metadata.json (compiled into the model blob)."""
+        m = mj_model or self.model_blob
+        return {n: dict(kp=m.kp[i], kd=m.kd[i], soft_torque_limit=m.tau_limit[i]) for i, n in enumerate(constants.JOINT_NAMES)}
+
+    def get_actuators(self) -> wiring.PositionActuatorsSpec:
+        return wiring.actuators(self.model_blob, self.kcfg)
+
+    def get_physics_randomizers(self) -> dict:
+        return wiring.physics_randomizers(self.kcfg)
+
+    def get_events(self) -> dict:
+        return wiring.events(self.kcfg)
+
+    def get_resets(self) -> list:
+        return wiring.resets(self.kcfg)
+
+    def get_observations(self) -> dict:
+        return wiring.observations(self.kcfg)
+
+    def get_commands(self) -> dict:
+        return wiring.commands(self.model_blob, self.kcfg)
+
+    def get_rewards(self) -> dict:
+        return wiring.rewards(self.kcfg)
+
+    def get_terminations(self) -> dict:
+        return wiring.terminations(self.kcfg)
+
+    def get_curriculum(self) -> wiring.CurriculumSpec:
+        return wiring.CurriculumSpec()
+
+    def get_ppo_variables(self) -> dict:
+        """train.py:1510-1524 for the LAST rollout: ksim recomputes log-probs / values with the pre-update model in a separate
+        on-policy pass; here they are produced by the rollout's own policy steps (same parameters, same observations)."""
+        return dict(log_probs=self.traj.logp, values=self.traj.value, action=self.traj.action)
+
+    def run_actor(self, actor_obs: torch.Tensor, critic_obs: torch.Tensor, step_index: int = 0):
+        """train.py:1351-1379 + Actor.forward (:913-941) for all envs: returns the distribution's mode (filtered mean incl. biases).
+        Both nets advance their carries (kbj_policy_step is the fused actor + critic step)."""
+        a, _, _ = self.sample_action(actor_obs, critic_obs, step_index, argmax=True)
+        return a
+
+    def run_critic(self, actor_obs: torch.Tensor, critic_obs: torch.Tensor, step_index: int = 0):
+        """train.py:1381-1433 + Critic.forward (:993-1004): the value estimate (carries advance as in run_actor)."""
+        _, _, v = self.sample_action(actor_obs, critic_obs, step_index, argmax=True)
+        return v
+
+    # ---- checkpointing in the xax `ckpt.bin` layout (host/ckpt.py; convert.sh:4, train.py:1788) ----
     def save_checkpoint(self, path: str):
-        import numpy as np
+        """Everything a bit-exact resume needs: parameters, optimizer, counters (upstream members) + env rows, reward carries, model
+        carries and the pending observation rows (kbj_* members)."""
+        T = self.T
         ep, es = self.ctx.env_get_state()
-        extra = {}
+        extras = dict(ep=ep, es=es, rc=self.ctx.env_get_reward_carry(), actor_hc=self.carry.actor_hc.cpu().numpy(), critic_hc=self.carry.critic_hc.cpu().numpy(),
+                      lpf=self.carry.lpf.cpu().numpy(), actor_obs_T=self.traj.actor_obs[T].cpu().numpy(), critic_obs_T=self.traj.critic_obs[T].cpu().numpy(),
+                      aux_T=self.traj.aux[T].cpu().numpy())
         if self.mirror:
-            extra = dict(actor_mirror_hc=self.carry.actor_mirror_hc.cpu().numpy(), critic_mirror_hc=self.carry.critic_mirror_hc.cpu().numpy(),
-                         lpf_mirror=self.carry.lpf_mirror.cpu().numpy())
-        np.savez(path, params=self.params.cpu().numpy(), opt_m=self.opt_m.cpu().numpy(), opt_v=self.opt_v.cpu().numpy(),
-                 opt_step=self.opt_step, iteration=self.iteration, ep=ep, es=es, actor_hc=self.carry.actor_hc.cpu().numpy(),
-                 critic_hc=self.carry.critic_hc.cpu().numpy(), lpf=self.carry.lpf.cpu().numpy(),
-                 config=str(dataclasses.asdict(self.config)), **extra)
+            extras.update(actor_mirror_hc=self.carry.actor_mirror_hc.cpu().numpy(), critic_mirror_hc=self.carry.critic_mirror_hc.cpu().numpy(),
+                          lpf_mirror=self.carry.lpf_mirror.cpu().numpy())
+        cfg = dataclasses.asdict(self.config)
+        cfg["action_latency_range"] = list(cfg["action_latency_range"])
+        if cfg.get("fixed_command") is not None:
+            cfg["fixed_command"] = list(cfg["fixed_command"])
+        state = dict(num_steps=self.iteration, opt_step=self.opt_step, num_samples=self.iteration * self.N * self.T * self.world_size,
+                     rank=self.rank, world_size=self.world_size)
+        ckpt_io.save_ckpt(path, self.params.cpu().numpy(), self.opt_m.cpu().numpy(), self.opt_v.cpu().numpy(), self.opt_step, self.H, self.kcfg.depth,
+                          state, cfg, extras)
 
     def load_checkpoint(self, path: str):
-        import numpy as np
-        if not os.path.exists(path):
-            raise FileNotFoundError(path)           # convert.py:33-34 error behaviour
-        z = np.load(path, allow_pickle=False)
-        self.params.copy_(torch.from_numpy(z["params"]))
-        self.opt_m.copy_(torch.from_numpy(z["opt_m"])); self.opt_v.copy_(torch.from_numpy(z["opt_v"]))
-        self.opt_step, self.iteration = int(z["opt_step"]), int(z["iteration"])
-        self.ctx.env_set_state(z["ep"], z["es"])
-        self.carry.actor_hc.copy_(torch.from_numpy(z["actor_hc"])); self.carry.critic_hc.copy_(torch.from_numpy(z["critic_hc"]))
-        self.carry.lpf.copy_(torch.from_numpy(z["lpf"]))
+        """Resume from save_checkpoint(): the next train_iteration() is bit-identical to the one the saved run would have made."""
+        z = ckpt_io.load_ckpt(path, "all", hidden_size=self.H, depth=self.kcfg.depth)
+        dev = self.device
+        self.params.copy_(torch.from_numpy(z["model"]))
+        self.opt_m.copy_(torch.from_numpy(z["opt_state"]["mu"])); self.opt_v.copy_(torch.from_numpy(z["opt_state"]["nu"]))
+        self.opt_step, self.iteration = int(z["state"]["opt_step"]), int(z["state"]["num_steps"])
+        x = z["extras"]
+        if "es" not in x:
+            return            # a model-only checkpoint (e.g. written by the reference): parameters and optimizer only
+        if x["es"].shape[0] != self.N:
+            raise B.KbjError(f"checkpoint holds {x['es'].shape[0]} envs, this task has {self.N}")
+        self.ctx.env_set_state(x["ep"], x["es"])
+        self.ctx.env_set_reward_carry(x["rc"])
+        T = self.T
+        self.carry.actor_hc.copy_(torch.from_numpy(x["actor_hc"])); self.carry.critic_hc.copy_(torch.from_numpy(x["critic_hc"]))
+        self.carry.lpf.copy_(torch.from_numpy(x["lpf"]))
+        self.traj.actor_obs[T].copy_(torch.from_numpy(x["actor_obs_T"])); self.traj.critic_obs[T].copy_(torch.from_numpy(x["critic_obs_T"]))
+        self.traj.aux[T].copy_(torch.from_numpy(x["aux_T"]))
         if self.mirror:
-            self.carry.actor_mirror_hc.copy_(torch.from_numpy(z["actor_mirror_hc"]))
-            self.carry.critic_mirror_hc.copy_(torch.from_numpy(z["critic_mirror_hc"]))
-            self.carry.lpf_mirror.copy_(torch.from_numpy(z["lpf_mirror"]))
+            self.carry.actor_mirror_hc.copy_(torch.from_numpy(x["actor_mirror_hc"]))
+            self.carry.critic_mirror_hc.copy_(torch.from_numpy(x["critic_mirror_hc"]))
+            self.carry.lpf_mirror.copy_(torch.from_numpy(x["lpf_mirror"]))
+
+    @classmethod
+    def load_task(cls, ckpt_path: str, device: Optional[torch.device] = None) -> "HumanoidWalkingTask":
+        """convert.py:36 `HumanoidWalkingTask.load_task(ckpt_path)`: rebuild the task from the checkpoint's config member and
+        load its state."""
+        cfg = ckpt_io.load_ckpt(ckpt_path, "config")
+        fields = {f.name for f in dataclasses.fields(HumanoidWalkingTaskConfig)}
+        kw = {k: v for k, v in cfg.items() if k in fields}
+        for k in ("action_latency_range", "fixed_command"):
+            if kw.get(k) is not None:
+                kw[k] = tuple(kw[k])
+        task = cls(HumanoidWalkingTaskConfig(**kw), device=device)
+        task.load_checkpoint(ckpt_path)
+        return task
+
+    def load_ckpt(self, path: str, init_params=None, part: str = "model"):
+        """convert.py:39 `task.load_ckpt(ckpt_path, init_params=..., part="model")[0]`: returns a 1-tuple-like list whose first element is
+        the requested part; for "model" a ModelView with `.actor` (named leaves) as convert.py:44-46 reads it."""
+        if part == "model":
+            flat = ckpt_io.load_ckpt(path, "model", hidden_size=self.H, depth=self.kcfg.depth)
+            return [ModelView(flat, self.H, self.kcfg.depth)]
+        return [ckpt_io.load_ckpt(path, part, hidden_size=self.H, depth=self.kcfg.depth)]
+
+    # ---- validation (train.py:1564 argmax=True; valid_every_n_steps train.py:1789) ----
+    def validate(self, num_envs: int = 64, seconds: Optional[float] = None, seed_offset: int = 7919) -> dict:
+        """Deterministic validation rollout: a separate small env set (its own context, carries and buffers, so training state is
+        untouched), actions = the distribution's mode, `render_length_seconds` long. Returns scalar statistics."""
+        seconds = self.config.render_length_seconds if seconds is None else seconds
+        T = max(1, int(round(seconds / self.config.ctrl_dt)))
+        key = (num_envs, T)
+        if getattr(self, "_valid", None) is None or self._valid[0] != key:
+            vcfg = self.config.to_kbj(num_envs) if num_envs % self.config.batch_size == 0 else dataclasses.replace(self.config, batch_size=num_envs).to_kbj(num_envs)
+            vcfg.rollout_len = T
+            vctx = B.Context(self.model_blob, vcfg, self.device.index or 0, torch.cuda.current_stream().cuda_stream)
+            self._valid = (key, vctx, CarryBuffers(num_envs, self.H, self.kcfg.depth, self.device, mirror=self.mirror),
+                           TrajBuffers(T, num_envs, self.H, self.kcfg.depth, self.device, mirror=self.mirror, reward_comps=True))
+        _, vctx, carry, tr = self._valid
+        seed = self.config.seed + seed_offset
+        carry.zero_()
+        vctx.env_reset_all(seed, tr.actor_obs[0], tr.critic_obs[0], tr.aux[0])
+        for t in range(T):
+            vctx.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], carry.c, seed, t, True, tr.action[t], tr.logp[t], tr.value[t])
+            vctx.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
+            vctx.carry_reset(carry.c, tr.aux[t].data_ptr() + 4 * L.AUX["DONE"], L.AUX["SIZE"])
+        vctx.rewards(tr.aux, T, tr.reward, tr.comps)
+        vctx.synchronize()
+        done = tr.done
+        fails, succ = float((done < 0).sum()), float((done > 0).sum())
+        out = {"valid/reward_per_step": float(tr.reward.mean()), "valid/failures_per_step": fails / (T * num_envs),
+               "valid/episode_length_s": float(T * num_envs / max(1.0, fails + succ + num_envs) * self.config.ctrl_dt), "valid/value_mean": float(tr.value.mean())}
+        for name, v in zip(constants.REWARD_NAMES, tr.comps.mean(dim=(0, 1)).cpu().tolist()):
+            out[f"valid/reward/{name}"] = v
+        return out
+
+    def scalars(self) -> dict:
+        """The scalars the reference's logger plots after each iteration (train.py:1783-1790): loss terms, reward, terminations."""
+        m = self.metrics.cpu().tolist()
+        names = ("loss", "policy_loss", "value_loss", "entropy", "clip_fraction", "approx_kl", "adv_mean", "adv_std", "action_mirror_loss", "value_mirror_loss")
+        out = {f"train/{n}": v for n, v in zip(names, m)}
+        done = self.traj.done
+        out["train/reward_per_step"] = float(self.traj.reward.mean())
+        out["train/failures_per_step"] = float((done < 0).float().mean())
+        out["train/truncations_per_step"] = float((done > 0).float().mean())
+        out["train/value_mean"] = float(self.traj.value.mean())
+        out["train/action_std_logp"] = float(self.traj.logp.mean())
+        if self.traj.comps is not None:
+            for name, v in self.reward_components().items():
+                out[f"reward/{name}"] = v
+        return out
 
     def export_actor(self, path: str):
         """convert.py's input: the actor's leaves, joint/command order and the flat carry size (host/export.py)."""
@@ -233,16 +408,65 @@ class HumanoidWalkingTask:
         return dict(zip(constants.REWARD_NAMES, self.traj.comps.mean(dim=(0, 1)).cpu().tolist()))
 
     @classmethod
-    def launch(cls, config: HumanoidWalkingTaskConfig, num_iterations: int = 10, log_every: int = 1):
-        """train.py:1760: build the task and run the training loop (single process; use bench.py / torchrun for N GPUs)."""
+    def launch(cls, config: HumanoidWalkingTaskConfig, num_iterations: int = 10, log_every: int = 1, run_dir: Optional[str] = None, quiet: bool = False):
+        """train.py:1760: build the task and run the training loop (single process; bench.py / torchrun drive N GPUs).
+        With `run_dir` (the reference's `humanoid_walking_task/run_N`): scalars go to `run_dir/logs` (CSV + TensorBoard event file),
+        `run_dir/checkpoints/ckpt.bin` is rewritten every `save_every_n_seconds` (train.py:1788, convert.sh:4) and at the end, and a
+        deterministic validation rollout runs every `valid_every_n_steps` iterations (train.py:1789)."""
+        from .scalars import ScalarLogger
         task = cls(config)
-        t0 = time.time()
+        logger, ckpt_path = None, None
+        if run_dir is not None:
+            logger = ScalarLogger(os.path.join(run_dir, "logs"))
+            os.makedirs(os.path.join(run_dir, "checkpoints"), exist_ok=True)
+            ckpt_path = os.path.join(run_dir, "checkpoints", "ckpt.bin")
+        t0 = last_save = last_valid = time.time()
         for it in range(num_iterations):
             task.train_iteration()
+            now = time.time()
             if (it + 1) % log_every == 0:
-                torch.cuda.synchronize()
-                m = task.metrics.cpu().tolist()
-                rew = float(task.traj.reward.mean())
-                print(f"iter {it + 1}: reward/step {rew:.4f} loss {m[0]:.4f} value_loss {m[2]:.4f} entropy {m[3]:.3f} "
-                      f"clipfrac {m[4]:.3f} | {task.env_steps_per_iteration() * (it + 1) / (time.time() - t0):.3e} env-steps/s")
+                sc = task.scalars()
+                sc["perf/env_steps_per_s"] = task.env_steps_per_iteration() * (it + 1) / (now - t0)
+                due = (config.valid_every_n_steps and (it + 1) % config.valid_every_n_steps == 0) or \
+                      (config.valid_every_n_seconds and now - last_valid >= config.valid_every_n_seconds)
+                if due:
+                    sc.update(task.validate())
+                    last_valid = now
+                if logger:
+                    logger.log(task.iteration, sc)
+                if not quiet:
+                    print(f"iter {it + 1}: reward/step {sc['train/reward_per_step']:.4f} loss {sc['train/loss']:.4f} value_loss {sc['train/value_loss']:.4f} "
+                          f"entropy {sc['train/entropy']:.3f} clipfrac {sc['train/clip_fraction']:.3f} | {sc['perf/env_steps_per_s']:.3e} env-steps/s")
+            if ckpt_path and config.save_every_n_seconds and now - last_save >= config.save_every_n_seconds:
+                task.save_checkpoint(ckpt_path)
+                last_save = now
+        if ckpt_path:
+            task.save_checkpoint(ckpt_path)
+        if logger:
+            logger.close()
         return task
+
+
+class ModelView:
+    """What convert.py:39-46 takes out of a checkpoint: `model.actor` with the leaves Actor.forward uses (train.py:847-941), as
+    numpy arrays under their equinox names, plus the carry layout convert.py:71-78 flattens."""
+
+    class _Net:
+        def __init__(self, leaves: dict, prefix: str, depth: int):
+            g = lambda k: leaves[f"{prefix}.{k}"]
+            self.input_proj = _Leaf(weight=g("input_proj.weight"), bias=g("input_proj.bias"))
+            self.rnns = tuple(_Leaf(weight_ih=g(f"rnns.{l}.weight_ih"), weight_hh=g(f"rnns.{l}.weight_hh"), bias=g(f"rnns.{l}.bias")) for l in range(depth))
+            self.output_proj = _Leaf(weight=g("output_proj.weight"), bias=g("output_proj.bias"))
+
+    def __init__(self, flat, hidden_size: int, depth: int = 2):
+        self.hidden_size, self.depth = hidden_size, depth
+        leaves = dict(ckpt_io.split_leaves(flat, hidden_size, depth))
+        self.leaves = leaves
+        self.actor = ModelView._Net(leaves, "actor", depth)
+        self.critic = ModelView._Net(leaves, "critic", depth)
+        self.carry_size = depth * 2 * hidden_size + L.NU     # convert.py:71: flat (depth, 2, H) LSTM carry + 20 low-pass floats
+
+
+class _Leaf:
+    def __init__(self, **kw):
+        self.__dict__.update(kw)

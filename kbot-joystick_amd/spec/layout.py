@@ -69,6 +69,12 @@ class Config(C.Structure):
         ("learning_rate", f32), ("adam_b1", f32), ("adam_b2", f32), ("adam_eps", f32), ("weight_decay", f32),
         ("adv_eps", f32), ("value_clip", f32), ("actor_mirror_loss_scale", f32), ("critic_mirror_loss_scale", f32),
         ("terrain_amp", f32), ("terrain_wavelength", f32), ("reserved_f", f32 * 4),
+        ("reward_scale", f32 * NREW),
+        ("rew_linvel_err", f32), ("rew_angvel_err", f32), ("rew_rollpitch_err", f32), ("rew_rollpitch_err_zero", f32),
+        ("rew_height_err", f32), ("rew_standard_height", f32), ("rew_foot_origin_height", f32),
+        ("rew_armpos_err", f32), ("rew_grace_period", f32), ("rew_touchdown_penalty", f32),
+        ("rew_feetorient_err", f32), ("rew_comdist_err", f32), ("rew_baseaccel_err", f32), ("rew_torque_err", f32),
+        ("reserved_r", f32 * 2),
     ]
 
 
@@ -124,6 +130,13 @@ def default_config(**overrides) -> Config:
     c.learning_rate, c.weight_decay = 5e-4, 1e-5                                  # train.py:95-102
     c.adam_b1, c.adam_b2, c.adam_eps, c.adv_eps, c.value_clip = 0.9, 0.999, 1e-8, 1e-6, 0.2
     c.terrain_amp, c.terrain_wavelength = 0.0, 2.0      # flat ground; BASELINE configs[4] sets terrain_amp = 0.05
+    # reward stack, KBJ_REW_* order (train.py:1225-1256)
+    for i, v in enumerate((0.2, 0.1, 0.2, 0.2, 0.2, 0.1, 0.1, 1.5, 0.1, 0.05, 0.1, 0.1)):
+        c.reward_scale[i] = v
+    c.rew_linvel_err, c.rew_angvel_err, c.rew_rollpitch_err, c.rew_rollpitch_err_zero = 0.2, 0.2, 0.03, 0.01
+    c.rew_height_err, c.rew_standard_height, c.rew_foot_origin_height = 0.02, 0.80, 0.06
+    c.rew_armpos_err, c.rew_grace_period, c.rew_touchdown_penalty = 0.1, 2.0, 0.4
+    c.rew_feetorient_err, c.rew_comdist_err, c.rew_baseaccel_err, c.rew_torque_err = 0.02, 0.04, 5.0, 5.0
     for k, v in overrides.items():
         if not hasattr(c, k):
             raise AttributeError(f"kbj_config has no field {k!r}")

@@ -114,6 +114,11 @@ int kbj_cpu_num_threads(void) {
   return 1;
 #endif
 }
+void kbj_cpu_set_num_threads(int n) {   // bench.py pins the thread count of the timed CPU baseline
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#endif
+}
 void kbj_cpu_threefry(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t* out) { threefry2x32(k0, k1, c0, c1, out[0], out[1]); }
 
 #define KBJ_EXPORTS(SUF, R)                                                                                                            \

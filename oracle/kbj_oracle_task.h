@@ -373,7 +373,8 @@ template <class R> struct Env {
 // aux: [T][stride] rows of KBJ_AUX_*; carry: KBJ_RC_*; out: reward[T], components[T][12] (unscaled terms)
 template <class R> void rewards_scan(const kbj_model* m, const kbj_config* c, const float* aux, size_t stride, int T, float* carry,
                                      float* reward, size_t rstride, float* comps, size_t cstride) {
-  static const R scales[KBJ_NREW] = {(R)0.2, (R)0.1, (R)0.2, (R)0.2, (R)0.2, (R)0.1, (R)0.1, (R)1.5, (R)0.1, (R)0.05, (R)0.1, (R)0.1};
+  R scales[KBJ_NREW];   // train.py:1224-1256, carried by kbj_config so that the stack is user-editable like get_rewards()
+  for (int k = 0; k < KBJ_NREW; ++k) scales[k] = (R)c->reward_scale[k];
   const R ctrl_dt = c->ctrl_dt;
   for (int t = 0; t < T; ++t) {
     const float* a = aux + (size_t)t * stride;
@@ -387,31 +388,31 @@ template <class R> void rewards_scan(const kbj_model* m, const kbj_config* c, co
       R ye[3] = {0, 0, be[2]}, yq[4], v[3] = {cmd[0], cmd[1], 0}, g[3];
       euler_to_quat(ye, yq); rotate_by_quat(v, yq, false, g);
       R ex = (R)a[KBJ_AUX_QVEL] - g[0], ey = (R)a[KBJ_AUX_QVEL + 1] - g[1], err = std::sqrt(ex * ex + ey * ey);
-      r[KBJ_REW_LINVEL] = std::exp(-(zc ? err : err * err) / (R)0.2);
+      r[KBJ_REW_LINVEL] = std::exp(-(zc ? err : err * err) / (R)c->rew_linvel_err);
     }
-    r[KBJ_REW_ANGVEL] = std::exp(-std::fabs((R)a[KBJ_AUX_QVEL + 5] - (R)cmd[2]) / (R)0.2);  // train.py:301-306
+    r[KBJ_REW_ANGVEL] = std::exp(-std::fabs((R)a[KBJ_AUX_QVEL + 5] - (R)cmd[2]) / (R)c->rew_angvel_err);  // train.py:301-306
     {  // roll_pitch (train.py:316-334)
       R e1[3] = {be[0], be[1], 0}, q1[4], e2[3] = {cmd[4], cmd[5], 0}, q2[4];
       euler_to_quat(e1, q1); euler_to_quat(e2, q2);
       R dt_ = q1[0] * q2[0] + q1[1] * q2[1] + q1[2] * q2[2] + q1[3] * q2[3];
-      r[KBJ_REW_ROLL_PITCH] = std::exp(-(1 - dt_ * dt_) / (zc ? (R)0.01 : (R)0.03));
+      r[KBJ_REW_ROLL_PITCH] = std::exp(-(1 - dt_ * dt_) / (zc ? (R)c->rew_rollpitch_err_zero : (R)c->rew_rollpitch_err));
     }
     {  // base_height (train.py:377-388)
-      R low = std::min((R)a[KBJ_AUX_LFZ] - (R)0.06, (R)a[KBJ_AUX_RFZ] - (R)0.06);
+      R low = std::min((R)a[KBJ_AUX_LFZ] - (R)c->rew_foot_origin_height, (R)a[KBJ_AUX_RFZ] - (R)c->rew_foot_origin_height);
       R h = (R)a[KBJ_AUX_BASEZ] - low;
-      r[KBJ_REW_BASE_HEIGHT] = std::exp(-std::fabs(h - ((R)cmd[3] + (R)0.80)) / (R)0.02);
+      r[KBJ_REW_BASE_HEIGHT] = std::exp(-std::fabs(h - ((R)cmd[3] + (R)c->rew_standard_height)) / (R)c->rew_height_err);
     }
     {  // arm_pos (train.py:261-265); xax.get_norm(.,"l2") is the elementwise square
       R e = 0;
       for (int j = 0; j < 10; ++j) { R dq = (R)a[KBJ_AUX_ARMQ + j] - ((R)cmd[6 + j] + (R)m->joint_bias[10 + j]); e += dq * dq; }
-      r[KBJ_REW_ARM_POS] = std::exp(-e / (R)0.1);
+      r[KBJ_REW_ARM_POS] = std::exp(-e / (R)c->rew_armpos_err);
     }
     bool cl = a[KBJ_AUX_TOUCH] > 0.1f, cr = a[KBJ_AUX_TOUCH + 1] > 0.1f;
     {  // single_contact (train.py:138-154), grace period 2.0 s
       R ts = (cl != cr) ? 0 : (R)carry[KBJ_RC_TSINGLE] + ctrl_dt;
-      if (zc) ts = 2.0;
+      if (zc) ts = (R)c->rew_grace_period;
       carry[KBJ_RC_TSINGLE] = (float)ts;
-      r[KBJ_REW_SINGLE_CONTACT] = zc ? 1 : (ts < (R)2.0 ? 1 : 0);
+      r[KBJ_REW_SINGLE_CONTACT] = zc ? 1 : (ts < (R)c->rew_grace_period ? 1 : 0);
     }
     r[KBJ_REW_NO_CONTACT] = zc ? 0 : ((cl || cr) ? 0 : 1);  // train.py:161-165
     {  // feet_airtime (train.py:197-213)
@@ -421,7 +422,7 @@ template <class R> void rewards_scan(const kbj_model* m, const kbj_config* c, co
         R prev_air = carry[KBJ_RC_AIRTIME + f];
         bool prev_con = carry[KBJ_RC_CONTACT + f] != 0;
         bool first = con[f] && !prev_con && !done;
-        rew += (prev_air - (R)0.4) * (first ? 1 : 0);
+        rew += (prev_air - (R)c->rew_touchdown_penalty) * (first ? 1 : 0);
         carry[KBJ_RC_AIRTIME + f] = (con[f] || done) ? 0.0f : (float)(prev_air + ctrl_dt);
         carry[KBJ_RC_CONTACT + f] = con[f] ? 1.0f : 0.0f;
       }
@@ -442,11 +443,11 @@ template <class R> void rewards_scan(const kbj_model* m, const kbj_config* c, co
         R d2 = tq[0] * fq0[0] + tq[1] * fq0[1] + tq[2] * fq0[2] + tq[3] * fq0[3];
         rp += 1 - d2 * d2;
       }
-      r[KBJ_REW_FEET_ORIENT] = std::exp(-(std::fabs((R)cmd[2]) > (R)1e-3 ? rp : rpy) / (R)0.02);
+      r[KBJ_REW_FEET_ORIENT] = std::exp(-(std::fabs((R)cmd[2]) > (R)1e-3 ? rp : rpy) / (R)c->rew_feetorient_err);
     }
     {  // com_distance (train.py:466-478)
       R cd = a[KBJ_AUX_COMDIST];
-      r[KBJ_REW_COM_DISTANCE] = (cd >= 0 && zc) ? std::exp(-cd / (R)0.04) : 0;
+      r[KBJ_REW_COM_DISTANCE] = (cd >= 0 && zc) ? std::exp(-cd / (R)c->rew_comdist_err) : 0;
     }
     {  // base_accel (train.py:487-494): velocity edge-padded at t = 0, difference zeroed after a done
       R e = 0;
@@ -454,11 +455,11 @@ template <class R> void rewards_scan(const kbj_model* m, const kbj_config* c, co
         const float* pa = aux + (size_t)(t - 1) * stride;
         if (pa[KBJ_AUX_DONE] == 0) for (int k = 0; k < 6; ++k) e += std::fabs((R)a[KBJ_AUX_QVEL + k] - (R)pa[KBJ_AUX_QVEL + k]);
       }
-      r[KBJ_REW_BASE_ACCEL] = std::exp(-e / (R)5.0);
+      r[KBJ_REW_BASE_ACCEL] = std::exp(-e / (R)c->rew_baseaccel_err);
     }
     {  // torque (train.py:503-506)
       R s = 0;
-      for (int u = 0; u < NU; ++u) s += std::exp(-std::fabs((R)a[KBJ_AUX_CTRL + u]) / (R)5.0);
+      for (int u = 0; u < NU; ++u) s += std::exp(-std::fabs((R)a[KBJ_AUX_CTRL + u]) / (R)c->rew_torque_err);
       r[KBJ_REW_TORQUE] = zc ? s / NU : 1;
     }
     R tot = 0;

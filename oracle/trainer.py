@@ -89,27 +89,40 @@ class OracleTrainer:
                                          tt(tr["action"])[:, ii], done[:, ii], ca, cc, self.carry0[2][ii])
         loss, metrics = ON.ppo_loss(self.cfg, lp, v, en, tt(tr["logp"])[:, ii], tt(tr["value"])[:, ii], adv[:, ii], target[:, ii])
         loss.backward()
-        return pf.grad.detach(), {k: float(x) for k, x in metrics.items()}
+        return pf.grad.detach(), {k: float(x.detach()) for k, x in metrics.items()}
 
-    def update(self, perms: list[np.ndarray]):
-        """perms: one env permutation per pass (the product draws them with torch.randperm on the host)."""
+    def update(self, perms: list[np.ndarray], allreduce: str = "per_step", reduce=None):
+        """perms: one env permutation per pass (the product draws them with torch.randperm on the host).
+        allreduce / reduce mirror HumanoidWalkingTask.update: `reduce(g)` sums g over the data-parallel ranks in place and returns
+        the 1/world scale; "per_pass" accumulates a pass's minibatch gradients and takes ONE step per pass."""
         L, T = self.L, self.T
         tr = self.traj
         tt = lambda a: torch.tensor(a, dtype=self.dt)
         adv, target = ON.gae(tt(tr["value"]), tt(tr["reward"]), tt(tr["aux"][:T, :, L.AUX["DONE"]]), self.cfg.gamma, self.cfg.lam)
         last = None
+        reduce = reduce or (lambda g: 1.0)
+        nmb = self.N // self.B
         for perm in perms:
-            for mb in range(self.N // self.B):
+            acc = torch.zeros_like(self.params)
+            for mb in range(nmb):
                 g, last = self.minibatch_grad(perm[mb * self.B:(mb + 1) * self.B], adv, target)
+                if allreduce == "per_pass":
+                    acc += g
+                    if mb + 1 < nmb:
+                        continue
+                    g = acc
+                scale = reduce(g)
+                if allreduce == "per_pass":
+                    scale /= nmb
                 self.opt_step += 1
-                ON.adamw_step(self.cfg, self.params, self.m, self.v, g, self.opt_step)
+                ON.adamw_step(self.cfg, self.params, self.m, self.v, g, self.opt_step, grad_scale=scale)
         return last
 
-    def train_iteration(self, perms: list[np.ndarray] | None = None):
+    def train_iteration(self, perms: list[np.ndarray] | None = None, allreduce: str = "per_step", reduce=None):
         self.rollout()
         if perms is None:
             rng = np.random.default_rng(self.seed + self.iteration)
             perms = [rng.permutation(self.N) for _ in range(self.cfg.num_passes)]
-        m = self.update(perms)
+        m = self.update(perms, allreduce, reduce)
         self.iteration += 1
         return m

@@ -58,6 +58,68 @@ def test_two_rank_sharding_and_allreduce():
     assert np.allclose(single.env.es[:, :54], both[:, :54], atol=1e-6)    # qpos/qvel: batch-size dependent BLAS rounding only
 
 
+def _worker_per_pass(rank, world, port, out):
+    import torch.distributed as dist
+    from kbot_joystick_amd.host import dist as D
+    from oracle.trainer import OracleTrainer
+    from oracle import nn as ON
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = compiler.load_model("kbot-headless")
+    n_local, off = D.env_shard(8, rank, world)
+    cfg = L.default_config(num_envs=n_local, env_id_offset=off, batch_size=2, rollout_len=4, hidden_size=16, num_passes=2)
+    params = (np.random.default_rng(0).uniform(-1, 1, ON.param_count(16)) / 4).astype(np.float32)
+    tr = OracleTrainer(model, cfg, seed=3, params=params, precision="f64")
+    perms = [np.arange(n_local), np.arange(n_local)[::-1].copy()]
+    calls = []
+
+    def reduce(g):
+        calls.append(1)
+        return D.allreduce_grad_(g, world)
+
+    tr.train_iteration(perms, allreduce="per_pass", reduce=reduce)
+    out[rank] = dict(params=tr.params.numpy(), steps=tr.opt_step, calls=len(calls))
+    dist.destroy_process_group()
+
+
+def test_two_rank_per_pass_accumulate():
+    """KBJ_ALLREDUCE=per_pass (north_star's "once per update"): ONE all-reduce and ONE optimizer step per pass; the result equals a
+    single process that averages the gradients of all (rank, minibatch) pairs of the pass."""
+    from oracle import oracle as O
+    from oracle import nn as ON
+    from oracle.trainer import OracleTrainer
+    O.build()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_per_pass, args=(2, 29519, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    assert r0["steps"] == r1["steps"] == 2 and r0["calls"] == r1["calls"] == 2      # 2 passes -> 2 exchanges, 2 steps
+    assert np.array_equal(r0["params"], r1["params"])
+    # single-process restatement: per pass, mean of the four (shard, minibatch) gradients, one AdamW step
+    model = compiler.load_model("kbot-headless")
+    params = (np.random.default_rng(0).uniform(-1, 1, ON.param_count(16)) / 4).astype(np.float32)
+    shards = []
+    for rank in range(2):
+        cfg = L.default_config(num_envs=4, env_id_offset=4 * rank, batch_size=2, rollout_len=4, hidden_size=16, num_passes=2)
+        tr = OracleTrainer(model, cfg, seed=3, params=params, precision="f64")
+        tr.rollout()
+        adv, tgt = ON.gae(torch.tensor(tr.traj["value"], dtype=torch.float64), torch.tensor(tr.traj["reward"], dtype=torch.float64),
+                          torch.tensor(tr.traj["aux"][:4, :, L.AUX["DONE"]], dtype=torch.float64), cfg.gamma, cfg.lam)
+        shards.append((tr, adv, tgt, cfg))
+    p = torch.tensor(params, dtype=torch.float64)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step, perm in enumerate([np.arange(4), np.arange(4)[::-1].copy()], start=1):
+        g = torch.zeros_like(p)
+        for tr, adv, tgt, cfg in shards:
+            tr.params = p.clone()
+            for mb in range(2):
+                gi, _ = tr.minibatch_grad(perm[2 * mb:2 * mb + 2], adv, tgt)
+                g += gi
+        ON.adamw_step(shards[0][3], p, m, v, g, step, grad_scale=1.0 / 4)
+    assert np.allclose(r0["params"], p.numpy(), rtol=0, atol=1e-12)
+
+
 def test_env_shard_helper():
     from kbot_joystick_amd.host import dist as D
     assert D.env_shard(65536, 3, 8) == (8192, 24576)

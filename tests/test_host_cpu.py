@@ -1,0 +1,90 @@
+"""Host-side pieces that need no GPU: the xax-layout checkpoint container, the scalar logger, reward / command overrides."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from kbot_joystick_amd.spec import constants, layout as L
+
+
+def test_ckpt_roundtrip_and_actor_contract(tmp_path):
+    """convert.py:36-46,67-78: `load_ckpt(part="model")` gives the actor's leaves in equinox order; carry = depth*2*H + 20."""
+    from kbot_joystick_amd.host import ckpt
+    from kbot_joystick_amd.host.task import ModelView
+    H, depth = 64, 2
+    pa, pc = L.param_count(H, depth)
+    rng = np.random.default_rng(0)
+    p, m, v = (rng.standard_normal(pa + pc).astype(np.float32) for _ in range(3))
+    path = str(tmp_path / "ckpt.bin")
+    ckpt.save_ckpt(path, p, m, v, 11, H, depth, dict(num_steps=3, opt_step=11), dict(hidden_size=H, depth=depth, robot="kbot"),
+                   extras=dict(es=np.arange(12, dtype=np.float32).reshape(3, 4)))
+    z = ckpt.load_ckpt(path)
+    assert np.array_equal(z["model"], p) and np.array_equal(z["opt_state"]["mu"], m) and np.array_equal(z["opt_state"]["nu"], v)
+    assert z["opt_state"]["count"] == 11 and z["state"]["num_steps"] == 3 and z["config"]["robot"] == "kbot"
+    assert np.array_equal(z["extras"]["es"], np.arange(12, dtype=np.float32).reshape(3, 4))
+    assert np.array_equal(ckpt.load_ckpt(path, "model"), p)                           # hidden size read from the config member
+    # the container: gzip tar with the four upstream member names first
+    import tarfile
+    with tarfile.open(path, "r:gz") as tar:
+        assert tar.getnames()[:4] == ["model_0", "opt_state_0", "state", "config"]
+        blob = tar.extractfile("model_0").read()
+    assert blob[:6] == b"\x93NUMPY"                                                   # back-to-back numpy.save blobs
+    mv = ModelView(z["model"], H, depth)
+    assert mv.actor.input_proj.weight.shape == (H, 65) and mv.actor.output_proj.weight.shape == (40, H)
+    assert mv.actor.rnns[1].weight_hh.shape == (4 * H, H) and mv.critic.input_proj.weight.shape == (H, 475)
+    assert mv.carry_size == depth * 2 * H + len(constants.JOINT_NAMES)
+    flat_actor = np.concatenate([a.ravel() for n, a in ckpt.split_leaves(p, H, depth) if n.startswith("actor.")])
+    assert np.array_equal(flat_actor, p[:pa])                                         # the actor is the prefix of the flat vector
+    with pytest.raises(FileNotFoundError):
+        ckpt.load_ckpt(str(tmp_path / "missing.bin"))                                 # convert.py:33-34
+    with pytest.raises(ValueError):
+        ckpt.load_ckpt(path, "model", hidden_size=128)
+
+
+def test_scalar_logger_writes_csv_and_tensorboard_events(tmp_path):
+    from kbot_joystick_amd.host import scalars as S
+    assert S.crc32c(b"123456789") == 0xE3069283                                       # CRC-32C check value
+    lg = S.ScalarLogger(str(tmp_path))
+    lg.log(1, {"train/loss": 1.5, "reward/linvel": 0.25})
+    lg.log(2, {"train/loss": 1.25, "valid/reward_per_step": 0.5})
+    lg.close()
+    ev = S.read_event_file(glob.glob(str(tmp_path / "events.out.tfevents.*"))[0])     # verifies both CRCs of every record
+    assert ev == [(1, {"train/loss": 1.5, "reward/linvel": 0.25}), (2, {"train/loss": 1.25, "valid/reward_per_step": 0.5})]
+    rows = open(tmp_path / "scalars.csv").read().strip().splitlines()
+    assert rows[0] == "step,wall_time,train/loss,reward/linvel,valid/reward_per_step" and len(rows) == 3
+
+
+def test_reward_and_command_overrides_reach_kbj_config():
+    from kbot_joystick_amd.host.task import launch_config
+    c = launch_config(reward_scales={"torque": 0.0, "feet_airtime": 2.0}, reward_params={"base_height": {"standard_height": 0.85}},
+                      command_ranges={"vx_range": (-1.0, 2.0)})
+    k = c.to_kbj(4096)
+    assert k.reward_scale[constants.REWARD_NAMES.index("torque")] == 0.0 and k.reward_scale[constants.REWARD_NAMES.index("feet_airtime")] == 2.0
+    assert abs(k.rew_standard_height - 0.85) < 1e-6 and (k.vx_lo, k.vx_hi) == (-1.0, 2.0)
+    with pytest.raises(KeyError):
+        launch_config(reward_scales={"nope": 1.0}).to_kbj(4096)
+    with pytest.raises(KeyError):
+        launch_config(reward_params={"torque": {"standard_height": 1.0}}).to_kbj(4096)
+    with pytest.raises(ValueError):
+        launch_config(allreduce="sometimes").to_kbj(4096)
+
+
+def test_oracle_rewards_follow_the_config(model):
+    """The oracle reads the reward table from kbj_config: doubling a scale changes the total by exactly that term."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(0)
+    N, T = 8, 5
+    aux = rng.normal(size=(T, N, L.AUX["SIZE"])).astype(np.float32) * 0.1
+    aux[:, :, L.AUX["BQUAT"]] = 1.0
+    aux[:, :, L.AUX["DONE"]:] = 0
+    base = L.default_config(num_envs=N, batch_size=N)
+    r0, c0 = O.Oracle(model, base, 0).rewards(aux)
+    i = constants.REWARD_NAMES.index("angvel")
+    mod = L.default_config(num_envs=N, batch_size=N)
+    mod.reward_scale[i] = 2 * base.reward_scale[i]
+    r1, c1 = O.Oracle(model, mod, 0).rewards(aux)
+    assert np.allclose(c0, c1) and np.allclose(r1 - r0, base.reward_scale[i] * c0[:, :, i], atol=1e-6)
+    mod2 = L.default_config(num_envs=N, batch_size=N, rew_angvel_err=0.4)
+    _, c2 = O.Oracle(model, mod2, 0).rewards(aux)
+    assert np.allclose(c2[:, :, i], np.sqrt(c0[:, :, i]), atol=1e-6)                 # exp(-e/0.4) = sqrt(exp(-e/0.2))

@@ -15,6 +15,7 @@ a, c, x = torch.zeros(N, 68, device=dev), torch.zeros(N, 476, device=dev), torch
 a2, c2, x2 = torch.zeros_like(a), torch.zeros_like(c), torch.zeros_like(x)
 ctx.env_reset_all(1, a, c, x)
 act = torch.from_numpy(np.tile(np.array(m.joint_bias, np.float32), (N, 1))).cuda()
+act = act + float(os.environ.get("KBJ_ACT_NOISE", "0.3")) * torch.randn(N, 20, device=dev, generator=torch.Generator(device=dev).manual_seed(0))   # a random-init policy's spread
 for _ in range(30): ctx.env_step(act, x, a2, c2, x2)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

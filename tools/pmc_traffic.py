@@ -44,6 +44,16 @@ def main():
         rd, wr = 2.0 * f_kib * 1024.0, w_kib * 1024.0
         out[name] = dict(hbm_bytes_per_launch=round(rd + wr), read_bytes=round(rd), write_bytes=round(wr), fetch_size_kib_raw=round(f_kib, 2),
                          write_size_kib_raw=round(w_kib, 2), launches=max(nf, nw), fetch_correction="x2 (gfx950)")
+    # provenance: bench.py only reports these bytes while the kernel sources are the ones profiled
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import subprocess
+    from bench import source_fingerprint
+    try:
+        git = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+    except Exception:
+        git = None
+    out["_meta"] = dict(source_fingerprint=source_fingerprint(), git=git, command=os.environ.get("KBJ_PROFILE_CMD"))
     json.dump(out, sys.stdout, indent=1)
     print()
 
