@@ -58,10 +58,12 @@ struct KbjShared {
   union {
     struct { float crb[NB][10]; };
     struct { float cfrc[NB][6], cfrc_acc[NB][6]; };
+#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)
     struct {
       float A[4][12][12];  // chain-local blocks [ankle..hip | base 6], row 11 = right-hand side
       float B[7][8];       // base block, row 6 = right-hand side
-    };
+    };                     // (LDS formulation of arrow_solve only; the product kernel keeps the blocks in registers)
+#endif
   } u;
   float Mb[6][6];       // mass matrix, base block
   float Mc[4][5][11];   // limb c, dof a (hip..ankle): columns 0..5 base dofs, 6..10 the limb's own dofs

@@ -11,6 +11,7 @@
 // complements are summed into the 6x6 base block, and the right-hand side rides along as an extra row.
 #pragma once
 #include "kbj_env_core.h"
+#include <type_traits>
 
 // diagnostics (tools/env_stamps.py, -DKBJ_ENV_STAMPS): shader-clock cycles of env 0 per phase, accumulated in a device array
 #if defined(KBJ_ENV_STAMPS) && !defined(KBJ_EMU)
@@ -295,6 +296,8 @@ KBJ_DEV int tri_count(int p) { return 65 - p * (23 - p) / 2; }  // entries with 
 #define KBJ_RCP(x) __frcp_rn(x)
 #endif
 
+#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)
+// LDS formulation (host emulation / A-B builds): one phase per pivot over the block entries spread across the lanes
 KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
   PFOR(w, 4 * 77) {
     int c = w / 77, e = w % 77, i = TRI.i[e], j = TRI.j[e];
@@ -370,6 +373,109 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
   }
   KBJ_SYNC();
 }
+#else
+// Register formulation (the product kernel). Lane 16 c + r of DPP row c holds ROW r of chain c's augmented block in registers
+// a[0..10] (r = 0..4 chain dofs ankle..hip, 5..10 base dofs, 11 right-hand side; lanes 12..15 shadow row 11 and are never read).
+// A pivot is pure VALU: `row_newbcast` hands lane j's entry of the pivot column to the whole row, so a[j] -= l_p * A[j][p] is one
+// DPP move + one FMA, with no LDS traffic and no phase boundary. The four Schur complements are summed across the rows
+// (xor-16 / xor-32 exchanges), every row then factors the 6 x 6 base block redundantly, and both back-substitutions are
+// 16-lane DPP row sums. ~0.35k instructions per solve instead of 16 LDS phases.
+template <int I, int N, class F> KBJ_DEV void static_for(F&& f) {
+  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+template <int J> KBJ_DEV float row_bcast(float v) {   // value of lane J of each 16-lane row, in every lane of that row
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xF, 0xF, true));
+}
+KBJ_DEV float row_sum16(float v) {  // sum over the 16 lanes of each DPP row, in every lane of the row
+  v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v); v = dpp_add<0x140>(v);
+  return v;
+}
+KBJ_DEV float rows_sum4(float v) {  // sum over the four rows (same lane-in-row), in every row
+  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));                       // lane ^ 16
+  v += __int_as_float(__builtin_amdgcn_ds_bpermute((KBJ_LANE ^ 32) << 2, __float_as_int(v)));      // lane ^ 32
+  return v;
+}
+
+KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
+  const int lane = KBJ_LANE, c = lane >> 4, r = lane & 15;
+  const int rr = r < 11 ? r : 11;
+  const int col = rr < 5 ? 10 - rr : rr - 5;   // column of Mc / Jc this row stands for (rows 0..10)
+  float a[11];
+  {
+    const float* src = rr < 11 ? &S.Mc[c][4][col] : rhs + 10 + 5 * c;   // A[r][j], j < 5: M(chain dof 4 - j, this row's dof) resp. rhs
+    const int stride = rr < 11 ? -11 : -1;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) a[j] = src[j * stride];
+#pragma unroll
+    for (int j = 5; j < 11; ++j) a[j] = 0.0f;
+  }
+  if (hess) {
+    if (c < 2 && rr < 11) {  // legs: J^T D J of this leg's 16 pyramid rows (those in their quadratic zone)
+      for (int k = 0; k < 16; ++k) {
+        const int row = 16 * c + k;
+        const float w = S.quad[ROW_CON + row] ? S.D[ROW_CON + row] : 0.0f;
+        if (__builtin_amdgcn_ballot_w64(w != 0.0f) == 0) continue;   // neither leg has this row active
+        const float* J = S.Jc[row];
+        const float t = w * J[col];
+        a[0] = fmaf(t, J[10], a[0]); a[1] = fmaf(t, J[9], a[1]); a[2] = fmaf(t, J[8], a[2]); a[3] = fmaf(t, J[7], a[3]); a[4] = fmaf(t, J[6], a[4]);
+        a[5] = fmaf(t, J[0], a[5]); a[6] = fmaf(t, J[1], a[6]); a[7] = fmaf(t, J[2], a[7]); a[8] = fmaf(t, J[3], a[8]); a[9] = fmaf(t, J[4], a[9]);
+        a[10] = fmaf(t, J[5], a[10]);
+      }
+    }
+    if (rr < 5) {  // friction-loss and joint-limit rows are unit vectors: they only touch the diagonal
+      const int u = 5 * c + 4 - rr;
+      const float dd = (S.quad[u] ? S.D[u] : 0.0f) + (S.quad[ROW_LIM + u] ? S.D[ROW_LIM + u] : 0.0f);
+#pragma unroll
+      for (int j = 0; j < 5; ++j) a[j] += rr == j ? dd : 0.0f;
+    }
+  }
+  // eliminate the five chain dofs; column p keeps its unscaled entries (L_ip D_p)
+  float inv[5];
+  static_for<0, 5>([&](auto P) {
+    constexpr int p = decltype(P)::value;
+    inv[p] = KBJ_RCP(row_bcast<p>(a[p]));
+    const float lp = -a[p] * inv[p];
+    static_for<p + 1, 11>([&](auto Jc_) {
+      constexpr int j = decltype(Jc_)::value;
+      a[j] = fmaf(lp, row_bcast<j>(a[p]), a[j]);
+    });
+  });
+  // base block: M_base + the four Schur complements (rows 5..10) and the reduced right-hand side (row 11)
+  float b[6];
+  {
+    const float* bsrc = (rr >= 5 && rr < 11) ? &S.Mb[rr - 5][0] : rhs;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) b[j] = rows_sum4(a[5 + j]) + bsrc[j];
+  }
+  float binv[6];
+  static_for<0, 6>([&](auto Q) {
+    constexpr int q = decltype(Q)::value;
+    binv[q] = KBJ_RCP(row_bcast<5 + q>(b[q]));
+    const float lp = -b[q] * binv[q];
+    static_for<q + 1, 6>([&](auto Jc_) {
+      constexpr int j = decltype(Jc_)::value;
+      b[j] = fmaf(lp, row_bcast<5 + j>(b[q]), b[j]);
+    });
+  });
+  // back-substitution: xm = this row's unknown once solved (-1 on the right-hand-side row, so a row sum gives rhs - sum of products)
+  float xm = r == 11 ? -1.0f : 0.0f;
+  static_for<0, 6>([&](auto K) {
+    constexpr int p = 5 - decltype(K)::value;
+    const float prod = (r > 5 + p && r <= 11) ? b[p] * xm : 0.0f;
+    const float xp = -row_sum16(prod) * binv[p];
+    xm = r == 5 + p ? xp : xm;
+  });
+  static_for<0, 5>([&](auto K) {
+    constexpr int p = 4 - decltype(K)::value;
+    const float prod = (r > p && r <= 11) ? a[p] * xm : 0.0f;
+    const float xp = -row_sum16(prod) * inv[p];
+    xm = r == p ? xp : xm;
+  });
+  if (r < 5) S.vec[10 + 5 * c - r] = xm;
+  else if (c == 0 && r <= 10) S.vec[r - 5] = xm;
+  KBJ_SYNC();
+}
+#endif
 
 // y = M v using the tree sparsity
 KBJ_DEV float mul_M_row(const KbjShared& S, int i, const float* v) {

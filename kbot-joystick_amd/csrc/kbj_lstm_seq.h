@@ -25,7 +25,7 @@ typedef float f32x4m __attribute__((ext_vector_type(4)));
 
 constexpr int SEQ_ROWS = 32;   // rows per workgroup
 constexpr int SEQ_UNITS = 16;  // hidden units per workgroup
-constexpr unsigned SEQ_SPIN_LIMIT = 1u << 24;
+constexpr unsigned SEQ_SPIN_LIMIT = 1u << 24;   // default bound of every inter-workgroup spin (args.spin_limit; shorter under fault injection)
 
 struct SeqFwdArgs {
   float* G;            // [T][B][4H] in: x W_ih^T + b, out: gate activations (i,f,g,o)
@@ -39,6 +39,7 @@ struct SeqFwdArgs {
   unsigned* err;       // set to 1 on a spin timeout
   int T, B;
   long long* stamps;   // optional [T][6] shader-clock stamps of workgroup 0 (diagnostics), else null
+  unsigned spin_limit = SEQ_SPIN_LIMIT;
 };
 
 struct SeqBwdArgs {
@@ -53,6 +54,7 @@ struct SeqBwdArgs {
   unsigned* err;
   int T, B;
   float* db;             // optional [4H]: bias gradient accumulated with atomics (column sums of dG)
+  unsigned spin_limit = SEQ_SPIN_LIMIT;
 };
 
 // gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each; shared with the rollout cell kernel)
@@ -62,7 +64,7 @@ __device__ __forceinline__ float seq_tanh(float x) { float xc = fminf(fmaxf(x, -
 // wait until *ctr >= target: one lane polls the one word (relaxed, agent scope); returns false on timeout
 // flags: one word per producer workgroup of the row group (nflags consecutive words = one cache line), each holding the
 // number of steps that producer has published; lanes 0..nflags-1 of wave 0 poll them with sc1 loads until all reach target
-__device__ __forceinline__ bool seq_wait(unsigned* flags, int nflags, unsigned target, unsigned* err, int* lds_flag) {
+__device__ __forceinline__ bool seq_wait(unsigned* flags, int nflags, unsigned target, unsigned* err, int* lds_flag, unsigned spin_limit) {
   if (threadIdx.x < 64) {
     unsigned spins = 0;
     int ok = 1;
@@ -71,7 +73,7 @@ __device__ __forceinline__ bool seq_wait(unsigned* flags, int nflags, unsigned t
       bool mine = l >= nflags || __hip_atomic_load(flags + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
       if (__all(mine)) break;
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > SEQ_SPIN_LIMIT) { ok = 0; if (l == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if (++spins > spin_limit) { ok = 0; if (l == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
     }
     if (l == 0) *lds_flag = ok;
   }
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   fetch_inputs(0);
   for (int t = 0; t < T; ++t) {
     SEQ_STAMP(0);
-    if (t > 0) { if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)t, a.err, &flag)) return; }
+    if (t > 0) { if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)t, a.err, &flag, a.spin_limit)) return; }
     SEQ_STAMP(1);
     SeqTile<H, NTH> tile;
     tile.load(a.Hm + (size_t)t * B * H, H, r0, B);
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
     };
     if (last) prefetch();
     else {
-      if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)(T - 1 - t), a.err, &flag)) return;
+      if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)(T - 1 - t), a.err, &flag, a.spin_limit)) return;
       f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
       const float* src = a.dG + (size_t)(t + 1) * B * 4 * H;
       SeqTile<H, NTH> tile;

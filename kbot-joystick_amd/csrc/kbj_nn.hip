@@ -166,12 +166,17 @@ int g_seq_uw = 2;
 // fault injection for the tests (KBJ_DEBUG_DROP_SEQ_WG = n at kbj_create): the next n forward-recurrence launches run with one
 // workgroup missing, so its partners' bounded spins expire and the timeout / fail-stop path is exercised on real hardware
 int g_seq_drop = 0;
-template <int H, int UW> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a) {
+unsigned g_seq_spin_limit = SEQ_SPIN_LIMIT;
+template <int H, int UW> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a0) {
+  SeqFwdArgs a = a0;
+  a.spin_limit = g_seq_spin_limit;
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
   if (g_seq_drop > 0 && grid > 1) { --g_seq_drop; --grid; }
   hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
-template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a) {
+template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0) {
+  SeqBwdArgs a = a0;
+  a.spin_limit = g_seq_spin_limit;
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
   hipLaunchKernelGGL((lstm_seq_bwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
@@ -295,6 +300,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
   g_seq_uw = getenv("KBJ_SEQ_UW") ? atoi(getenv("KBJ_SEQ_UW")) : 2;
   if (g_seq_uw != 1 && g_seq_uw != 2) return kbj_fail(ctx, "KBJ_SEQ_UW must be 1 or 2");
   g_seq_drop = getenv("KBJ_DEBUG_DROP_SEQ_WG") ? atoi(getenv("KBJ_DEBUG_DROP_SEQ_WG")) : 0;
+  g_seq_spin_limit = g_seq_drop > 0 ? (1u << 15) : SEQ_SPIN_LIMIT;   // an injected fault should not cost the full 2^24-spin bound
   // Residency of the persistent recurrences: the workgroups of one launch spin on each other, and kbj_ppo_grad keeps TWO launches
   // (actor-type and critic-type net, one per stream; the mirror branches queue behind them on the same two streams) in flight, so
   // 2 x grid workgroups must be resident at once. Every other kernel of the schedule (GEMMs, heads) terminates on its own, so it can

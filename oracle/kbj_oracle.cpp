@@ -31,12 +31,13 @@ void reset_all(const kbj_model* m, const kbj_config* c, uint32_t seed, float* ep
 
 template <class R>
 void env_step(const kbj_model* m, const kbj_config* c, uint32_t seed, float* ep, float* es, const float* action, float* aux_t,
-              float* actor_next, float* critic_next, float* aux_next) {
+              float* actor_next, float* critic_next, float* aux_next, int* diag = nullptr) {
   int N = c->num_envs;
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < N; ++i) {
     Env<R>* e = new Env<R>();
     e->bind(m, c, seed, c->env_id_offset + i, ep + (size_t)i * KBJ_EP_SIZE, es + (size_t)i * KBJ_ES_SIZE);
+    if (diag) { e->diag = diag + 4 * (size_t)i; for (int k = 0; k < 4; ++k) e->diag[k] = 0; }
     e->step(action + (size_t)i * KBJ_NU, aux_t + (size_t)i * KBJ_AUX_SIZE, actor_next + (size_t)i * KBJ_LD_ACTOR,
             critic_next + (size_t)i * KBJ_LD_CRITIC, aux_next + (size_t)i * KBJ_AUX_SIZE);
     delete e;
@@ -126,6 +127,12 @@ void kbj_cpu_threefry(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32
                                 float* x0) { reset_all<R>(m, c, seed, ep, es, a0, c0, x0); }                                          \
   void kbj_cpu##SUF##_env_step(const kbj_model* m, const kbj_config* c, uint32_t seed, float* ep, float* es, const float* action,      \
                                float* aux_t, float* an, float* cn, float* xn) { env_step<R>(m, c, seed, ep, es, action, aux_t, an, cn, xn); } \
+  /* same step + per-env int[4] diagnostics: max / total Newton iterations over the substeps, hashes of the active-contact history */ \
+  /* and of the force-carrying-row history (tools/parity_quantiles.py: which env-steps sit on a discrete switch) */                   \
+  void kbj_cpu##SUF##_env_step_diag(const kbj_model* m, const kbj_config* c, uint32_t seed, float* ep, float* es, const float* action, \
+                                    float* aux_t, float* an, float* cn, float* xn, int* diag) {                                      \
+    env_step<R>(m, c, seed, ep, es, action, aux_t, an, cn, xn, diag);                                                                 \
+  }                                                                                                                                    \
   void kbj_cpu##SUF##_rewards(const kbj_model* m, const kbj_config* c, const float* aux, int T, int N, float* carry, float* reward,    \
                               float* comps) { rewards<R>(m, c, aux, T, N, carry, reward, comps); }                                     \
   void kbj_cpu##SUF##_forward(const kbj_model* m, const kbj_config* c, const float* ep, const double* qpos, const double* qvel,        \

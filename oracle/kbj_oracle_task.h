@@ -309,6 +309,7 @@ template <class R> struct Env {
 
   // one control step: action latency/drop, push event, 5 physics substeps, termination, reset / command update,
   // next observation. `aux_t` is the record of this step, `*_next` the rows of step t+1.
+  int* diag = nullptr;   // optional int[4], see step()
   void step(const float* action, float* aux_t, float* actor_next, float* critic_next, float* aux_next) {
     load_state();
     uint32_t st = stepctr();
@@ -338,6 +339,15 @@ template <class R> struct Env {
       const float* a = s >= lat ? a_eff : es + KBJ_ES_ACT_PREV;
       pd_torque(a, last_ctrl);
       phy.forward(qpos, qvel, last_ctrl, pushing ? push : nullptr, warm, d);
+      if (diag) {   // discrete solver state of this substep (parity diagnostics: which env-steps sit on a discrete switch)
+        diag[0] = std::max(diag[0], d.solver_iters);
+        diag[1] += d.solver_iters;
+        int cbits = 0, nz = 0;
+        for (int k = 0; k < NCON; ++k) cbits |= d.con_active[k] << k;
+        for (int r = 0; r < NEFC; ++r) nz += d.efc_force[r] != 0 ? (r < ROW_LIM ? (std::fabs(d.efc_force[r]) < d.efc_floss[r] ? 1 : 3) : 1) : 0;
+        diag[2] = diag[2] * 257 + cbits;          // history of the active-contact set
+        diag[3] = diag[3] * 131 + nz;             // history of (rows carrying force, friction rows saturated)
+      }
       phy.integrate(qpos, qvel, d);
       for (int i = 0; i < NV; ++i) warm[i] = d.qacc[i];
     }

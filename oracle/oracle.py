@@ -83,6 +83,16 @@ class Oracle:
                              _p(aux_t), _p(a), _p(c), _p(x))
         return a, c, x
 
+    def step_diag(self, action: np.ndarray, aux_t: np.ndarray):
+        """step() + per-env int32[4] diagnostics: (max Newton iterations, total iterations, active-contact history hash,
+        force-carrying-row history hash) over the substeps of this control step."""
+        action = np.ascontiguousarray(action, np.float32)
+        a, c, x = self.new_obs()
+        diag = np.zeros((self.N, 4), np.int32)
+        self._fn("env_step_diag")(_ref(self.model), _ref(self.config), C.c_uint32(self.seed), _p(self.ep), _p(self.es), _p(action),
+                                  _p(aux_t), _p(a), _p(c), _p(x), _p(diag, C.c_int32))
+        return a, c, x, diag
+
     def rewards(self, aux: np.ndarray):
         """aux [T,N,72] -> (reward [T,N], components [T,N,12]); updates the reward carry."""
         T, N = aux.shape[:2]

@@ -1,0 +1,195 @@
+"""GPU tests of the host-side contract around the hot path: bit-exact checkpoint resume (xax-layout ckpt.bin), user-edited reward
+table vs the oracle, deterministic validation rollouts, the scalar logger fed by a real run, fail-stop behaviour when a persistent
+recurrence times out, the accumulate-per-pass exchange variant, and bench.py's own N-rank launch."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from kbot_joystick_amd.spec import constants, layout as L
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _small(**kw):
+    from kbot_joystick_amd.host.task import launch_config
+    base = dict(num_envs=64, batch_size=32, hidden_size=64, rollout_length_seconds=0.2, robot="kbot-headless", seed=4, num_passes=1)
+    base.update(kw)
+    return launch_config(**base)
+
+
+@pytest.mark.parametrize("mirror", [False, True])
+def test_checkpoint_resume_is_bit_identical(tmp_path, mirror):
+    """save_checkpoint after iteration 2, load into a FRESH task: the rollout of iteration 3 is BIT-identical in both runs (parameters,
+    env rows, reward carries, model carries, pending observation rows all travel through ckpt.bin) and the update agrees to the
+    run-to-run noise of the fp32 atomic gradient accumulation (the split-K weight gradients add in arrival order)."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    kw = dict(actor_mirror_loss_scale=1.0, critic_mirror_loss_scale=0.01) if mirror else {}
+    cfg = _small(num_passes=2, **kw)
+    a = HumanoidWalkingTask(cfg)
+    for _ in range(2):
+        a.train_iteration()
+    path = str(tmp_path / "ckpt.bin")
+    a.save_checkpoint(path)
+    a.train_iteration()
+    torch.cuda.synchronize()
+    b = HumanoidWalkingTask(cfg)
+    b.load_checkpoint(path)
+    assert (b.iteration, b.opt_step) == (2, a.opt_step - 4)
+    b.train_iteration()
+    torch.cuda.synchronize()
+    for name in ("actor_obs", "critic_obs", "aux", "action", "logp", "value", "reward", "carry0_actor_hc", "carry0_critic_hc", "carry0_lpf"):
+        assert torch.equal(getattr(a.traj, name), getattr(b.traj, name)), name
+    for name, tol in (("params", 1e-6), ("opt_m", 1e-6), ("opt_v", 1e-8)):
+        assert torch.allclose(getattr(a, name), getattr(b, name), rtol=0, atol=tol), name
+    assert a.opt_step == b.opt_step
+    assert torch.equal(a.carry.actor_hc, b.carry.actor_hc) and torch.equal(a.carry.lpf, b.carry.lpf)
+    ea, eb = a.ctx.env_get_state(), b.ctx.env_get_state()
+    assert np.array_equal(ea[0], eb[0]) and np.array_equal(ea[1].view(np.uint32), eb[1].view(np.uint32))
+    assert np.array_equal(a.ctx.env_get_reward_carry(), b.ctx.env_get_reward_carry())
+    # load_task rebuilds the task from the checkpoint's own config member (convert.py:36); load_ckpt(part="model") as convert.py:39
+    c = HumanoidWalkingTask.load_task(path)
+    assert c.config.hidden_size == cfg.hidden_size and c.iteration == 2
+    mv = c.load_ckpt(path, part="model")[0]
+    n = c.ctx.actor_param_count()
+    flat = np.concatenate([mv.leaves[k].ravel() for k in mv.leaves if k.startswith("actor.")])
+    assert flat.size == n and mv.carry_size == 2 * 2 * cfg.hidden_size + 20
+    for t in (a, b, c):
+        t.ctx.close()
+
+
+def test_edited_reward_table_matches_oracle(model):
+    """f3: scales / error scales are data (kbj_config), not kernel literals: a user-edited stack gives the oracle's numbers."""
+    import torch
+    from kbot_joystick_amd.host import binding as B
+    from oracle import oracle as O
+    N, T = 64, 12
+    rng = np.random.default_rng(3)
+    over = dict(rew_linvel_err=0.35, rew_rollpitch_err=0.05, rew_standard_height=0.75, rew_grace_period=0.1, rew_touchdown_penalty=0.2, rew_torque_err=2.0)
+    cfg = L.default_config(num_envs=N, batch_size=N, **over)
+    for i, s in enumerate((0.3, 0.0, 0.1, 0.4, 0.0, 0.2, 0.3, 0.7, 0.05, 0.2, 0.0, 0.6)):
+        cfg.reward_scale[i] = s
+    base = L.default_config(num_envs=N, batch_size=N)
+    # a plausible trajectory: roll the oracle env for T steps with random actions
+    o = O.Oracle(model, cfg, seed=2, precision="f32")
+    _, _, x = o.reset_all()
+    aux = np.zeros((T + 1, N, L.AUX["SIZE"]), np.float32)
+    aux[0] = x
+    from tests import helpers as H
+    for t in range(T):
+        _, _, aux[t + 1] = o.step(H.random_actions(model, rng, N, 0.5), aux[t])
+    r_o, c_o = o.rewards(aux[:T])
+    r_b, _ = O.Oracle(model, base, seed=2, precision="f32").rewards(aux[:T])
+    assert np.abs(r_o - r_b).max() > 0.05                                            # the edit really changes the reward
+    ctx = B.Context(model, cfg, 0, torch.cuda.current_stream().cuda_stream)
+    rew = torch.zeros(T, N, device="cuda:0"); comps = torch.zeros(T, N, L.NREW, device="cuda:0")
+    a, c, xx = (torch.zeros(N, d, device="cuda:0") for d in (L.LD_ACTOR, L.LD_CRITIC, L.AUX["SIZE"]))
+    ctx.env_reset_all(2, a, c, xx)                                                    # initialises the reward carries as the oracle's
+    ctx.rewards(torch.from_numpy(aux[:T].copy()).cuda(), T, rew, comps)
+    ctx.synchronize()
+    assert np.abs(comps.cpu().numpy() - c_o).max() < 2e-4 and np.abs(rew.cpu().numpy() - r_o).max() < 2e-4
+    ctx.close()
+
+
+def test_validation_is_deterministic_and_leaves_training_untouched():
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    task = HumanoidWalkingTask(_small(log_reward_components=True))
+    task.train_iteration()
+    p0, es0 = task.params.clone(), task.ctx.env_get_state()[1].copy()
+    v1 = task.validate(num_envs=32, seconds=1.0)
+    v2 = task.validate(num_envs=32, seconds=1.0)
+    assert v1 == v2 and all(np.isfinite(x) for x in v1.values())                     # argmax actions, fixed seed: bit-reproducible
+    assert set(f"valid/reward/{n}" for n in constants.REWARD_NAMES) <= set(v1)
+    assert torch.equal(p0, task.params) and np.array_equal(es0.view(np.uint32), task.ctx.env_get_state()[1].view(np.uint32))
+    sc = task.scalars()
+    assert abs(sum(constants.REWARD_SCALES[i] * sc[f"reward/{n}"] for i, n in enumerate(constants.REWARD_NAMES)) - sc["train/reward_per_step"]) < 1e-4
+    task.ctx.close()
+
+
+def test_launch_writes_logs_and_checkpoint(tmp_path):
+    from kbot_joystick_amd.host import ckpt, scalars as S
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    cfg = _small(valid_every_n_steps=2, render_length_seconds=0.4, log_reward_components=True, save_every_n_seconds=0.0001)
+    run = str(tmp_path / "humanoid_walking_task" / "run_0")
+    task = HumanoidWalkingTask.launch(cfg, num_iterations=3, run_dir=run, quiet=True)
+    ev = S.read_event_file(glob.glob(os.path.join(run, "logs", "events.out.tfevents.*"))[0])
+    assert [s for s, _ in ev] == [1, 2, 3] and "valid/reward_per_step" in ev[1][1] and "valid/reward_per_step" not in ev[0][1]
+    assert {"train/loss", "train/reward_per_step", "reward/feet_airtime", "perf/env_steps_per_s"} <= set(ev[0][1])
+    z = ckpt.load_ckpt(os.path.join(run, "checkpoints", "ckpt.bin"))                   # convert.sh:4 path convention
+    assert z["state"]["num_steps"] == 3 and np.array_equal(z["model"], task.params.cpu().numpy())
+    task.ctx.close()
+
+
+def test_recurrence_timeout_is_fail_stop(monkeypatch):
+    """Fault injection: the first forward recurrence of the update is launched with one workgroup missing, so its partners' bounded
+    spins expire. The gradient is poisoned on the device, the optimizer step is skipped (parameters and moments unchanged), the
+    error surfaces as KbjError at the iteration's synchronisation point, and the context stays usable and destroyable."""
+    import torch
+    from kbot_joystick_amd.host import binding as B
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    monkeypatch.setenv("KBJ_DEBUG_DROP_SEQ_WG", "1")
+    task = HumanoidWalkingTask(_small(num_envs=64, batch_size=64))
+    monkeypatch.delenv("KBJ_DEBUG_DROP_SEQ_WG")
+    p0 = task.params.clone()
+    with pytest.raises(B.KbjError, match="timed out"):
+        task.train_iteration()
+    torch.cuda.synchronize()
+    assert torch.equal(p0, task.params) and float(task.opt_m.abs().max()) == 0.0      # the step was a no-op on the device
+    task.train_iteration()                                                            # the injected fault is spent: the context still works
+    torch.cuda.synchronize()
+    assert torch.isfinite(task.params).all() and not torch.equal(p0, task.params)
+    task.ctx.close()
+
+
+def test_per_pass_accumulate_variant_matches_manual_accumulation():
+    """KBJ_ALLREDUCE=per_pass: one optimizer step per pass on the mean of the pass's minibatch gradients."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    cfg = _small(num_envs=128, batch_size=32, num_passes=2, allreduce="per_pass")
+    task = HumanoidWalkingTask(cfg)
+    task.rollout()
+    ref = HumanoidWalkingTask(_small(num_envs=128, batch_size=32, num_passes=2))
+    for name in ("actor_obs", "critic_obs", "aux", "action", "logp", "value", "reward", "carry0_actor_hc", "carry0_critic_hc", "carry0_lpf"):
+        getattr(ref.traj, name).copy_(getattr(task.traj, name))
+    task.update()
+    torch.cuda.synchronize()
+    assert task.opt_step == 2
+    # manual restatement on the second task: same permutations, accumulate 4 gradients, one AdamW step with scale 1/4
+    ref.ctx.gae(ref.traj.c, ref.traj.adv, ref.traj.target)
+    for p in range(2):
+        g = torch.Generator(device="cpu"); g.manual_seed((cfg.seed * 1000003 + 0 * 97 + p) & 0x7FFFFFFF)
+        perm = torch.randperm(128, generator=g).int().cuda()
+        acc = torch.zeros_like(ref.params)
+        for mb in range(4):
+            ref.ctx.ppo_grad(ref.params, ref.traj.c, perm[32 * mb:32 * mb + 32].contiguous(), 32, ref.traj.adv, ref.traj.target, ref.grad, ref.metrics)
+            acc += ref.grad
+        ref.ctx.adamw_step(ref.params, ref.opt_m, ref.opt_v, acc, p + 1, 0.25)
+    torch.cuda.synchronize()
+    assert torch.allclose(task.params, ref.params, rtol=0, atol=1e-7)
+    task.ctx.close(); ref.ctx.close()
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it) starts two ranks itself before touching the GPU. On this one-GPU box the
+    ranks share GPU 0 and gloo carries the gradient (RCCL refuses two ranks on one device); the 8-GPU job differs only in
+    --backend nccl and one GPU per rank."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--envs-per-gpu", "512",
+                          "--hidden", "64", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["value"] > 0 and rec["config"]["envs_per_gpu"] == 512 and rec["scaling"] == "weak"
+    assert abs(rec["value"] - 2 * 512 * 100 / (rec["ms_per_step"] * 1e-3)) < 1e-3 * rec["value"]
+    # a mismatch between --gpus and the launcher's world size is an error, not a silent pass
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=120,
+                         env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
+    assert bad.returncode != 0 and "does not match WORLD_SIZE" in (bad.stderr + bad.stdout)
