@@ -10,6 +10,55 @@ from kbot_joystick_amd.spec import layout as L
 pytestmark = pytest.mark.gpu
 
 
+def _check_rollout_against_oracle(task, ref, T):
+    """Free-running rollout with sampled actions vs the oracle trainer. Steps 0 and 1 start from (nearly) identical states: every
+    sample is bounded there (max). Over the whole rollout the trajectories separate slowly (chaotic contact dynamics feed back through
+    the policy), so the bulk is bounded by median AND p99, and the discrete outcomes (done flags) must agree exactly."""
+    act = task.traj.action.cpu().numpy()
+    logp, val, rew = task.traj.logp.cpu().numpy(), task.traj.value.cpu().numpy(), task.traj.reward.cpu().numpy()
+    assert np.abs(act[0] - ref["action"][0]).max() < 1e-4 and np.abs(act[1] - ref["action"][1]).max() < 2e-3   # bounded max, steps 0..1
+    assert np.abs(logp[:2] - ref["logp"][:2]).max() < 2e-2 and np.abs(val[:2] - ref["value"][:2]).max() < 1e-3
+    assert np.abs(rew[:2] - ref["reward"][:2]).max() < 5e-3
+    assert np.array_equal(task.traj.aux[:T, :, L.AUX["DONE"]].cpu().numpy(), ref["aux"][:T, :, L.AUX["DONE"]])
+    for name, got, want, med, p99 in (("action", act, ref["action"], 1e-4, 5e-2), ("logp", logp, ref["logp"], 1e-3, 5e-1),
+                                      ("value", val, ref["value"], 1e-4, 2e-2), ("reward", rew, ref["reward"], 1e-3, 1e-1)):
+        d = np.abs(got - want)
+        assert np.median(d) < med, (name, "median", float(np.median(d)))
+        assert np.quantile(d, 0.99) < p99, (name, "p99", float(np.quantile(d, 0.99)))
+
+
+def test_config0_full_iteration_matches_oracle():
+    """BASELINE configs[0] (`python -m train num_envs=4`, plumbing): kbot-headless, 4 envs, a 64-step rollout, batch 4, the launch
+    networks (hidden 256), 3 passes - one whole train_iteration against the oracle trainer."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
+    from oracle.trainer import OracleTrainer
+    cfg = launch_config(num_envs=4, batch_size=4, rollout_length_seconds=64 * 0.02, robot="kbot-headless", seed=0)
+    task = HumanoidWalkingTask(cfg, device=torch.device("cuda", 0))
+    assert (task.T, task.H, task.kcfg.num_passes) == (64, 256, 3)
+    params0 = task.params.cpu().numpy().copy()
+    tr = OracleTrainer(task.model_blob, task.kcfg, seed=0, params=params0, precision="f32")
+    task.rollout()
+    torch.cuda.synchronize()
+    ref = tr.rollout()
+    _check_rollout_against_oracle(task, ref, task.T)
+    for name in ("actor_obs", "critic_obs", "aux"):
+        getattr(task.traj, name).copy_(torch.from_numpy(ref[name]))
+    for name in ("action", "logp", "value", "reward"):
+        getattr(task.traj, name).copy_(torch.from_numpy(ref[name]))
+    perms = []
+    for p in range(3):
+        g = torch.Generator(device="cpu"); g.manual_seed((cfg.seed * 1000003 + task.iteration * 97 + p) & 0x7FFFFFFF)
+        perms.append(torch.randperm(task.N, generator=g).numpy())
+    task.update()
+    torch.cuda.synchronize()
+    tr.update(perms)
+    p_gpu, p_ref = task.params.cpu().numpy(), tr.params.numpy()
+    moved = np.abs(p_ref - params0).max()
+    assert moved > 1e-4 and np.abs(p_gpu - p_ref).max() < 0.02 * moved + 1e-6 and task.opt_step == tr.opt_step == 3
+    task.ctx.close()
+
+
 def test_training_iteration_matches_oracle():
     import torch
     from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
@@ -23,13 +72,7 @@ def test_training_iteration_matches_oracle():
     torch.cuda.synchronize()
     ref = tr.rollout()
     T = task.T
-    act = task.traj.action.cpu().numpy()
-    assert np.abs(act[0] - ref["action"][0]).max() < 1e-4                      # step 0: identical observations
-    assert np.median(np.abs(act - ref["action"])) < 1e-4
-    assert np.array_equal(task.traj.aux[:T, :, L.AUX["DONE"]].cpu().numpy(), ref["aux"][:T, :, L.AUX["DONE"]])
-    assert np.median(np.abs(task.traj.logp.cpu().numpy() - ref["logp"])) < 1e-3
-    assert np.median(np.abs(task.traj.value.cpu().numpy() - ref["value"])) < 1e-4
-    assert np.median(np.abs(task.traj.reward.cpu().numpy() - ref["reward"])) < 1e-3
+    _check_rollout_against_oracle(task, ref, T)
     # ---- update on the ORACLE's trajectory (so both sides differentiate the same data) ----
     for name in ("actor_obs", "critic_obs", "aux"):
         getattr(task.traj, name).copy_(torch.from_numpy(ref[name]))

@@ -130,7 +130,7 @@ def test_ppo_grad_matches_autograd(H, N, B, T):
     go = pf.grad
     mg = metrics.cpu().double()
     for k, name in enumerate(["loss", "policy", "value", "entropy", "clipfrac", "kl", "adv_mean", "adv_std"]):
-        assert abs(mg[k] - float(mt[name])) < 2e-4 * (1 + abs(float(mt[name]))), (name, float(mg[k]), float(mt[name]))
+        assert abs(mg[k] - float(mt[name].detach())) < 2e-4 * (1 + abs(float(mt[name].detach()))), (name, float(mg[k]), float(mt[name].detach()))
     assert 0.02 < float(mt["clipfrac"]) < 0.98                         # both clip branches exercised
     gg = grad.cpu().double()
     off = 0
