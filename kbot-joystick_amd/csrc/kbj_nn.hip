@@ -601,7 +601,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     const NetOff& oa = w.net[0];
     GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, KBJ_LD_ACTOR, 0, 1, nullptr};
     gemm_launch<true, false>(s, g);
-    hipLaunchKernelGGL(matvec_kernel, g1(4 * H), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
+    hipLaunchKernelGGL(matvec_kernel, dim3((4 * H + 3) / 4), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
     // each accumulator is cleared on the lane whose side stream later accumulates into it (actor-type nets: the caller's stream,
     // critic-type nets with KBJ_FOLD_CRITIC: the second stream), so the clear is always ordered before the split-K atomics
     for (int n = 0; n < w.nnets; ++n) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), ns[n & 1]));
@@ -735,7 +735,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   if (fold_actor)   // the bias terms of layer 0 (db_0 is complete now): db_in = W_ih0^T db_0, dW_ih0 += db_0 b_in^T (X0 = obs W_in^T + b_in)
     for (int k = 0; k < (fold_critic ? 2 : 1); ++k) {
       const NetOff& oa = w.net[k];
-      hipLaunchKernelGGL(matvec_t_acc_kernel, g1(H), dim3(256), 0, ctx->stream, params_d + oa.w_ih[0], grad_d + oa.b[0], 4 * H, H, grad_d + oa.b_in);
+      hipLaunchKernelGGL(matvec_t_acc_kernel, dim3((H + 63) / 64, 16), dim3(256), 0, ctx->stream, params_d + oa.w_ih[0], grad_d + oa.b[0], 4 * H, H, grad_d + oa.b_in);
       hipLaunchKernelGGL(outer_acc_kernel, g1((size_t)4 * H * H), dim3(256), 0, ctx->stream, grad_d + oa.w_ih[0], grad_d + oa.b[0], params_d + oa.b_in, 4 * H, H);
     }
   // a recurrence that timed out left a truncated gradient: poison it so that every data-parallel rank skips the optimizer step

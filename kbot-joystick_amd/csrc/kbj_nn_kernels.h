@@ -347,20 +347,25 @@ __global__ void actor_head_train_bwd_kernel(const float* __restrict__ keep, Head
 }
 
 // y[m] = sum_k W[m][k] x[k] + add[m]   (W [M][K] row-major; one thread per row)
+// one wavefront per output row (launch: M / 4 blocks of 256 threads): coalesced reads along k, DPP-free shuffle reduction
 __global__ void matvec_kernel(const float* __restrict__ W, const float* __restrict__ x, const float* __restrict__ add, int M, int K, float* __restrict__ y) {
-  int m = blockIdx.x * blockDim.x + threadIdx.x;
+  int m = blockIdx.x * 4 + (threadIdx.x >> 6), l = threadIdx.x & 63;
   if (m >= M) return;
   float s = 0;
-  for (int k = 0; k < K; ++k) s += W[(size_t)m * K + k] * x[k];
-  y[m] = s + (add ? add[m] : 0.0f);
+  for (int k = l; k < K; k += 64) s += W[(size_t)m * K + k] * x[k];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if (l == 0) y[m] = s + (add ? add[m] : 0.0f);
 }
-// y[n] += sum_k W[k][n] x[k]   (W [K][N] row-major; one thread per column, coalesced over n)
+// y[n] += sum_k W[k][n] x[k]   (W [K][N] row-major): block = 64 columns x 4 row phases, grid.y slices of k, one atomic per column and
+// block (a single thread per column walking all K rows serially took 270 us on the critical path of every minibatch)
 __global__ void matvec_t_acc_kernel(const float* __restrict__ W, const float* __restrict__ x, int K, int N, float* __restrict__ y) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float red[4][64];
+  int n = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   float s = 0;
-  for (int k = 0; k < K; ++k) s += W[(size_t)k * N + n] * x[k];
-  y[n] += s;
+  if (n < N) for (int k = ph + 4 * blockIdx.y; k < K; k += 4 * gridDim.y) s += W[(size_t)k * N + n] * x[k];
+  red[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && n < N) atomicAdd(&y[n], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // C[m][n] += u[m] v[n]   (rank-1 update, C [M][N] row-major)
