@@ -390,27 +390,35 @@ KBJ_DEV float row_sum16(float v) {  // sum over the 16 lanes of each DPP row, in
   v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v); v = dpp_add<0x140>(v);
   return v;
 }
-KBJ_DEV float rows_sum4(float v) {  // sum over the four rows (same lane-in-row), in every row
+KBJ_DEV float rows_sum4(float v) {  // sum over the four rows (same lane-in-row), in every row: (r0 + r1) + (r2 + r3)
+#ifdef KBJ_ROWS_SUM_LDS   // LDS-crossbar form (A/B)
   v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));                       // lane ^ 16
   v += __int_as_float(__builtin_amdgcn_ds_bpermute((KBJ_LANE ^ 32) << 2, __float_as_int(v)));      // lane ^ 32
+#else                     // gfx950 lane swaps, VALU only: swap odd rows of one copy with even rows of the other, then the 32-lane halves
+  auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(p[0]) + __uint_as_float(p[1]);
+  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
+#endif
   return v;
 }
 
-KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
-  const int lane = KBJ_LANE, c = lane >> 4, r = lane & 15;
+// Solves G x = g with G = M (+ J^T D J of the rows in their quadratic zone when HESS). Everything is in the SOLVER LAYOUT of the
+// wavefront: lane 16 c + r holds, for r = 0..4, chain dof 10 + 5 c - r (ankle .. hip of limb c) and, for r = 5..10, base dof r - 5
+// (replicated in the four DPP rows); m[0..10] is that dof's row of M against (its chain's dofs ankle..hip | the six base dofs).
+// g comes in and x goes out in that layout, so a solve touches LDS only for the contact rows of the Hessian.
+template <bool HESS> KBJ_DEV float arrow_solve_reg(const KbjShared& S, const float (&m)[11], float g, float diag_add, int c, int r) {
   const int rr = r < 11 ? r : 11;
-  const int col = rr < 5 ? 10 - rr : rr - 5;   // column of Mc / Jc this row stands for (rows 0..10)
+  float bc[11];
+  static_for<0, 11>([&](auto Jc_) { constexpr int j = decltype(Jc_)::value; bc[j] = row_bcast<j>(g); });
   float a[11];
-  {
-    const float* src = rr < 11 ? &S.Mc[c][4][col] : rhs + 10 + 5 * c;   // A[r][j], j < 5: M(chain dof 4 - j, this row's dof) resp. rhs
-    const int stride = rr < 11 ? -11 : -1;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) a[j] = src[j * stride];
+  for (int j = 0; j < 5; ++j) a[j] = r < 11 ? m[j] : bc[j];   // rows 0..10: M; row 11 (and its shadows 12..15): the right-hand side
 #pragma unroll
-    for (int j = 5; j < 11; ++j) a[j] = 0.0f;
-  }
-  if (hess) {
+  for (int j = 5; j < 11; ++j) a[j] = 0.0f;
+  if (HESS) {
     if (c < 2 && rr < 11) {  // legs: J^T D J of this leg's 16 pyramid rows (those in their quadratic zone)
+      const int col = rr < 5 ? 10 - rr : rr - 5;
       for (int k = 0; k < 16; ++k) {
         const int row = 16 * c + k;
         const float w = S.quad[ROW_CON + row] ? S.D[ROW_CON + row] : 0.0f;
@@ -422,12 +430,8 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
         a[10] = fmaf(t, J[5], a[10]);
       }
     }
-    if (rr < 5) {  // friction-loss and joint-limit rows are unit vectors: they only touch the diagonal
-      const int u = 5 * c + 4 - rr;
-      const float dd = (S.quad[u] ? S.D[u] : 0.0f) + (S.quad[ROW_LIM + u] ? S.D[ROW_LIM + u] : 0.0f);
 #pragma unroll
-      for (int j = 0; j < 5; ++j) a[j] += rr == j ? dd : 0.0f;
-    }
+    for (int j = 0; j < 5; ++j) a[j] += r == j ? diag_add : 0.0f;   // friction-loss / joint-limit rows are unit vectors: diagonal only
   }
   // eliminate the five chain dofs; column p keeps its unscaled entries (L_ip D_p)
   float inv[5];
@@ -440,13 +444,10 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
       a[j] = fmaf(lp, row_bcast<j>(a[p]), a[j]);
     });
   });
-  // base block: M_base + the four Schur complements (rows 5..10) and the reduced right-hand side (row 11)
+  // base block: M_base + the four Schur complements (rows 5..10) and the reduced right-hand side (row 11), identical in every DPP row
   float b[6];
-  {
-    const float* bsrc = (rr >= 5 && rr < 11) ? &S.Mb[rr - 5][0] : rhs;
 #pragma unroll
-    for (int j = 0; j < 6; ++j) b[j] = rows_sum4(a[5 + j]) + bsrc[j];
-  }
+  for (int j = 0; j < 6; ++j) b[j] = rows_sum4(a[5 + j]) + (r < 11 ? m[5 + j] : bc[5 + j]);
   float binv[6];
   static_for<0, 6>([&](auto Q) {
     constexpr int q = decltype(Q)::value;
@@ -471,9 +472,7 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
     const float xp = -row_sum16(prod) * inv[p];
     xm = r == p ? xp : xm;
   });
-  if (r < 5) S.vec[10 + 5 * c - r] = xm;
-  else if (c == 0 && r <= 10) S.vec[r - 5] = xm;
-  KBJ_SYNC();
+  return xm;   // lanes r <= 10: the solution for this lane's dof
 }
 #endif
 
@@ -646,6 +645,7 @@ KBJ_DEV void rows_force(KbjShared& S) {
   KBJ_SYNC();
 }
 
+#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)
 // Newton iterations on the convex constraint cost with an exact (safeguarded Newton) line search
 KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
   float* warm = S.es + KBJ_ES_WARM;
@@ -729,6 +729,167 @@ KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
   rows_force(S);
   S.iters = iters;
 }
+#else
+// Newton iterations on the convex constraint cost with an exact (safeguarded Newton) line search - register-resident form.
+// The whole solve lives in the solver layout of arrow_solve_reg: a lane keeps its dof's scalars (qfrc_smooth, qacc_smooth, qacc,
+// M qacc, search, M search), its dof's row of M, the friction-loss and limit rows of its joint (unit-vector rows: same lane as
+// the dof) and ONE pyramid row of its leg (contact row 16 c + r of leg c sits in lane 16 c + r, so J^T f of a leg is a 16-lane DPP
+// row sum inside the DPP row that also holds the leg's dofs). Matrix-vector products broadcast the vector along the DPP row
+// (row_newbcast) and sum the base part over the four rows with gfx950 lane swaps. LDS is touched for the initial loads, for the
+// Hessian's contact rows (quad flags out, Jc rows in) and for the results (qacc, contact forces).
+KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& mdl, const PhysConst& pc) {
+  const int lane = KBJ_LANE, c = lane >> 4, r = lane & 15;
+  const bool is_chain = r < 5, is_base = r >= 5 && r <= 10;
+  const bool own = is_chain || (is_base && c == 0);   // every dof exactly once in the wave sums (base dofs are replicated per row)
+  const bool is_con = lane < 32;                        // lanes 0..31 = the 2 x 16 pyramid rows
+  const int d = is_chain ? 10 + 5 * c - r : (is_base ? r - 5 : 0);
+  const int u = is_chain ? d - 6 : 0;
+  // ---- this lane's row of M: columns 0..4 = its chain's dofs (ankle..hip), 5..10 = base dofs ----
+  float m[11];
+  {
+    const int rc = r <= 10 ? r : 10;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int rowi = rc < 5 ? 4 - (rc < j ? rc : j) : 4 - j, coli = rc < 5 ? 10 - (rc > j ? rc : j) : rc - 5;
+      m[j] = S.Mc[c][rowi][coli];
+    }
+#pragma unroll
+    for (int j = 5; j < 11; ++j) {
+      const int bj = j - 5, br = rc - 5;
+      const float* p = rc < 5 ? &S.Mc[c][4 - rc][bj] : &S.Mb[br > bj ? br : bj][br < bj ? br : bj];
+      m[j] = *p;
+    }
+  }
+  const float qs = S.qfrc_smooth[d];
+  const float warm = S.es[KBJ_ES_WARM + d];
+  // friction-loss + limit row of this lane's joint (chain lanes), one pyramid row (lanes 0..31); inactive rows have D = 0
+  float Df = 0, thr = 0, fl = 0, aref_f = 0, Dl = 0, aref_l = 0, ls = 0;
+  if (is_chain) {
+    Df = S.D[u]; fl = S.floss[u]; thr = S.Rf[u] * fl; aref_f = S.aref[u];
+    Dl = S.D[ROW_LIM + u]; aref_l = S.aref[ROW_LIM + u]; ls = S.lsign[u];
+  }
+  float Dc = 0, aref_c = 0, jc[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) jc[k] = is_con ? S.Jc[lane & 31][k] : 0.0f;
+  if (is_con) { Dc = S.D[ROW_CON + lane]; aref_c = S.aref[ROW_CON + lane]; }
+
+  auto bcast11 = [&](float v, float (&vj)[11]) { static_for<0, 11>([&](auto J_) { constexpr int j = decltype(J_)::value; vj[j] = row_bcast<j>(v); }); };
+  auto mul_M = [&](const float (&vj)[11]) {   // (M v) for this lane's dof
+    float p1 = 0, p2 = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) p1 = fmaf(m[j], vj[j], p1);
+#pragma unroll
+    for (int j = 5; j < 11; ++j) p2 = fmaf(m[j], vj[j], p2);
+    const float t = rows_sum4(p1);            // base dofs couple to every chain: sum the chain parts over the four rows
+    return (is_base ? t : p1) + p2;
+  };
+  auto jdot = [&](const float (&vj)[11]) {    // pyramid row . v  (Jc columns: 0..5 base, 6..10 the leg's dofs hip..ankle)
+    float x = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) x = fmaf(jc[k], vj[5 + k], x);
+#pragma unroll
+    for (int a = 0; a < 5; ++a) x = fmaf(jc[6 + a], vj[4 - a], x);
+    return x;
+  };
+  auto cost_f = [&](float x) { if (Df == 0) return 0.0f; if (x <= -thr) return fl * (-0.5f * thr - x); if (x >= thr) return fl * (-0.5f * thr + x); return 0.5f * Df * x * x; };
+  auto cost_u = [&](float D, float x) { return (D != 0 && x < 0) ? 0.5f * D * x * x : 0.0f; };
+
+  // ---- unconstrained acceleration ----
+  const float qas = arrow_solve_reg<false>(S, m, qs, 0.0f, c, r);
+  KBJ_STAMP(7);
+  // ---- warm start: the cheaper of the previous step's acceleration and the unconstrained one ----
+  float vj[11];
+  bcast11(qas, vj);
+  const float Ma_s = mul_M(vj);
+  const float jf_s = Df != 0 ? qas - aref_f : 0.0f, jl_s = Dl != 0 ? ls * qas - aref_l : 0.0f, jc_s = Dc != 0 ? jdot(vj) - aref_c : 0.0f;
+  const float cs = wsum_lanes(cost_f(jf_s) + cost_u(Dl, jl_s) + cost_u(Dc, jc_s));          // the Gauss term vanishes at qacc_smooth
+  bcast11(warm, vj);
+  const float Ma_w = mul_M(vj);
+  const float jf_w = Df != 0 ? warm - aref_f : 0.0f, jl_w = Dl != 0 ? ls * warm - aref_l : 0.0f, jc_w = Dc != 0 ? jdot(vj) - aref_c : 0.0f;
+  const float cw = wsum_lanes((own ? 0.5f * (Ma_w - qs) * (warm - qas) : 0.0f) + cost_f(jf_w) + cost_u(Dl, jl_w) + cost_u(Dc, jc_w));
+  const bool use_warm = cw < cs;
+  float qa = use_warm ? warm : qas, Ma = use_warm ? Ma_w : Ma_s;
+  float jar_f = use_warm ? jf_w : jf_s, jar_l = use_warm ? jl_w : jl_s, jar_c = use_warm ? jc_w : jc_s;
+  KBJ_STAMP(8);
+  const float scale = 1.0f / (mdl.meaninertia * NV);
+  int iters = 0;
+  float ff = 0, flm = 0, fc = 0;
+  bool qf = false, ql = false, qc = false;
+  auto rows_force_reg = [&]() {
+    ff = 0; qf = false; flm = 0; ql = false; fc = 0; qc = false;
+    if (Df != 0) { if (jar_f <= -thr) ff = fl; else if (jar_f >= thr) ff = -fl; else { ff = -Df * jar_f; qf = true; } }
+    if (Dl != 0 && jar_l < 0) { flm = -Dl * jar_l; ql = true; }
+    if (Dc != 0 && jar_c < 0) { fc = -Dc * jar_c; qc = true; }
+  };
+  for (int it = 0; it < pc.iterations; ++it) {
+    rows_force_reg();
+    if (is_con) S.quad[ROW_CON + lane] = qc;   // the Hessian's contact part reads the quadratic-zone flags (and D, Jc) from LDS
+    // gradient: M qacc - qfrc_smooth - J^T force
+    float s[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) s[k] = row_sum16(jc[k] * fc);     // per leg (DPP row): column k of J^T f
+    float gcon = 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { const float t = rows_sum4(s[k]); gcon = r == 5 + k ? t : gcon; }   // base dofs: both legs
+#pragma unroll
+    for (int a = 0; a < 5; ++a) gcon = r == 4 - a ? s[6 + a] : gcon;                                  // leg dof hip + a sits in lane 4 - a
+    const float gr = Ma - qs - (ff + ls * flm) - gcon;
+    const float gg = wsum_lanes(own ? gr * gr : 0.0f);
+    KBJ_SYNC();
+    KBJ_STAMP(9);
+    if (scale * sqrtf(gg) < pc.tolerance) break;
+    const float se = arrow_solve_reg<true>(S, m, -gr, (qf ? Df : 0.0f) + (ql ? Dl : 0.0f), c, r);
+    KBJ_STAMP(10);
+    bcast11(se, vj);
+    const float mv = mul_M(vj);
+    const float jv_f = Df != 0 ? se : 0.0f, jv_l = Dl != 0 ? ls * se : 0.0f, jv_c = Dc != 0 ? jdot(vj) : 0.0f;
+    KBJ_STAMP(11);
+    float g1, g2;
+    {
+      float x1 = own ? se * (Ma - qs) : 0.0f, x2 = own ? se * mv : 0.0f;
+      g1 = wsum_lanes(x1); g2 = wsum_lanes(x2);
+    }
+    auto eval = [&](float a, float& d1, float& d2) {
+      float x1 = 0, x2 = 0;
+      if (Df != 0) {
+        const float x = jar_f + a * jv_f;
+        if (x <= -thr) x1 -= fl * jv_f; else if (x >= thr) x1 += fl * jv_f; else { x1 += Df * x * jv_f; x2 += Df * jv_f * jv_f; }
+      }
+      if (Dl != 0) { const float x = jar_l + a * jv_l; if (x < 0) { x1 += Dl * x * jv_l; x2 += Dl * jv_l * jv_l; } }
+      if (Dc != 0) { const float x = jar_c + a * jv_c; if (x < 0) { x1 += Dc * x * jv_c; x2 += Dc * jv_c * jv_c; } }
+      d1 = wsum_lanes(x1) + g1 + a * g2; d2 = wsum_lanes(x2) + g2;
+    };
+    float d1, d2, alpha = 0;
+    eval(0.0f, d1, d2);
+    if (d1 < 0 && d2 > 0) {
+      float lo = 0, hi = 0;
+      bool hi_valid = false;
+      float a = -d1 / d2;
+      const float d1_stop = 0.01f * fabsf(d1);  // MuJoCo's default ls_tolerance: relative slope reduction
+      for (int lsi = 0; lsi < pc.ls_iterations; ++lsi) {
+        eval(a, d1, d2);
+        if (fabsf(d1) <= d1_stop) break;
+        if (d1 < 0) lo = a; else { hi = a; hi_valid = true; }
+        float an = a - d1 / d2;
+        if (an <= lo || (hi_valid && an >= hi)) an = hi_valid ? 0.5f * (lo + hi) : 2 * a;
+        a = an;
+      }
+      alpha = a;
+    }
+    KBJ_STAMP(12);
+    qa += alpha * se; Ma += alpha * mv;
+    jar_f += alpha * jv_f; jar_l += alpha * jv_l; jar_c += alpha * jv_c;
+    KBJ_STAMP(13);
+    iters = it + 1;
+    if (alpha == 0) break;
+  }
+  rows_force_reg();
+  if (own) S.qacc[d] = qa;
+  if (is_con) S.force[ROW_CON + lane] = fc;
+  if (lane == 0) S.iters = iters;
+  KBJ_SYNC();
+}
+#endif
 
 KBJ_DEV void phys_sensors(KbjShared& S, const kbj_model& m) {
   PFOR(w, 3) {
