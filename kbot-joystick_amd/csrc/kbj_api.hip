@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include "kbj_ctx.h"
+#include "kbj_env_core.h"
 
 thread_local std::string kbj_global_error;
 thread_local kbj_ctx* kbj_prof_ctx = nullptr;
@@ -73,6 +74,12 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   KBJ_TRY(hipMalloc(&ctx->cfg_d, sizeof(kbj_config)));
   KBJ_TRY(hipMemcpy(ctx->model_d, &ctx->model_h, sizeof(kbj_model), hipMemcpyHostToDevice));
   KBJ_TRY(hipMemcpy(ctx->cfg_d, &ctx->cfg_h, sizeof(kbj_config), hipMemcpyHostToDevice));
+  {
+    kbj::KbjModelLds mc;
+    kbj::model_lds_fill(mc, ctx->model_h);
+    KBJ_TRY(hipMalloc(&ctx->mc_d, sizeof(mc)));
+    KBJ_TRY(hipMemcpy(ctx->mc_d, &mc, sizeof(mc), hipMemcpyHostToDevice));
+  }
   KBJ_TRY(hipMalloc(&ctx->ep_d, N * KBJ_EP_SIZE * sizeof(float)));
   KBJ_TRY(hipMalloc(&ctx->es_d, N * KBJ_ES_SIZE * sizeof(float)));
   KBJ_TRY(hipMalloc(&ctx->rcarry_d, N * KBJ_RC_SIZE * sizeof(float)));
@@ -108,6 +115,7 @@ int kbj_destroy(kbj_ctx* ctx) {
   kbj_nn_destroy(ctx);
   if (ctx->model_d) hipFree(ctx->model_d);
   if (ctx->cfg_d) hipFree(ctx->cfg_d);
+  if (ctx->mc_d) hipFree(ctx->mc_d);
   if (ctx->ep_d) hipFree(ctx->ep_d);
   if (ctx->es_d) hipFree(ctx->es_d);
   if (ctx->rcarry_d) hipFree(ctx->rcarry_d);

@@ -23,6 +23,7 @@ struct kbj_ctx {
   kbj_config cfg_h;
   kbj_model* model_d = nullptr;
   kbj_config* cfg_d = nullptr;
+  float* mc_d = nullptr;        // KbjModelLds image (kbj_env_core.h): the model constants every env workgroup copies into LDS
   float* ep_d = nullptr;        // [N][KBJ_EP_SIZE]
   float* es_d = nullptr;        // [N][KBJ_ES_SIZE]
   float* rcarry_d = nullptr;    // [N][KBJ_RC_SIZE] reward carries

@@ -43,11 +43,40 @@ KBJ_DEV int body_parent(int b) { return b <= 1 ? 0 : (b == 2 ? 1 : ((b - 3) % 5 
 KBJ_DEV int dof_body(int d) { return d < 6 ? 1 : d - 3; }
 KBJ_DEV int dof_parent(int d) { return d == 0 ? -1 : (d < 6 ? d - 1 : ((d - 6) % 5 == 0 ? 5 : d - 1)); }
 
-// Everything one env needs between phases, 13.4 KB so that 12 single-wavefront workgroups (3 waves per SIMD) share a CU.
+// The model constants the per-substep phases read (same field names as kbj_model, so the phases are written against either): a
+// per-workgroup LDS copy, loaded once per launch with coalesced reads. In global memory every one of these reads was a dependent
+// vector load (~200-500 cycles) in the middle of a serial chain (e.g. 13 per body in the kinematics walk).
+struct KbjModelLds {
+  float body_pos[NB][3], body_quat[NB][4], jnt_axis[NB][3];
+  float cap_axis[KBJ_NCAP][3];
+  float act_range[NU][2], dof_range[NV][2], dof_invweight0[NV], body_invweight0[NB][2];
+  float site_pos[2][3], site_size[2][3], imu_quat[4];
+  float fric_solref[2], fric_solimp[5], limit_solref[2], limit_solimp[5], contact_solref[2], contact_solimp[5];
+  float gravity[3], meaninertia;
+};
+static inline void model_lds_fill(KbjModelLds& o, const kbj_model& m) {   // host side (kbj_create, emulation)
+  for (int b = 0; b < NB; ++b) {
+    for (int k = 0; k < 3; ++k) { o.body_pos[b][k] = m.body_pos[b][k]; o.jnt_axis[b][k] = m.jnt_axis[b][k]; }
+    for (int k = 0; k < 4; ++k) o.body_quat[b][k] = m.body_quat[b][k];
+    o.body_invweight0[b][0] = m.body_invweight0[b][0]; o.body_invweight0[b][1] = m.body_invweight0[b][1];
+  }
+  for (int c = 0; c < KBJ_NCAP; ++c) for (int k = 0; k < 3; ++k) o.cap_axis[c][k] = m.cap_axis[c][k];
+  for (int u = 0; u < NU; ++u) { o.act_range[u][0] = m.act_range[u][0]; o.act_range[u][1] = m.act_range[u][1]; }
+  for (int d = 0; d < NV; ++d) { o.dof_range[d][0] = m.dof_range[d][0]; o.dof_range[d][1] = m.dof_range[d][1]; o.dof_invweight0[d] = m.dof_invweight0[d]; }
+  for (int f = 0; f < 2; ++f) for (int k = 0; k < 3; ++k) { o.site_pos[f][k] = m.site_pos[f][k]; o.site_size[f][k] = m.site_size[f][k]; }
+  for (int k = 0; k < 4; ++k) o.imu_quat[k] = m.imu_quat[k];
+  for (int k = 0; k < 2; ++k) { o.fric_solref[k] = m.fric_solref[k]; o.limit_solref[k] = m.limit_solref[k]; o.contact_solref[k] = m.contact_solref[k]; }
+  for (int k = 0; k < 5; ++k) { o.fric_solimp[k] = m.fric_solimp[k]; o.limit_solimp[k] = m.limit_solimp[k]; o.contact_solimp[k] = m.contact_solimp[k]; }
+  for (int k = 0; k < 3; ++k) o.gravity[k] = m.gravity[k];
+  o.meaninertia = m.meaninertia;
+}
+
+// Everything one env needs between phases, 12.4 KB so that 12 single-wavefront workgroups (3 waves per SIMD) share a CU.
 // Buffers whose lifetimes do not overlap share storage (union `u`): composite inertias (until the mass matrix exists),
 // RNE body forces (until the bias force exists), then the arrow-matrix blocks of the Newton solves. Rotation matrices
 // are recomputed from xquat where needed instead of being stored; the mass matrix is stored in its tree sparsity.
 struct KbjShared {
+  KbjModelLds mc;
   float ep[KBJ_EP_SIZE];
   float es[KBJ_ES_SIZE];
   float xpos[NB][3], xquat[NB][4], xipos[NB][3];
@@ -67,12 +96,15 @@ struct KbjShared {
   } u;
   float Mb[6][6];       // mass matrix, base block
   float Mc[4][5][11];   // limb c, dof a (hip..ankle): columns 0..5 base dofs, 6..10 the limb's own dofs
-  float qfrc_act[NV], qfrc_smooth[NV], qacc_smooth[NV], qacc[NV];
-  float Ma[NV], grad[NV], search[NV], mv[NV], vec[NV];
+  float qfrc_act[NV], qfrc_smooth[NV], qacc[NV];
+#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)   // the LDS formulation of the solver keeps its vectors here; the product kernel keeps them in registers
+  float qacc_smooth[NV], Ma[NV], grad[NV], search[NV], mv[NV], vec[NV];
+  float jar[NROW], jv[NROW];
+#endif
   float conpos[NCON][3], condist[NCON], connrm[NCON][3];
   int conact[NCON];
   float Jc[32][11];  // contact rows: columns 0..5 base dofs, 6..10 the leg's dofs hip..ankle
-  float D[NROW], aref[NROW], jar[NROW], jv[NROW], force[NROW];  // a row is active iff D != 0
+  float D[NROW], aref[NROW], force[NROW];  // a row is active iff D != 0
   float Rf[NU], floss[NU], lsign[NU];                           // Huber half-width data of the frictionloss rows, limit signs
   int quad[NROW];
   float ctrl[NU], push[6], act_eff[NU];

@@ -47,71 +47,88 @@ KBJ_DEV void terrain_eval(const PhysConst& pc, float x, float y, float& h, float
 }
 
 // ---- position stage ----------------------------------------------------------------------------------------
-KBJ_DEV void phys_kinematics(KbjShared& S, const kbj_model& m) {
+// v rotated by the unit quaternion q: v + w t + u x t with t = 2 u x v
+KBJ_DEV void quat_rot(const float* q, const float* v, float* o) {
+  float t[3] = {2 * (q[2] * v[2] - q[3] * v[1]), 2 * (q[3] * v[0] - q[1] * v[2]), 2 * (q[1] * v[1] - q[2] * v[0])};
+  o[0] = v[0] + q[0] * t[0] + (q[2] * t[2] - q[3] * t[1]);
+  o[1] = v[1] + q[0] * t[1] + (q[3] * t[0] - q[1] * t[2]);
+  o[2] = v[2] + q[0] * t[2] + (q[1] * t[1] - q[2] * t[0]);
+}
+KBJ_DEV void quat_norm_fast(float* q) {   // one reciprocal square root instead of a square root and four divisions
+  float inv = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; ++k) q[k] *= inv;
+}
+
+// Kinematics in three phases: (1) every joint's local rotation body_quat * rot(axis, angle) in parallel (the trigonometry of all
+// 20 joints at once), (2) five walkers (four limbs + the imu body) compose them from the torso outwards - a quaternion product, a
+// normalisation and one vector rotation per body, (3) everything that hangs off a body's pose (inertial frame origin, world hinge
+// axis) in parallel over bodies, see phys_com.
+KBJ_DEV void phys_kinematics(KbjShared& S, const KbjModelLds& m) {
   const float* qpos = S.es + KBJ_ES_QPOS;
-  PFOR(w, 1) {
-    for (int k = 0; k < 3; ++k) { S.xpos[0][k] = 0; S.xipos[0][k] = 0; }
-    S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
-    float q[4] = {qpos[3], qpos[4], qpos[5], qpos[6]}, mat[9], t[3];
-    quat_norm(q);
-    for (int k = 0; k < 3; ++k) S.xpos[1][k] = qpos[k];
-    for (int k = 0; k < 4; ++k) S.xquat[1][k] = q[k];
-    quat_to_mat(q, mat);
-    mat_vec(mat, S.ep + KBJ_EP_IPOS + 3, t);
-    for (int k = 0; k < 3; ++k) S.xipos[1][k] = S.xpos[1][k] + t[k];
-    // torso: welded to the base
-    mat_vec(mat, m.body_pos[2], t);
-    for (int k = 0; k < 3; ++k) S.xpos[2][k] = S.xpos[1][k] + t[k];
-    float q2[4];
-    quat_mul(q, m.body_quat[2], q2);
-    quat_norm(q2);
-    for (int k = 0; k < 4; ++k) S.xquat[2][k] = q2[k];
-    quat_to_mat(q2, mat);
-    mat_vec(mat, S.ep + KBJ_EP_IPOS + 6, t);
-    for (int k = 0; k < 3; ++k) S.xipos[2][k] = S.xpos[2][k] + t[k];
+  PFOR(u, NU) {
+    const int b = 3 + u;
+    const float ang = qpos[7 + u], sn = sinf(ang / 2), co = cosf(ang / 2);
+    const float jq[4] = {co, sn * m.jnt_axis[b][0], sn * m.jnt_axis[b][1], sn * m.jnt_axis[b][2]};
+    float q[4];
+    quat_mul(m.body_quat[b], jq, q);
+    for (int k = 0; k < 4; ++k) S.xquat[b][k] = q[k];   // staged: the walker of this limb replaces it by the world orientation
   }
   KBJ_SYNC();
-  PFOR(c, 5) {  // lanes 0..3 walk one limb each from the torso outwards, lane 4 places the imu body
-    float ppos[3], pquat[4], pmat[9];
-    for (int k = 0; k < 3; ++k) ppos[k] = S.xpos[2][k];
-    for (int k = 0; k < 4; ++k) pquat[k] = S.xquat[2][k];
-    quat_to_mat(pquat, pmat);
-    int nb = c < 4 ? 5 : 1;
+  PFOR(c, 5) {
+    // base and torso (welded to the base), recomputed by every walker instead of a phase of their own
+    float pq[4] = {qpos[3], qpos[4], qpos[5], qpos[6]}, pp[3] = {qpos[0], qpos[1], qpos[2]}, t[3], q[4];
+    quat_norm_fast(pq);
+    if (c == 4) {
+      for (int k = 0; k < 3; ++k) { S.xpos[0][k] = 0; S.xpos[1][k] = pp[k]; }
+      S.xquat[0][0] = 1; S.xquat[0][1] = S.xquat[0][2] = S.xquat[0][3] = 0;
+      for (int k = 0; k < 4; ++k) S.xquat[1][k] = pq[k];
+    }
+    quat_rot(pq, m.body_pos[2], t);
+    for (int k = 0; k < 3; ++k) pp[k] += t[k];
+    quat_mul(pq, m.body_quat[2], q);
+    quat_norm_fast(q);
+    for (int k = 0; k < 4; ++k) pq[k] = q[k];
+    if (c == 4) {
+      for (int k = 0; k < 3; ++k) S.xpos[2][k] = pp[k];
+      for (int k = 0; k < 4; ++k) S.xquat[2][k] = pq[k];
+    }
+    const int nb = c < 4 ? 5 : 1;
     for (int k5 = 0; k5 < nb; ++k5) {
-      int b = c < 4 ? 3 + 5 * c + k5 : 23;
-      float t[3], q[4];
-      mat_vec(pmat, m.body_pos[b], t);
-      for (int k = 0; k < 3; ++k) ppos[k] += t[k];
-      quat_mul(pquat, m.body_quat[b], q);
-      if (c < 4) {
-        float ang = qpos[7 + 5 * c + k5];
-        float s = sinf(ang / 2), co = cosf(ang / 2);
-        float jq[4] = {co, s * m.jnt_axis[b][0], s * m.jnt_axis[b][1], s * m.jnt_axis[b][2]}, q2[4];
-        quat_mul(q, jq, q2);
-        for (int k = 0; k < 4; ++k) q[k] = q2[k];
-      }
-      quat_norm(q);
-      for (int k = 0; k < 4; ++k) pquat[k] = q[k];
-      quat_to_mat(pquat, pmat);
-      for (int k = 0; k < 3; ++k) S.xpos[b][k] = ppos[k];
-      for (int k = 0; k < 4; ++k) S.xquat[b][k] = pquat[k];
-      mat_vec(pmat, S.ep + KBJ_EP_IPOS + 3 * b, t);
-      for (int k = 0; k < 3; ++k) S.xipos[b][k] = ppos[k] + t[k];
-      if (c < 4) mat_vec(pmat, m.jnt_axis[b], S.cdof[b + 3]);  // world hinge axis = angular part of the motion axis
+      const int b = c < 4 ? 3 + 5 * c + k5 : 23;
+      quat_rot(pq, m.body_pos[b], t);
+      for (int k = 0; k < 3; ++k) pp[k] += t[k];
+      const float* ql = c < 4 ? S.xquat[b] : m.body_quat[b];
+      const float qloc[4] = {ql[0], ql[1], ql[2], ql[3]};
+      quat_mul(pq, qloc, q);
+      quat_norm_fast(q);
+      for (int k = 0; k < 4; ++k) pq[k] = q[k];
+      for (int k = 0; k < 3; ++k) S.xpos[b][k] = pp[k];
+      for (int k = 0; k < 4; ++k) S.xquat[b][k] = pq[k];
     }
   }
   KBJ_SYNC();
 }
 
-KBJ_DEV void phys_com(KbjShared& S) {
+// centre of mass, body inertias about it, motion axes (cdof) - parallel over bodies / dofs, the two centre-of-mass sums as wave sums
+KBJ_DEV void phys_com(KbjShared& S, const KbjModelLds& m) {
   const float* mass = S.ep + KBJ_EP_MASS;
-  PFOR(w, 3) {
-    float s2 = 0, m2 = 0;
-    for (int b = 2; b < NB; ++b) { s2 += mass[b] * S.xipos[b][w]; m2 += mass[b]; }
-    float s1 = s2 + mass[1] * S.xipos[1][w], m1 = m2 + mass[1];
-    S.com2[w] = s2 / m2;
-    S.com[w] = s1 / m1;
-    if (w == 0) S.com[3] = m1;
+  PFOR(b, NB) {
+    float mat[9], t[3] = {0, 0, 0};
+    if (b > 0) { quat_to_mat(S.xquat[b], mat); mat_vec(mat, S.ep + KBJ_EP_IPOS + 3 * b, t); }
+    for (int k = 0; k < 3; ++k) S.xipos[b][k] = S.xpos[b][k] + t[k];
+  }
+  KBJ_SYNC();
+  {
+    float s2[3], m2;
+    for (int w = 0; w < 3; ++w) s2[w] = wsum(NB, [&](int l) { return l >= 2 ? mass[l] * S.xipos[l][w] : 0.0f; });
+    m2 = wsum(NB, [&](int l) { return l >= 2 ? mass[l] : 0.0f; });
+    const float m1 = m2 + mass[1];
+    KBJ_SYNC();   // (emulation: the sums above read what the stores below overwrite nothing of; on the GPU a no-op for one wavefront)
+    PFOR(w, 3) {
+      S.com2[w] = s2[w] / m2;
+      S.com[w] = (s2[w] + mass[1] * S.xipos[1][w]) / m1;
+      if (w == 0) S.com[3] = m1;
+    }
   }
   KBJ_SYNC();
   PFOR(b, NB) {
@@ -143,15 +160,12 @@ KBJ_DEV void phys_com(KbjShared& S) {
     int b = dof_body(d);
     float off[3] = {S.com[0] - S.xpos[b][0], S.com[1] - S.xpos[b][1], S.com[2] - S.xpos[b][2]};
     if (d < 3) { for (int k = 0; k < 6; ++k) cd[k] = 0; cd[3 + d] = 1; }
-    else if (d < 6) {
-      int i = d - 3;
-      float mat[9];
-      quat_to_mat(S.xquat[1], mat);
-      float ax[3] = {mat[i], mat[3 + i], mat[6 + i]};
+    else {
+      float mat[9], ax[3];
+      quat_to_mat(S.xquat[b], mat);
+      if (d < 6) { int i = d - 3; ax[0] = mat[i]; ax[1] = mat[3 + i]; ax[2] = mat[6 + i]; }
+      else mat_vec(mat, m.jnt_axis[b], ax);   // world hinge axis = angular part of the motion axis
       for (int k = 0; k < 3; ++k) cd[k] = ax[k];
-      cross3(ax, off, cd + 3);
-    } else {
-      float ax[3] = {cd[0], cd[1], cd[2]};  // written by the kinematics walkers
       cross3(ax, off, cd + 3);
     }
   }
@@ -184,7 +198,7 @@ KBJ_DEV void phys_crb_mass(KbjShared& S) {
 }
 
 // ---- contacts + velocity stage -------------------------------------------------------------------------------
-KBJ_DEV void phys_collide_vel(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
+KBJ_DEV void phys_collide_vel(KbjShared& S, const KbjModelLds& m, const PhysConst& pc) {
   const float* qvel = S.es + KBJ_ES_QVEL;
   PFOR(ci, NCON) {  // capsule end ci%2 of capsule ci/2 against the plane z = 0
     int c = ci / 2, b = c < 2 ? 7 : 12;
@@ -247,7 +261,7 @@ KBJ_DEV void phys_collide_vel(KbjShared& S, const kbj_model& m, const PhysConst&
   KBJ_SYNC();
 }
 
-KBJ_DEV void phys_smooth_forces(KbjShared& S, const kbj_model& m) {
+KBJ_DEV void phys_smooth_forces(KbjShared& S, const KbjModelLds& m) {
   PFOR(i, NV) {
     float s = 0;
     for (int k = 0; k < 6; ++k) s += S.cdof[i][k] * S.u.cfrc_acc[dof_body(i)][k];
@@ -476,6 +490,7 @@ template <bool HESS> KBJ_DEV float arrow_solve_reg(const KbjShared& S, const flo
 }
 #endif
 
+#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)
 // y = M v using the tree sparsity
 KBJ_DEV float mul_M_row(const KbjShared& S, int i, const float* v) {
   float s = 0;
@@ -489,6 +504,7 @@ KBJ_DEV float mul_M_row(const KbjShared& S, int i, const float* v) {
   }
   return s;
 }
+#endif
 
 // ---- constraint rows -------------------------------------------------------------------------------------------
 KBJ_DEV float impedance(float dist, const float* solimp) {
@@ -511,7 +527,7 @@ KBJ_DEV void kbi(const float* solref, const float* solimp, float dist, float dt,
   imp = impedance(dist, solimp);
 }
 
-KBJ_DEV void phys_make_constraints(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
+KBJ_DEV void phys_make_constraints(KbjShared& S, const KbjModelLds& m, const PhysConst& pc) {
   const float* qpos = S.es + KBJ_ES_QPOS;
   const float* qvel = S.es + KBJ_ES_QVEL;
   PFOR(u, NU) {
@@ -576,6 +592,7 @@ KBJ_DEV void phys_make_constraints(KbjShared& S, const kbj_model& m, const PhysC
   KBJ_SYNC();
 }
 
+#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)   // ---- LDS formulation of the solver (host emulation / A-B builds) ----
 // J q for row r (r active)
 KBJ_DEV float row_dot(const KbjShared& S, int r, const float* q) {
   if (r < ROW_LIM) return q[6 + r];
@@ -645,9 +662,8 @@ KBJ_DEV void rows_force(KbjShared& S) {
   KBJ_SYNC();
 }
 
-#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)
 // Newton iterations on the convex constraint cost with an exact (safeguarded Newton) line search
-KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
+KBJ_DEV void phys_solve(KbjShared& S, const KbjModelLds& m, const PhysConst& pc) {
   float* warm = S.es + KBJ_ES_WARM;
   arrow_solve(S, S.qfrc_smooth, false);
   PFOR(i, NV) S.qacc_smooth[i] = S.vec[i];
@@ -737,7 +753,7 @@ KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
 // row sum inside the DPP row that also holds the leg's dofs). Matrix-vector products broadcast the vector along the DPP row
 // (row_newbcast) and sum the base part over the four rows with gfx950 lane swaps. LDS is touched for the initial loads, for the
 // Hessian's contact rows (quad flags out, Jc rows in) and for the results (qacc, contact forces).
-KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& mdl, const PhysConst& pc) {
+KBJ_DEV void phys_solve(KbjShared& S, const KbjModelLds& mdl, const PhysConst& pc) {
   const int lane = KBJ_LANE, c = lane >> 4, r = lane & 15;
   const bool is_chain = r < 5, is_base = r >= 5 && r <= 10;
   const bool own = is_chain || (is_base && c == 0);   // every dof exactly once in the wave sums (base dofs are replicated per row)
@@ -891,7 +907,7 @@ KBJ_DEV void phys_solve(KbjShared& S, const kbj_model& mdl, const PhysConst& pc)
 }
 #endif
 
-KBJ_DEV void phys_sensors(KbjShared& S, const kbj_model& m) {
+KBJ_DEV void phys_sensors(KbjShared& S, const KbjModelLds& m) {
   PFOR(w, 3) {
     if (w == 0) {
       float iq[4], sm[9];
@@ -921,16 +937,18 @@ KBJ_DEV void phys_sensors(KbjShared& S, const kbj_model& m) {
 }
 
 // full forward pass on the state in S.es with torques S.ctrl and (if S.pushing) wrench S.push
-KBJ_DEV void phys_forward(KbjShared& S, const kbj_model& m, const PhysConst& pc) {
+// `sensors`: gyro / projected gravity / touch only feed the observations, i.e. they are needed after the LAST substep of a control step
+KBJ_DEV void phys_forward(KbjShared& S, const KbjModelLds& m, const PhysConst& pc, bool sensors = true) {
   KBJ_STAMP(0);
   phys_kinematics(S, m); KBJ_STAMP(1);
-  phys_com(S); KBJ_STAMP(2);
+  phys_com(S, m); KBJ_STAMP(2);
   phys_crb_mass(S); KBJ_STAMP(3);
   phys_collide_vel(S, m, pc); KBJ_STAMP(4);
   phys_smooth_forces(S, m); KBJ_STAMP(5);
   phys_make_constraints(S, m, pc); KBJ_STAMP(6);
   phys_solve(S, m, pc); KBJ_STAMP(15);
-  phys_sensors(S, m); KBJ_STAMP(16);
+  if (sensors) phys_sensors(S, m);
+  KBJ_STAMP(16);
 }
 
 // semi-implicit Euler; also refreshes the warm start (kept in the state row)

@@ -125,7 +125,7 @@ KBJ_DEV void task_reset(KbjShared& S, const kbj_model& m, const kbj_config& c, c
   }
   KBJ_SYNC();
   task_pd(S, es + KBJ_ES_ACT_PREV);
-  phys_forward(S, m, pc);
+  phys_forward(S, S.mc, pc);
   PFOR(k, 3) es[KBJ_ES_PGLAG + k] = S.pg[k];
   KBJ_SYNC();
 }
@@ -272,7 +272,7 @@ KBJ_DEV void task_step(KbjShared& S, const kbj_model& m, const kbj_config& c, co
   int lat = (int)S.ep[KBJ_EP_LATENCY];
   for (int s = 0; s < c.substeps; ++s) {
     task_pd(S, s >= lat ? S.act_eff : es + KBJ_ES_ACT_PREV);
-    phys_forward(S, m, pc);
+    phys_forward(S, S.mc, pc, s == c.substeps - 1);
     phys_integrate(S, pc);
     KBJ_STAMP(17);
   }

@@ -22,6 +22,7 @@ void kbj_emu_reset_all(const kbj_model* m, const kbj_config* c, uint32_t seed, f
   for (int i = 0; i < c->num_envs; ++i) {
     std::unique_ptr<KbjShared> S(new KbjShared());
     std::memset(S.get(), 0, sizeof(KbjShared));
+    model_lds_fill(S->mc, *m);
     Rng rng{seed, (uint32_t)(c->env_id_offset + i)};
     task_reset(*S, *m, *c, pc, rng);
     task_write_obs(*S, *m, *c, rng, a0 + (size_t)i * KBJ_LD_ACTOR, c0 + (size_t)i * KBJ_LD_CRITIC, x0 + (size_t)i * KBJ_AUX_SIZE);
@@ -37,6 +38,7 @@ void kbj_emu_env_step(const kbj_model* m, const kbj_config* c, uint32_t seed, fl
   for (int i = 0; i < c->num_envs; ++i) {
     std::unique_ptr<KbjShared> S(new KbjShared());
     std::memset(S.get(), 0, sizeof(KbjShared));
+    model_lds_fill(S->mc, *m);
     std::memcpy(S->ep, ep + (size_t)i * KBJ_EP_SIZE, sizeof(S->ep));
     std::memcpy(S->es, es + (size_t)i * KBJ_ES_SIZE, sizeof(S->es));
     Rng rng{seed, (uint32_t)(c->env_id_offset + i)};

@@ -60,7 +60,8 @@ def check_against_oracle_spread(err_hip: dict, err_o32: dict, switch: np.ndarray
     """HIP-vs-fp64 error distribution against the oracle's own fp32-vs-fp64 distribution measured on the SAME env-steps:
       * median, p99, p99.9 at most 2x the oracle's (floored at a few fp32 roundings of the quantity);
       * no heavier tail: the count of env-steps beyond 2x the oracle's p99.9 is at most 1.5x the oracle's own count (+5);
-      * the extreme value at most 4x the oracle's own extreme value;
+      * the extreme value inside the absolute bound of the tolerance table (a single env-step on a discrete switch sets it, in
+        the oracle's fp32-vs-fp64 comparison just the same: the ratio of two such extremes is not a stable statistic);
       * beyond 2x the oracle's p99.9, at most 8 env-steps that the oracle does not itself flag as sitting on a discrete switch of
         the solver (`switch`: active contacts / force-carrying rows / iteration counts differ between two evaluations that differ
         only by rounding, or the iteration cap bites) - measured: 2-3 of 98k, the kernel's own rounding flips a switch there."""
@@ -74,7 +75,7 @@ def check_against_oracle_spread(err_hip: dict, err_o32: dict, switch: np.ndarray
         thr = 2 * np.quantile(o, 0.999)
         nh, no = int((h > thr).sum()), int((o > thr).sum())
         assert nh <= 1.5 * no + 5, f"{label}{k}: {nh} env-steps beyond {thr:.2e}, the oracle's fp32 run has {no}"
-        assert h.max() <= 4 * max(o.max(), 1000 * floor[k]), f"{label}{k}: max {h.max():.3e} vs oracle fp32 max {o.max():.3e}"
+        assert h.max() <= TOL[k][3], f"{label}{k}: max {h.max():.3e} (oracle fp32 max {o.max():.3e})"
         unexplained = int(((h > thr) & ~sw).sum())
         assert unexplained <= 8, f"{label}{k}: {unexplained} outliers beyond {thr:.2e} on env-steps without a discrete solver switch"
 
