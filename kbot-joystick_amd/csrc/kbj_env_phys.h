@@ -182,16 +182,32 @@ template <int W> KBJ_DEV float subtree_sum(const float (*q)[W], int b, int k) {
 }
 
 KBJ_DEV void phys_crb_mass(KbjShared& S) {
-  PFOR(w, NB * 10) { int b = w / 10, k = w % 10; S.u.crb[b][k] = subtree_sum<10>(S.cinert, b, k); }
+  // composite inertias: suffix sums from the tip of each limb towards the torso (one lane per limb and component), then torso and base
+  PFOR(w, 50) {
+    const int c = w / 10, k = w % 10;
+    if (c < 4) {
+      float acc = 0;
+      for (int k5 = 4; k5 >= 0; --k5) { const int b = 3 + 5 * c + k5; acc += S.cinert[b][k]; S.u.crb[b][k] = acc; }
+    } else S.u.crb[23][k] = S.cinert[23][k];
+  }
   KBJ_SYNC();
+  PFOR(k, 10) {
+    const float t = S.cinert[2][k] + (((S.u.crb[3][k] + S.u.crb[8][k]) + (S.u.crb[13][k] + S.u.crb[18][k])) + S.u.crb[23][k]);
+    S.u.crb[2][k] = t; S.u.crb[1][k] = t + S.cinert[1][k]; S.u.crb[0][k] = 0;
+  }
+  KBJ_SYNC();
+  // M[i][j] = cdof_j . (crb[body_i] cdof_i) for j = i and its ancestors: the six base dofs, then the limb's dofs up to i
   PFOR(i, NV) {
     float buf[6];
     inert_mul(S.u.crb[dof_body(i)], S.cdof[i], buf);
-    for (int j = i; j >= 0; j = dof_parent(j)) {
-      float s = 0;
-      for (int k = 0; k < 6; ++k) s += S.cdof[j][k] * buf[k];
-      if (j == i) s += S.ep[KBJ_EP_ARMATURE + i];
-      M_at(S, i, j) = s;
+    auto dot = [&](int j) { float x = 0; for (int k = 0; k < 6; ++k) x += S.cdof[j][k] * buf[k]; return x; };
+    const float arm = S.ep[KBJ_EP_ARMATURE + i];
+    if (i < 6) {
+      for (int j = 0; j <= i; ++j) S.Mb[i][j] = dot(j) + (j == i ? arm : 0.0f);
+    } else {
+      const int c = (i - 6) / 5, a = (i - 6) % 5;
+      for (int j = 0; j < 6; ++j) S.Mc[c][a][j] = dot(j);
+      for (int a2 = 0; a2 <= a; ++a2) S.Mc[c][a][6 + a2] = dot(6 + 5 * c + a2) + (a2 == a ? arm : 0.0f);
     }
   }
   KBJ_SYNC();
@@ -224,9 +240,11 @@ KBJ_DEV void phys_collide_vel(KbjShared& S, const KbjModelLds& m, const PhysCons
       S.conact[ci] = dist < 0;
     }
   }
-  PFOR(c, 5) {  // limb walkers: spatial velocity, acceleration bias and body forces (RNE forward pass)
+  // RNE forward pass in two steps: five walkers (four limbs + imu) carry the spatial velocity and the bias acceleration outwards
+  // (a cross product and two axpys per body), then the body forces I a + v x* (I v) for all bodies in parallel
+  PFOR(c, 5) {
     float v[6] = {0, 0, 0, 0, 0, 0}, a[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
-    float cdd[6], Ia[6], Iv[6], x[6];
+    float cdd[6];
     // base body: 3 translations (cdof_dot = 0) then 3 rotations sharing the pre-rotation velocity
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 6; ++k) v[k] += S.cdof[i][k] * qvel[i];
     float vb[6];
@@ -235,29 +253,41 @@ KBJ_DEV void phys_collide_vel(KbjShared& S, const KbjModelLds& m, const PhysCons
       cross_motion(vb, S.cdof[i], cdd);
       for (int k = 0; k < 6; ++k) { v[k] += S.cdof[i][k] * qvel[i]; a[k] += cdd[k] * qvel[i]; }
     }
-    if (c == 0) {
-      for (int b = 0; b < 3; ++b) {
-        if (b == 0) { for (int k = 0; k < 6; ++k) { S.cvel[0][k] = 0; S.u.cfrc[0][k] = 0; } continue; }
-        for (int k = 0; k < 6; ++k) S.cvel[b][k] = v[k];
-        inert_mul(S.cinert[b], a, Ia); inert_mul(S.cinert[b], v, Iv); cross_force(v, Iv, x);
-        for (int k = 0; k < 6; ++k) S.u.cfrc[b][k] = Ia[k] + x[k];
-      }
+    if (c == 4) {   // base and torso move together; world body at rest
+      for (int k = 0; k < 6; ++k) { S.cvel[0][k] = 0; S.u.cfrc_acc[0][k] = 0; S.cvel[1][k] = v[k]; S.u.cfrc_acc[1][k] = a[k]; S.cvel[2][k] = v[k]; S.u.cfrc_acc[2][k] = a[k]; }
     }
-    int nb = c < 4 ? 5 : 1;
+    const int nb = c < 4 ? 5 : 1;
     for (int k5 = 0; k5 < nb; ++k5) {
-      int b = c < 4 ? 3 + 5 * c + k5 : 23;
+      const int b = c < 4 ? 3 + 5 * c + k5 : 23;
       if (c < 4) {
-        int d = b + 3;
+        const int d = b + 3;
         cross_motion(v, S.cdof[d], cdd);
         for (int k = 0; k < 6; ++k) { v[k] += S.cdof[d][k] * qvel[d]; a[k] += cdd[k] * qvel[d]; }
       }
-      for (int k = 0; k < 6; ++k) S.cvel[b][k] = v[k];
-      inert_mul(S.cinert[b], a, Ia); inert_mul(S.cinert[b], v, Iv); cross_force(v, Iv, x);
-      for (int k = 0; k < 6; ++k) S.u.cfrc[b][k] = Ia[k] + x[k];
+      for (int k = 0; k < 6; ++k) { S.cvel[b][k] = v[k]; S.u.cfrc_acc[b][k] = a[k]; }   // cfrc_acc doubles as the acceleration buffer
     }
   }
   KBJ_SYNC();
-  PFOR(w, NB * 6) { int b = w / 6, k = w % 6; S.u.cfrc_acc[b][k] = subtree_sum<6>(S.u.cfrc, b, k); }
+  PFOR(b, NB) {
+    float v[6], a[6], Ia[6], Iv[6], x[6];
+    for (int k = 0; k < 6; ++k) { v[k] = S.cvel[b][k]; a[k] = S.u.cfrc_acc[b][k]; }
+    inert_mul(S.cinert[b], a, Ia); inert_mul(S.cinert[b], v, Iv); cross_force(v, Iv, x);
+    for (int k = 0; k < 6; ++k) S.u.cfrc[b][k] = b ? Ia[k] + x[k] : 0.0f;
+  }
+  KBJ_SYNC();
+  // subtree sums of the body forces: suffix sums along the limbs, then torso and base
+  PFOR(w, 30) {
+    const int c = w / 6, k = w % 6;
+    if (c < 4) {
+      float acc = 0;
+      for (int k5 = 4; k5 >= 0; --k5) { const int b = 3 + 5 * c + k5; acc += S.u.cfrc[b][k]; S.u.cfrc_acc[b][k] = acc; }
+    } else S.u.cfrc_acc[23][k] = S.u.cfrc[23][k];
+  }
+  KBJ_SYNC();
+  PFOR(k, 6) {
+    const float t = S.u.cfrc[2][k] + (((S.u.cfrc_acc[3][k] + S.u.cfrc_acc[8][k]) + (S.u.cfrc_acc[13][k] + S.u.cfrc_acc[18][k])) + S.u.cfrc_acc[23][k]);
+    S.u.cfrc_acc[2][k] = t; S.u.cfrc_acc[1][k] = t + S.u.cfrc[1][k]; S.u.cfrc_acc[0][k] = 0;
+  }
   KBJ_SYNC();
 }
 
