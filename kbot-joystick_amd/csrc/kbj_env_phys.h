@@ -450,9 +450,8 @@ KBJ_DEV float rows_sum4(float v) {  // sum over the four rows (same lane-in-row)
 // Solves G x = g with G = M (+ J^T D J of the rows in their quadratic zone when HESS). Everything is in the SOLVER LAYOUT of the
 // wavefront: lane 16 c + r holds, for r = 0..4, chain dof 10 + 5 c - r (ankle .. hip of limb c) and, for r = 5..10, base dof r - 5
 // (replicated in the four DPP rows); m[0..10] is that dof's row of M against (its chain's dofs ankle..hip | the six base dofs).
-// g comes in and x goes out in that layout, so a solve touches LDS only for the contact rows of the Hessian.
-template <bool HESS> KBJ_DEV float arrow_solve_reg(const KbjShared& S, const float (&m)[11], float g, float diag_add, int c, int r) {
-  const int rr = r < 11 ? r : 11;
+// g comes in and x goes out in that layout: a solve touches no memory at all.
+template <bool HESS> KBJ_DEV float arrow_solve_reg(const float (&m)[11], const float (&h)[11], float g, float diag_add, int r) {
   float bc[11];
   static_for<0, 11>([&](auto Jc_) { constexpr int j = decltype(Jc_)::value; bc[j] = row_bcast<j>(g); });
   float a[11];
@@ -460,20 +459,9 @@ template <bool HESS> KBJ_DEV float arrow_solve_reg(const KbjShared& S, const flo
   for (int j = 0; j < 5; ++j) a[j] = r < 11 ? m[j] : bc[j];   // rows 0..10: M; row 11 (and its shadows 12..15): the right-hand side
 #pragma unroll
   for (int j = 5; j < 11; ++j) a[j] = 0.0f;
-  if (HESS) {
-    if (c < 2 && rr < 11) {  // legs: J^T D J of this leg's 16 pyramid rows (those in their quadratic zone)
-      const int col = rr < 5 ? 10 - rr : rr - 5;
-      for (int k = 0; k < 16; ++k) {
-        const int row = 16 * c + k;
-        const float w = S.quad[ROW_CON + row] ? S.D[ROW_CON + row] : 0.0f;
-        if (__builtin_amdgcn_ballot_w64(w != 0.0f) == 0) continue;   // neither leg has this row active
-        const float* J = S.Jc[row];
-        const float t = w * J[col];
-        a[0] = fmaf(t, J[10], a[0]); a[1] = fmaf(t, J[9], a[1]); a[2] = fmaf(t, J[8], a[2]); a[3] = fmaf(t, J[7], a[3]); a[4] = fmaf(t, J[6], a[4]);
-        a[5] = fmaf(t, J[0], a[5]); a[6] = fmaf(t, J[1], a[6]); a[7] = fmaf(t, J[2], a[7]); a[8] = fmaf(t, J[3], a[8]); a[9] = fmaf(t, J[4], a[9]);
-        a[10] = fmaf(t, J[5], a[10]);
-      }
-    }
+  if (HESS) {   // h: this row of J^T D J over the leg's pyramid rows in their quadratic zone (kept up to date by the caller)
+#pragma unroll
+    for (int j = 0; j < 11; ++j) a[j] += r < 11 ? h[j] : 0.0f;
 #pragma unroll
     for (int j = 0; j < 5; ++j) a[j] += r == j ? diag_add : 0.0f;   // friction-loss / joint-limit rows are unit vectors: diagonal only
   }
@@ -841,7 +829,11 @@ KBJ_DEV void phys_solve(KbjShared& S, const KbjModelLds& mdl, const PhysConst& p
   auto cost_u = [&](float D, float x) { return (D != 0 && x < 0) ? 0.5f * D * x * x : 0.0f; };
 
   // ---- unconstrained acceleration ----
-  const float qas = arrow_solve_reg<false>(S, m, qs, 0.0f, c, r);
+  float h[11];
+#pragma unroll
+  for (int j = 0; j < 11; ++j) h[j] = 0.0f;
+  float w_prev = 0.0f;   // weight (D when in the quadratic zone, else 0) with which this lane's pyramid row currently sits in h
+  const float qas = arrow_solve_reg<false>(m, h, qs, 0.0f, r);
   KBJ_STAMP(7);
   // ---- warm start: the cheaper of the previous step's acceleration and the unconstrained one ----
   float vj[11];
@@ -869,7 +861,13 @@ KBJ_DEV void phys_solve(KbjShared& S, const KbjModelLds& mdl, const PhysConst& p
   };
   for (int it = 0; it < pc.iterations; ++it) {
     rows_force_reg();
-    if (is_con) S.quad[ROW_CON + lane] = qc;   // the Hessian's contact part reads the quadratic-zone flags (and D, Jc) from LDS
+    // contact part of the Hessian, incrementally: only rows whose quadratic-zone flag flipped since the last solve change h (all active
+    // rows on the first iteration). The weight changes go through LDS (S.force is free until the solve ends), the changed rows are a
+    // ballot mask, so an iteration without flips costs nothing here.
+    const float w_now = qc ? Dc : 0.0f, dw = w_now - w_prev;
+    w_prev = w_now;
+    if (is_con) S.force[ROW_CON + lane] = dw;
+    const unsigned long long chg = __builtin_amdgcn_ballot_w64(is_con && dw != 0.0f);
     // gradient: M qacc - qfrc_smooth - J^T force
     float s[11];
 #pragma unroll
@@ -884,7 +882,23 @@ KBJ_DEV void phys_solve(KbjShared& S, const KbjModelLds& mdl, const PhysConst& p
     KBJ_SYNC();
     KBJ_STAMP(9);
     if (scale * sqrtf(gg) < pc.tolerance) break;
-    const float se = arrow_solve_reg<true>(S, m, -gr, (qf ? Df : 0.0f) + (ql ? Dl : 0.0f), c, r);
+    {
+      unsigned rows = (unsigned)(chg & 0xFFFFu) | (unsigned)((chg >> 16) & 0xFFFFu);   // row k of either leg changed
+      const int col = r < 5 ? 10 - r : (r <= 10 ? r - 5 : 0);                            // column of Jc this lane's block row stands for
+      while (rows) {
+        const int k = __builtin_ctz(rows);
+        rows &= rows - 1;
+        if (c < 2 && r <= 10) {
+          const int row = 16 * c + k;
+          const float* J = S.Jc[row];
+          const float t = S.force[ROW_CON + row] * J[col];
+          h[0] = fmaf(t, J[10], h[0]); h[1] = fmaf(t, J[9], h[1]); h[2] = fmaf(t, J[8], h[2]); h[3] = fmaf(t, J[7], h[3]); h[4] = fmaf(t, J[6], h[4]);
+          h[5] = fmaf(t, J[0], h[5]); h[6] = fmaf(t, J[1], h[6]); h[7] = fmaf(t, J[2], h[7]); h[8] = fmaf(t, J[3], h[8]); h[9] = fmaf(t, J[4], h[9]);
+          h[10] = fmaf(t, J[5], h[10]);
+        }
+      }
+    }
+    const float se = arrow_solve_reg<true>(m, h, -gr, (qf ? Df : 0.0f) + (ql ? Dl : 0.0f), r);
     KBJ_STAMP(10);
     bcast11(se, vj);
     const float mv = mul_M(vj);
