@@ -8,7 +8,7 @@ using namespace kbj;
 
 namespace {
 
-__device__ __forceinline__ PhysConst make_pc(const kbj_config& c) { return phys_const(c); }
+
 
 // grid = N workgroups of one wavefront; env state rows are read/written lane-contiguously (coalesced)
 __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, uint32_t seed,
@@ -19,7 +19,7 @@ __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restri
   PFOR(k, KBJ_ES_SIZE) S.es[k] = 0;
   KBJ_SYNC();
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
-  PhysConst pc = make_pc(*c);
+  PhysConst pc = phys_const(*c, *m);
   task_reset(S, *m, *c, pc, rng);
   task_write_obs(S, *m, *c, rng, actor0 + (size_t)env * KBJ_LD_ACTOR, critic0 + (size_t)env * KBJ_LD_CRITIC, aux0 + (size_t)env * KBJ_AUX_SIZE);
   PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR
   PFOR(k, KBJ_ES_SIZE) S.es[k] = es[(size_t)env * KBJ_ES_SIZE + k];
   KBJ_SYNC();
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
-  PhysConst pc = make_pc(*c);
+  PhysConst pc = phys_const(*c, *m);
   KBJ_STAMP(18);
   task_step(S, *m, *c, pc, rng, action + (size_t)env * KBJ_NU, aux_t + (size_t)env * KBJ_AUX_SIZE, actor_next + (size_t)env * KBJ_LD_ACTOR,
             critic_next + (size_t)env * KBJ_LD_CRITIC, aux_next + (size_t)env * KBJ_AUX_SIZE);

@@ -87,6 +87,7 @@ struct KbjShared {
   union {
     struct { float crb[NB][10]; };
     struct { float cfrc[NB][6], cfrc_acc[NB][6]; };
+    struct { float jp[NCON][11][3]; };   // contact-frame point Jacobians (normal, tangent 1, tangent 2) while the constraint rows are built
 #if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)
     struct {
       float A[4][12][12];  // chain-local blocks [ankle..hip | base 6], row 11 = right-hand side

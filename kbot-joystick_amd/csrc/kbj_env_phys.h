@@ -25,16 +25,32 @@ __shared__ unsigned long long kbj_env_stamp_last;
 
 namespace kbj {
 
-struct PhysConst {  // per-launch constants derived from kbj_config
+// solref / solimp of one constraint family, reduced once per launch to what the rows need: stiffness k and damping b of the
+// reference acceleration, and the clamped impedance parameters (MuJoCo's mj_makeImpedance)
+struct ImpConst { float k, b, dmin, dmax, width, mid, power; };
+KBJ_DEV ImpConst imp_const(const float* solref, const float* solimp, float dt) {
+  ImpConst ic;
+  ic.dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f); ic.dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
+  ic.width = fmaxf(solimp[2], 1e-15f); ic.mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f); ic.power = fmaxf(solimp[4], 1.0f);
+  const float tc = fmaxf(solref[0], 2 * dt), dr = solref[1];
+  ic.k = 1 / (ic.dmax * ic.dmax * tc * tc * dr * dr);
+  ic.b = 2 / (ic.dmax * tc);
+  return ic;
+}
+struct PhysConst {  // per-launch constants derived from kbj_config and the model
   float dt, tolerance;
   int iterations, ls_iterations;
   float tamp, tkw;   // terrain z = tamp sin(tkw x) sin(tkw y); tamp = 0: the plane z = 0
+  ImpConst fric, lim, con;
 };
-KBJ_DEV PhysConst phys_const(const kbj_config& c) {
+KBJ_DEV PhysConst phys_const(const kbj_config& c, const kbj_model& m) {
   PhysConst pc;
   pc.dt = c.dt; pc.tolerance = c.solver_tolerance; pc.iterations = c.solver_iterations; pc.ls_iterations = c.ls_iterations;
   pc.tamp = c.terrain_amp;
   pc.tkw = c.terrain_amp != 0 ? (float)(6.283185307179586 / c.terrain_wavelength) : 0.0f;
+  pc.fric = imp_const(m.fric_solref, m.fric_solimp, c.dt);
+  pc.lim = imp_const(m.limit_solref, m.limit_solimp, c.dt);
+  pc.con = imp_const(m.contact_solref, m.contact_solimp, c.dt);
   return pc;
 }
 // terrain height and unit normal at (x, y)
@@ -525,24 +541,16 @@ KBJ_DEV float mul_M_row(const KbjShared& S, int i, const float* v) {
 #endif
 
 // ---- constraint rows -------------------------------------------------------------------------------------------
-KBJ_DEV float impedance(float dist, const float* solimp) {
-  float dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f), dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
-  float width = fmaxf(solimp[2], 1e-15f), mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f), power = fmaxf(solimp[4], 1.0f);
-  float x = fabsf(dist) / width;
-  if (x >= 1) return dmax;
-  if (x <= 0) return dmin;
+KBJ_DEV float impedance(float dist, const ImpConst& ic) {
+  float x = fabsf(dist) / ic.width;
+  if (x >= 1) return ic.dmax;
+  if (x <= 0) return ic.dmin;
   float y;
-  if (power == 1.0f) y = x;
-  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1);
-  else y = 1 - powf(1 - x, power) / powf(1 - mid, power - 1);
-  return dmin + y * (dmax - dmin);
-}
-KBJ_DEV void kbi(const float* solref, const float* solimp, float dist, float dt, float& k, float& b, float& imp) {
-  float dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
-  float tc = fmaxf(solref[0], 2 * dt), dr = solref[1];
-  k = 1 / (dmax * dmax * tc * tc * dr * dr);
-  b = 2 / (dmax * tc);
-  imp = impedance(dist, solimp);
+  if (ic.power == 1.0f) y = x;
+  else if (ic.power == 2.0f) y = x <= ic.mid ? x * x / ic.mid : 1 - (1 - x) * (1 - x) / (1 - ic.mid);   // MuJoCo's default power, without pow()
+  else if (x <= ic.mid) y = powf(x, ic.power) / powf(ic.mid, ic.power - 1);
+  else y = 1 - powf(1 - x, ic.power) / powf(1 - ic.mid, ic.power - 1);
+  return ic.dmin + y * (ic.dmax - ic.dmin);
 }
 
 KBJ_DEV void phys_make_constraints(KbjShared& S, const KbjModelLds& m, const PhysConst& pc) {
@@ -550,8 +558,7 @@ KBJ_DEV void phys_make_constraints(KbjShared& S, const KbjModelLds& m, const Phy
   const float* qvel = S.es + KBJ_ES_QVEL;
   PFOR(u, NU) {
     int dof = 6 + u;
-    float k, b, imp;
-    kbi(m.fric_solref, m.fric_solimp, 0.0f, pc.dt, k, b, imp);
+    const float b = pc.fric.b, imp = pc.fric.dmin;   // impedance at distance 0
     float fl = S.ep[KBJ_EP_FRICLOSS + dof];
     float Rr = fmaxf(1e-15f, (1 - imp) / imp * m.dof_invweight0[dof]);
     S.Rf[u] = Rr; S.D[u] = fl > 0 ? 1 / Rr : 0.0f; S.aref[u] = -b * qvel[dof]; S.floss[u] = fl;
@@ -561,47 +568,52 @@ KBJ_DEV void phys_make_constraints(KbjShared& S, const KbjModelLds& m, const Phy
     int r = ROW_LIM + u;
     S.lsign[u] = sgn;
     if (pos < 0) {
-      kbi(m.limit_solref, m.limit_solimp, pos, pc.dt, k, b, imp);
-      float Rl = fmaxf(1e-15f, (1 - imp) / imp * m.dof_invweight0[dof]);
-      S.D[r] = 1 / Rl; S.aref[r] = -b * sgn * qvel[dof] - k * imp * pos;
+      const float impl = impedance(pos, pc.lim);
+      float Rl = fmaxf(1e-15f, (1 - impl) / impl * m.dof_invweight0[dof]);
+      S.D[r] = 1 / Rl; S.aref[r] = -pc.lim.b * sgn * qvel[dof] - pc.lim.k * impl * pos;
     } else { S.D[r] = 0; S.aref[r] = 0; }
   }
+  // point Jacobian of every active contact in its contact frame, once per (contact, column) - the four pyramid rows of a contact
+  // are combinations of the same three components (normal, two tangents)
+  PFOR(w, NCON * 11) {
+    const int ci = w / 11, k = w % 11, leg = ci / 4;
+    if (!S.conact[ci]) continue;
+    const int dk = k < 6 ? k : 6 + 5 * leg + (k - 6);
+    const float off[3] = {S.conpos[ci][0] - S.com[0], S.conpos[ci][1] - S.com[1], S.conpos[ci][2] - S.com[2]};
+    float t[3];
+    cross3(S.cdof[dk], off, t);
+    const float jp[3] = {S.cdof[dk][3] + t[0], S.cdof[dk][4] + t[1], S.cdof[dk][5] + t[2]};
+    float jn = jp[2], j1 = jp[0], j2 = jp[1];   // plane z = 0: normal = world z, tangents = world x, y
+    if (pc.tamp != 0) {  // contact frame: n = surface normal, t1 = world x made orthogonal to n, t2 = n x t1
+      const float nr[3] = {S.connrm[ci][0], S.connrm[ci][1], S.connrm[ci][2]};
+      const float inv = 1 / sqrtf(1 - nr[0] * nr[0]);
+      const float t1[3] = {(1 - nr[0] * nr[0]) * inv, -nr[0] * nr[1] * inv, -nr[0] * nr[2] * inv};
+      const float t2[3] = {nr[1] * t1[2] - nr[2] * t1[1], nr[2] * t1[0] - nr[0] * t1[2], nr[0] * t1[1] - nr[1] * t1[0]};
+      jn = nr[0] * jp[0] + nr[1] * jp[1] + nr[2] * jp[2];
+      j1 = t1[0] * jp[0] + t1[1] * jp[1] + t1[2] * jp[2];
+      j2 = t2[0] * jp[0] + t2[1] * jp[1] + t2[2] * jp[2];
+    }
+    S.u.jp[ci][k][0] = jn; S.u.jp[ci][k][1] = j1; S.u.jp[ci][k][2] = j2;
+  }
+  KBJ_SYNC();
   PFOR(r, 32) {
-    int ci = r / 4, e = r % 4, leg = ci / 4, row = ROW_CON + r;
+    const int ci = r / 4, e = r % 4, leg = ci / 4, row = ROW_CON + r;
     if (!S.conact[ci]) {
       S.D[row] = 0; S.aref[row] = 0;
       for (int k = 0; k < 11; ++k) S.Jc[r][k] = 0;
       continue;
     }
-    float off[3] = {S.conpos[ci][0] - S.com[0], S.conpos[ci][1] - S.com[1], S.conpos[ci][2] - S.com[2]};
-    float mu = S.ep[KBJ_EP_MU];
-    int ax = e / 2;
-    float sg = (e & 1) ? -mu : mu, vel = 0;
-    float nr[3] = {0, 0, 1}, tg[3] = {ax == 0 ? 1.0f : 0.0f, ax == 1 ? 1.0f : 0.0f, 0};
-    if (pc.tamp != 0) {  // contact frame: n = surface normal, t1 = world x made orthogonal to n, t2 = n x t1
-      for (int k = 0; k < 3; ++k) nr[k] = S.connrm[ci][k];
-      float inv = 1 / sqrtf(1 - nr[0] * nr[0]);
-      float t1[3] = {(1 - nr[0] * nr[0]) * inv, -nr[0] * nr[1] * inv, -nr[0] * nr[2] * inv};
-      if (ax == 0) { tg[0] = t1[0]; tg[1] = t1[1]; tg[2] = t1[2]; }
-      else { tg[0] = nr[1] * t1[2] - nr[2] * t1[1]; tg[1] = nr[2] * t1[0] - nr[0] * t1[2]; tg[2] = nr[0] * t1[1] - nr[1] * t1[0]; }
-    }
+    const float mu = S.ep[KBJ_EP_MU];
+    const int ax = e / 2;
+    const float sg = (e & 1) ? -mu : mu;
+    float vel = 0;
     for (int k = 0; k < 11; ++k) {
-      int dk = k < 6 ? k : 6 + 5 * leg + (k - 6);
-      float t[3];
-      cross3(S.cdof[dk], off, t);
-      float jn, jt;
-      if (pc.tamp == 0) { jn = S.cdof[dk][5] + t[2]; jt = S.cdof[dk][3 + ax] + t[ax]; }
-      else {
-        float jp[3] = {S.cdof[dk][3] + t[0], S.cdof[dk][4] + t[1], S.cdof[dk][5] + t[2]};
-        jn = nr[0] * jp[0] + nr[1] * jp[1] + nr[2] * jp[2];
-        jt = tg[0] * jp[0] + tg[1] * jp[1] + tg[2] * jp[2];
-      }
-      float j = jn + sg * jt;
+      const int dk = k < 6 ? k : 6 + 5 * leg + (k - 6);
+      const float j = S.u.jp[ci][k][0] + sg * S.u.jp[ci][k][1 + ax];
       S.Jc[r][k] = j;
       vel += j * qvel[dk];
     }
-    float k_, b_, imp;
-    kbi(m.contact_solref, m.contact_solimp, S.condist[ci], pc.dt, k_, b_, imp);
+    const float k_ = pc.con.k, b_ = pc.con.b, imp = impedance(S.condist[ci], pc.con);
     float tran = m.body_invweight0[leg ? 12 : 7][0];
     float invw = (tran + mu * mu * tran) * 2 * mu * mu;
     float Rc = fmaxf(1e-15f, (1 - imp) / imp * invw);

@@ -9,15 +9,12 @@
 
 using namespace kbj;
 
-static PhysConst make_pc(const kbj_config* c) {
-  PhysConst pc = phys_const(*c);
-  return pc;
-}
+static PhysConst make_pc(const kbj_config* c, const kbj_model* m) { return phys_const(*c, *m); }
 
 extern "C" {
 
 void kbj_emu_reset_all(const kbj_model* m, const kbj_config* c, uint32_t seed, float* ep, float* es, float* a0, float* c0, float* x0) {
-  PhysConst pc = make_pc(c);
+  PhysConst pc = make_pc(c, m);
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < c->num_envs; ++i) {
     std::unique_ptr<KbjShared> S(new KbjShared());
@@ -33,7 +30,7 @@ void kbj_emu_reset_all(const kbj_model* m, const kbj_config* c, uint32_t seed, f
 
 void kbj_emu_env_step(const kbj_model* m, const kbj_config* c, uint32_t seed, float* ep, float* es, const float* action, float* aux_t,
                       float* an, float* cn, float* xn) {
-  PhysConst pc = make_pc(c);
+  PhysConst pc = make_pc(c, m);
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < c->num_envs; ++i) {
     std::unique_ptr<KbjShared> S(new KbjShared());
