@@ -1,0 +1,26 @@
+#!/bin/bash
+# Collects every profile the repo commits under profiles/ (run on the GPU box through gpurun):
+#   1. rocprofv3 --kernel-trace --stats of the default bench  -> gpurun_out/<tag>/stats (summarised by tools/rocprof_summary.py)
+#   2. PMC passes (each its own run, kernel-trace only): FETCH_SIZE, WRITE_SIZE (HBM traffic), MFMA / VALU busy of the update
+#      kernels, SQ counters of env_step_kernel
+# usage: tools/profile_all.sh <tag>      (then tools/profile_collect.py <tag> on the build box writes profiles/)
+set -o pipefail
+TAG=${1:-r02}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+export TMPDIR=/tmp
+cd /tmp
+python3 $R/bench.py --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
+rocprofv3 --kernel-trace --stats -d $O/stats -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1 || exit 1
+python3 $R/tools/rocprof_summary.py $O/stats/run_results.db > $O/kernel_stats.md || exit 1
+python3 $R/tools/pmc_sq.py $O/pmc_bench --set hbm --set mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_bench.txt 2>&1 || exit 1
+KBJ_PROFILE_CMD="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline" python3 $R/tools/pmc_traffic.py $O/pmc_bench/pass0 $O/pmc_bench/pass1 > $O/pmc_traffic.json || exit 1
+python3 $R/tools/pmc_sq.py $O/pmc_env --kernel env_step --set sq --set hbm -- python3 $R/tools/bench_env.py 8192 > $O/pmc_env.txt 2>&1 || exit 1
+# the raw traces are hundreds of MB: only the summaries travel back (gpurun_out is capped at 64 MiB)
+cp $O/pmc_bench/summary.json $O/pmc_bench_summary.json && cp $O/pmc_env/summary.json $O/pmc_env_summary.json
+rm -rf $O/stats $O/pmc_bench $O/pmc_env
+python3 $R/tools/bench_env.py 8192 > $O/bench_env.txt 2>&1
+python3 $R/tools/env_stamps.py > $O/env_stamps.txt 2>&1
+python3 $R/tools/bench_ppo.py > $O/bench_ppo.txt 2>&1
+echo done
