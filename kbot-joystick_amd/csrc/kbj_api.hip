@@ -88,7 +88,14 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   KBJ_TRY(hipMemset(ctx->rcarry_d, 0, N * KBJ_RC_SIZE * sizeof(float)));
   KBJ_TRY(hipEventCreate(&ctx->ev0));
   KBJ_TRY(hipEventCreate(&ctx->ev1));
-  KBJ_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+  // stream2 carries the critic-type nets of the update. The critic's chain is the longer one (a 475-wide input projection in front of
+  // layer 0 that the actor folds away), so the joins wait for it: KBJ_CRITIC_PRIORITY=1 gives its lane the highest queue priority.
+  {
+    int lo = 0, hi = 0;
+    KBJ_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const bool critic_high = getenv("KBJ_CRITIC_PRIORITY") && atoi(getenv("KBJ_CRITIC_PRIORITY")) != 0;
+    KBJ_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, critic_high ? hi : 0));
+  }
   // The side lanes carry work that hangs off the critical chain of the update (weight-gradient GEMMs, bias sums) and the critic of the
   // rollout. KBJ_SIDE_PRIORITY=1 gives them the lowest queue priority, so that when a dX GEMM of the chain and a dW GEMM compete for
   // CUs the chain's workgroups go first. Measured zero-sum (7.70 vs 7.68 ms per minibatch): the dX GEMMs finish in 520 instead of
