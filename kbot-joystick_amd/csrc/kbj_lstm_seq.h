@@ -40,6 +40,10 @@ struct SeqFwdArgs {
   int T, B;
   long long* stamps;   // optional [T][6] shader-clock stamps of workgroup 0 (diagnostics), else null
   unsigned spin_limit = SEQ_SPIN_LIMIT;
+  // fused input projection (FUSE kernels): gates = x_t W_ih^T + bias + h_{t-1} W_hh^T computed here, G is then output only
+  const float* X = nullptr;     // [T][B][H] layer input
+  const float* Wih = nullptr;   // [4H][H]
+  const float* bias = nullptr;  // [4H]
 };
 
 struct SeqBwdArgs {
@@ -106,6 +110,15 @@ template <int H, int NTH> struct SeqTile {
       if (r >= B) v[i] = f32x4m{0, 0, 0, 0};
     }
   }
+  // same tile from memory written by an EARLIER kernel (no hand-off): plain cached 16-byte loads
+  __device__ __forceinline__ void load_plain(const float* src, int ld, int r0, int B) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
+      v[i] = *reinterpret_cast<const f32x4m*>(src + (size_t)(r < B ? r : 0) * ld + 4 * c4);
+      if (r >= B) v[i] = f32x4m{0, 0, 0, 0};
+    }
+  }
   __device__ __forceinline__ void to_lds(float* lds) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
@@ -118,12 +131,16 @@ template <int H, int NTH> struct SeqTile {
 // UW = 1: 4 wavefronts own 16 hidden units; UW = 2: 8 wavefronts own 32 units (two 16-unit halves that share the staged h tile and
 // advance in lock step on the same SIMDs: their matrix phases queue behind each other deterministically instead of colliding at
 // random with another workgroup's, and the row group has half as many partners to wait for)
-template <int H, int UW>
+// FUSE: the layer's input projection x_t W_ih^T + b (no dependence on the recurrence) is computed inside the step instead of by a
+// GEMM launch in front of it: its MFMAs are split in two halves placed before the flag poll and behind the issue of the h-tile loads,
+// where the matrix pipe otherwise idles through the hand-off latency; W_ih's slice sits in a second set of 64 B-operand registers.
+template <int H, int UW, bool FUSE = false>
 __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW;
   constexpr int LDH = H + 4;
   constexpr int NUG = H / UNITS;
   __shared__ __attribute__((aligned(16))) float hs[SEQ_ROWS * LDH];
+  __shared__ __attribute__((aligned(16))) float xs[FUSE ? SEQ_ROWS * LDH : 4];
   __shared__ float gbuf[4][SEQ_ROWS][UNITS + 1];
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, gate = (tid >> 6) & 3, uh = tid >> 8;
@@ -140,6 +157,15 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     const float* wrow = a.Whh + (size_t)(gate * H + u0 + SEQ_UNITS * uh + (lane & 15)) * H + (lane >> 4);
 #pragma unroll
     for (int s = 0; s < H / 4; ++s) wreg[s] = wrow[4 * s];
+  }
+  float wxreg[FUSE ? H / 4 : 1];
+  float bias_col = 0.0f;
+  if (FUSE) {
+    const int grow = gate * H + u0 + SEQ_UNITS * uh + (lane & 15);
+    const float* wrow = a.Wih + (size_t)grow * H + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < H / 4; ++s) wxreg[s] = wrow[4 * s];
+    bias_col = a.bias[grow];
   }
   // the two (row, unit) elements of this thread in the cell epilogue and their cell state
   int erow[2], eunit[2];
@@ -163,13 +189,31 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
       bool ok = r < B && tt < T;
       const float* g = a.G + ((size_t)(ok ? tt : 0) * B + (ok ? r : 0)) * 4 * H + u0 + eunit[i];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gxn[i][k] = ok ? g[k * H] : 0.0f;
+      for (int k = 0; k < 4; ++k) gxn[i][k] = (ok && !FUSE) ? g[k * H] : 0.0f;
       kpn[i] = ok ? a.keep[(size_t)tt * B + r] : 0.0f;
     }
   };
   fetch_inputs(0);
+  const float* a0p = hs + (lane & 15) * LDH + (lane >> 4);
+  const float* a1p = a0p + 16 * LDH;
+  const float* x0p = xs + (lane & 15) * LDH + (lane >> 4);
+  const float* x1p = x0p + 16 * LDH;
+  if (FUSE) {   // x_0 tile
+    SeqTile<H, NTH> xt;
+    xt.load_plain(a.X, H, r0, B);
+    xt.to_lds(xs);
+    __syncthreads();
+  }
   for (int t = 0; t < T; ++t) {
     SEQ_STAMP(0);
+    f32x4m acc0 = {bias_col, bias_col, bias_col, bias_col}, acc1 = acc0;
+    if (FUSE) {   // first half of the input projection: runs while the partners' flags travel
+#pragma unroll
+      for (int s = 0; s < H / 8; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
+      }
+    }
     if (t > 0) { if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)t, a.err, &flag, a.spin_limit)) return; }
     SEQ_STAMP(1);
     SeqTile<H, NTH> tile;
@@ -191,12 +235,18 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
         a.Cm[o1 + (size_t)B * H] = cm[i];
       }
     }
+    if (FUSE) {   // second half of the input projection: hides the h-tile fetch
+#pragma unroll
+      for (int s = H / 8; s < H / 4; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
+      }
+    }
     tile.to_lds(hs);
+    SeqTile<H, NTH> xt;
+    if (FUSE && t + 1 < T) xt.load_plain(a.X + (size_t)(t + 1) * B * H, H, r0, B);   // next step's input tile rides behind the recurrent MFMAs
     __syncthreads();
     SEQ_STAMP(2);
-    f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-    const float* a0p = hs + (lane & 15) * LDH + (lane >> 4);
-    const float* a1p = a0p + 16 * LDH;
 #pragma unroll
     for (int s = 0; s < H / 4; ++s) {
       acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * s], wreg[s], acc0, 0, 0, 0);
@@ -207,6 +257,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
       gbuf[gate][(lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc0[r];
       gbuf[gate][16 + (lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc1[r];
     }
+    if (FUSE && t + 1 < T) xt.to_lds(xs);   // every wave is past its reads of xs (they precede this step's barrier above)
     __syncthreads();
     SEQ_STAMP(3);
 #pragma unroll

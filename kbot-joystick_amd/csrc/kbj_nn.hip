@@ -172,7 +172,8 @@ template <int H, int UW> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a0
   a.spin_limit = g_seq_spin_limit;
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
   if (g_seq_drop > 0 && grid > 1) { --g_seq_drop; --grid; }
-  hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
+  if (a.X) hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, true>), dim3(grid), dim3(256 * UW), 0, s, a);   // input projection fused
+  else hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, false>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
 template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0) {
   SeqBwdArgs a = a0;
@@ -182,7 +183,7 @@ template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0
 }
 int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {
   hipMemsetAsync(a.counters, 0, 256 * sizeof(unsigned), st);
-  KbjKernelTimer timer(st, KBJ_KIND_SEQ_FWD, 2.0 * a.T * a.B * 4.0 * H * H);
+  KbjKernelTimer timer(st, KBJ_KIND_SEQ_FWD, (a.X ? 2.0 : 1.0) * 2.0 * a.T * a.B * 4.0 * H * H);
   switch (H * 10 + g_seq_uw) {
     case 641: seq_fwd_launch<64, 1>(st, a); break;
     case 642: seq_fwd_launch<64, 2>(st, a); break;
@@ -594,6 +595,10 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // latency bound, so the two nets overlap) ----
   static const bool fold_actor = getenv("KBJ_FOLD_ACTOR") ? atoi(getenv("KBJ_FOLD_ACTOR")) != 0 : true;
   static const bool fold_critic = getenv("KBJ_FOLD_CRITIC") ? atoi(getenv("KBJ_FOLD_CRITIC")) != 0 : false;   // backward only (475 > H inputs)
+  // forward: the K = H input projections (x W_ih^T + b) run inside the persistent recurrence, their MFMAs placed around the flag poll and
+  // the h-tile fetch where the matrix pipe idles (kbj_lstm_seq.h FUSE): a fused launch takes 1.11 instead of 0.88 ms, the 0.41-0.48 ms
+  // GEMM in front of it and its 210 MB round trip of G disappear: ppo_grad 7.72 -> 7.47 ms. KBJ_SEQ_FUSE=0: separate GEMMs.
+  static const bool fuse_ih = getenv("KBJ_SEQ_FUSE") ? atoi(getenv("KBJ_SEQ_FUSE")) != 0 : true;
   if (fold_actor) {
     // The actor's input projection (65 -> H, no activation) feeds only layer 0's input GEMM, so gates_0 = obs (W_ih0 W_in)^T +
     // (W_ih0 b_in + b_0): a 65-deep contraction instead of 65 -> H -> 4H (6.8 instead of 28.5 GFLOP per minibatch forward, and
@@ -626,13 +631,16 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
       if (fold_actor && (n & 1) == 0 && l == 0) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, KBJ_LD_ACTOR, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0);
-      else linear_fwd(ns[n & 1], l == 0 ? t.X0 : t.Hout[0], H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
+      else if (!fuse_ih) linear_fwd(ns[n & 1], l == 0 ? t.X0 : t.Hout[0], H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
     }
     align();
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
       SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * n, w.seq_err, T, B, (n == 0 && l == 0) ? w.seq_stamps : nullptr};
+      if (fuse_ih && !(fold_actor && (n & 1) == 0 && l == 0)) {   // K = H input projections ride inside the recurrence (kbj_lstm_seq.h FUSE)
+        fa.X = l == 0 ? t.X0 : t.Hout[0]; fa.Wih = params_d + o.w_ih[l]; fa.bias = params_d + o.b[l];
+      }
       if (seq_fwd(ctx, ns[n & 1], H, fa)) return -1;
     }
   }
