@@ -106,8 +106,7 @@ template <int H, int NTH> struct SeqTile {
       int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
       unsigned off = (unsigned)(((size_t)(r < B ? r : 0) * ld + 4 * c4) * sizeof(float));
       u32x4 u = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 16);
-      v[i] = __builtin_bit_cast(f32x4m, u);
-      if (r >= B) v[i] = f32x4m{0, 0, 0, 0};
+      v[i] = __builtin_bit_cast(f32x4m, u);   // rows beyond B are zeroed in to_lds: touching the value here would put the vmcnt wait here
     }
   }
   // same tile from memory written by an EARLIER kernel (no hand-off): plain cached 16-byte loads
@@ -116,14 +115,13 @@ template <int H, int NTH> struct SeqTile {
     for (int i = 0; i < NV; ++i) {
       int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
       v[i] = *reinterpret_cast<const f32x4m*>(src + (size_t)(r < B ? r : 0) * ld + 4 * c4);
-      if (r >= B) v[i] = f32x4m{0, 0, 0, 0};
     }
   }
-  __device__ __forceinline__ void to_lds(float* lds) const {
+  __device__ __forceinline__ void to_lds(float* lds, int r0, int B) const {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4);
-      *reinterpret_cast<f32x4m*>(lds + row * (H + 4) + 4 * c4) = v[i];
+      *reinterpret_cast<f32x4m*>(lds + row * (H + 4) + 4 * c4) = r0 + row < B ? v[i] : f32x4m{0, 0, 0, 0};
     }
   }
 };
@@ -201,7 +199,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   if (FUSE) {   // x_0 tile
     SeqTile<H, NTH> xt;
     xt.load_plain(a.X, H, r0, B);
-    xt.to_lds(xs);
+    xt.to_lds(xs, r0, B);
     __syncthreads();
   }
   for (int t = 0; t < T; ++t) {
@@ -235,14 +233,17 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
         a.Cm[o1 + (size_t)B * H] = cm[i];
       }
     }
-    if (FUSE) {   // second half of the input projection: hides the h-tile fetch
+    if (FUSE) {   // second half of the input projection: hides the h-tile fetch (the scheduling fences keep the compiler from hoisting the
+                  // tile's LDS stores - and the vmcnt wait in front of them - above these MFMAs)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int s = H / 8; s < H / 4; ++s) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    tile.to_lds(hs);
+    tile.to_lds(hs, r0, B);
     SeqTile<H, NTH> xt;
     if (FUSE && t + 1 < T) xt.load_plain(a.X + (size_t)(t + 1) * B * H, H, r0, B);   // next step's input tile rides behind the recurrent MFMAs
     __syncthreads();
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
       gbuf[gate][(lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc0[r];
       gbuf[gate][16 + (lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc1[r];
     }
-    if (FUSE && t + 1 < T) xt.to_lds(xs);   // every wave is past its reads of xs (they precede this step's barrier above)
+    if (FUSE && t + 1 < T) xt.to_lds(xs, r0, B);   // every wave is past its reads of xs (they precede this step's barrier above)
     __syncthreads();
     SEQ_STAMP(3);
 #pragma unroll
@@ -357,7 +358,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       for (int c = 0; c < 4; ++c) {
         float* buf = ds;
         if (c) __syncthreads();                                   // the previous chunk's fragment reads are done
-        tile.to_lds(buf);
+        tile.to_lds(buf, r0, B);
         if (c < 3) tile.load(src + (c + 1) * H, 4 * H, r0, B);   // next chunk in flight during this chunk's MFMAs
         __syncthreads();
         const float* a0p = buf + (lane & 15) * LDH + wave * KW + (lane >> 4);

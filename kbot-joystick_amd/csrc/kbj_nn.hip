@@ -594,6 +594,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // ---- forward through time: actor on the caller's stream, critic on the context's second stream (the recurrences are
   // latency bound, so the two nets overlap) ----
   static const bool fold_actor = getenv("KBJ_FOLD_ACTOR") ? atoi(getenv("KBJ_FOLD_ACTOR")) != 0 : true;
+  static const int stamp_sel = getenv("KBJ_SEQ_STAMPS") ? atoi(getenv("KBJ_SEQ_STAMPS")) : 1;   // diagnostics: 1 + net + 2 * layer picks the stamped forward launch
+  const int stamp_net = (stamp_sel - 1) & 1, stamp_layer = ((stamp_sel - 1) >> 1) & 1;
   static const bool fold_critic = getenv("KBJ_FOLD_CRITIC") ? atoi(getenv("KBJ_FOLD_CRITIC")) != 0 : false;   // backward only (475 > H inputs)
   // forward: the K = H input projections (x W_ih^T + b) run inside the persistent recurrence, their MFMAs placed around the flag poll and
   // the h-tile fetch where the matrix pipe idles (kbj_lstm_seq.h FUSE): a fused launch takes 1.11 instead of 0.88 ms, the 0.41-0.48 ms
@@ -637,7 +639,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
-      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * n, w.seq_err, T, B, (n == 0 && l == 0) ? w.seq_stamps : nullptr};
+      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * n, w.seq_err, T, B, (n == stamp_net && l == stamp_layer) ? w.seq_stamps : nullptr};
       if (fuse_ih && !(fold_actor && (n & 1) == 0 && l == 0)) {   // K = H input projections ride inside the recurrence (kbj_lstm_seq.h FUSE)
         fa.X = l == 0 ? t.X0 : t.Hout[0]; fa.Wih = params_d + o.w_ih[l]; fa.bias = params_d + o.b[l];
       }
