@@ -204,6 +204,9 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   }
   for (int t = 0; t < T; ++t) {
     SEQ_STAMP(0);
+    float gx[2][4], kp[2];   // this step's own inputs, fetched one step ago (taken over before any load of this step is in flight)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { kp[i] = kpn[i]; for (int k = 0; k < 4; ++k) gx[i][k] = gxn[i][k]; }
     f32x4m acc0 = {bias_col, bias_col, bias_col, bias_col}, acc1 = acc0;
     if (FUSE) {   // first half of the input projection: runs while the partners' flags travel
 #pragma unroll
@@ -216,10 +219,19 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     SEQ_STAMP(1);
     SeqTile<H, NTH> tile;
     tile.load(a.Hm + (size_t)t * B * H, H, r0, B);
-    // behind the payload loads: the next step's own inputs, then the previous step's BPTT stash
-    float gx[2][4], kp[2];
+    if (FUSE) {   // second half of the input projection: hides the h-tile fetch (the scheduling fences keep the compiler from hoisting the
+                  // tile's LDS stores - and the vmcnt wait in front of them - above these MFMAs)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { kp[i] = kpn[i]; for (int k = 0; k < 4; ++k) gx[i][k] = gxn[i][k]; }
+      for (int s = H / 8; s < H / 4; ++s) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    tile.to_lds(hs, r0, B);
+    // AFTER the tile has gone to LDS (vector-memory operations retire in order: anything issued between the tile loads and their wait
+    // would be waited for as well): the next step's own inputs, then the previous step's BPTT stash - both have a whole step to land
     fetch_inputs(t + 1);
     if (t > 0) {
 #pragma unroll
@@ -233,17 +245,6 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
         a.Cm[o1 + (size_t)B * H] = cm[i];
       }
     }
-    if (FUSE) {   // second half of the input projection: hides the h-tile fetch (the scheduling fences keep the compiler from hoisting the
-                  // tile's LDS stores - and the vmcnt wait in front of them - above these MFMAs)
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = H / 8; s < H / 4; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    tile.to_lds(hs, r0, B);
     SeqTile<H, NTH> xt;
     if (FUSE && t + 1 < T) xt.load_plain(a.X + (size_t)(t + 1) * B * H, H, r0, B);   // next step's input tile rides behind the recurrent MFMAs
     __syncthreads();
@@ -353,13 +354,14 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       const float* src = a.dG + (size_t)(t + 1) * B * 4 * H;
       SeqTile<H, NTH> tile;
       tile.load(src, 4 * H, r0, B);
-      prefetch();                               // own inputs ride behind the first payload chunk
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         float* buf = ds;
         if (c) __syncthreads();                                   // the previous chunk's fragment reads are done
         tile.to_lds(buf, r0, B);
         if (c < 3) tile.load(src + (c + 1) * H, 4 * H, r0, B);   // next chunk in flight during this chunk's MFMAs
+        else prefetch();   // own inputs of the next step: issued behind the LAST payload wait (vector-memory operations retire in order, so
+                           // anything issued between a chunk's loads and its wait is waited for too); they land during the cell and the hand-off
         __syncthreads();
         const float* a0p = buf + (lane & 15) * LDH + wave * KW + (lane >> 4);
         const float* a1p = a0p + 16 * LDH;
