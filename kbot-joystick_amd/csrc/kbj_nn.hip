@@ -561,7 +561,10 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   auto gather = [&](hipStream_t st, const float* src, int wdt, int lds, float* dst, int ldd) {
-    hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)R * wdt), dim3(256), 0, st, src, idx, T, N, B, wdt, lds, ldd, dst);
+    if (wdt % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && ((size_t)src & 15) == 0 && ((size_t)dst & 15) == 0)
+      hipLaunchKernelGGL(gather_rows4_kernel, g1((size_t)R * (wdt / 4)), dim3(256), 0, st, reinterpret_cast<const float4*>(src), idx, T, N, B, wdt / 4, lds / 4, ldd / 4,
+                         reinterpret_cast<float4*>(dst));
+    else hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)R * wdt), dim3(256), 0, st, src, idx, T, N, B, wdt, lds, ldd, dst);
   };
   gather(ns[1], tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);
   gather(s, tr->actor_obs_d, KBJ_LD_ACTOR, KBJ_LD_ACTOR, w.tb[0].obs, KBJ_LD_ACTOR);

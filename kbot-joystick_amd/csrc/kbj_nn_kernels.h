@@ -111,6 +111,17 @@ __global__ void gather_rows_kernel(const float* __restrict__ src, const int* __r
   int b = r % B, t = r / B;
   dst[r * ld_dst + k] = src[((size_t)t * N + idx[b]) * ld_src + k];
 }
+// the same with 16-byte accesses (w, ld_src, ld_dst multiples of 4 and 16-byte aligned bases: the padded observation rows): one thread
+// moves a float4, a row of the critic observations is 119 consecutive lanes
+__global__ void gather_rows4_kernel(const float4* __restrict__ src, const int* __restrict__ idx, int T, int N, int B, int w4, int ld_src4, int ld_dst4, float4* __restrict__ dst) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)T * B * w4;
+  if (i >= total) return;
+  int k = i % w4;
+  size_t r = i / w4;
+  int b = r % B, t = r / B;
+  dst[r * ld_dst4 + k] = src[((size_t)t * N + idx[b]) * ld_src4 + k];
+}
 // keep[t][b] = 1 - (aux[t][idx[b]][DONE] != 0)
 __global__ void gather_keep_kernel(const float* __restrict__ aux, const int* __restrict__ idx, int T, int N, int B, float* __restrict__ keep) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
