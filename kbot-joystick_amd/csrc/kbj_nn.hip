@@ -183,7 +183,7 @@ template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0
 }
 int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {
   hipMemsetAsync(a.counters, 0, 256 * sizeof(unsigned), st);
-  KbjKernelTimer timer(st, KBJ_KIND_SEQ_FWD, (a.X ? 2.0 : 1.0) * 2.0 * a.T * a.B * 4.0 * H * H);
+  KbjKernelTimer timer(st, a.X ? KBJ_KIND_SEQ_FWD_FUSED : KBJ_KIND_SEQ_FWD, (a.X ? 2.0 : 1.0) * 2.0 * a.T * a.B * 4.0 * H * H);
   switch (H * 10 + g_seq_uw) {
     case 641: seq_fwd_launch<64, 1>(st, a); break;
     case 642: seq_fwd_launch<64, 2>(st, a); break;
