@@ -97,12 +97,12 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
     KBJ_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, critic_high ? hi : 0));
   }
   // The side lanes carry work that hangs off the critical chain of the update (weight-gradient GEMMs, bias sums) and the critic of the
-  // rollout. KBJ_SIDE_PRIORITY=1 gives them the lowest queue priority, so that when a dX GEMM of the chain and a dW GEMM compete for
-  // CUs the chain's workgroups go first. Measured zero-sum (7.70 vs 7.68 ms per minibatch): the dX GEMMs finish in 520 instead of
-  // 756 us, but the displaced dW GEMMs then run beside the backward recurrences, which slow from 895 to 1209 us. Off by default.
+  // rollout: lowest queue priority, so that when a dX GEMM of the chain and a dW GEMM compete for CUs the chain's workgroups go first.
+  // Nearly zero-sum (the dX GEMMs finish in 520 instead of 756 us, but the displaced dW GEMMs then run beside the backward recurrences,
+  // which slow from 895 to 1209 us): 6.91 -> 6.86 ms per minibatch, 444.2 -> 441.8 ms per iteration. KBJ_SIDE_PRIORITY=0: default priority.
   int prio_least = 0, prio_greatest = 0;
   KBJ_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-  const bool side_low = getenv("KBJ_SIDE_PRIORITY") && atoi(getenv("KBJ_SIDE_PRIORITY")) != 0;
+  const bool side_low = !(getenv("KBJ_SIDE_PRIORITY") && atoi(getenv("KBJ_SIDE_PRIORITY")) == 0);
   for (int n = 0; n < 2; ++n) {
     KBJ_TRY(hipStreamCreateWithPriority(&ctx->side[n], hipStreamNonBlocking, side_low ? prio_least : 0));
     KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_side[n], hipEventDisableTiming));

@@ -390,7 +390,7 @@ void policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo,
     if (n == 3) continue;  // the mirrored critic's value is only needed under the gradient; at rollout time only its carry advances
     linear_fwd(s, x, H, params_d + o.w_out, H, params_d + o.b_out, Out, 40, cnt, o.nout, H, 0);
     if (n == 0)
-      hipLaunchKernelGGL(actor_head_sample_kernel, g1(cnt, 64), dim3(64), 0, s, Out, obs, carry->lpf_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, hp, seed,
+      hipLaunchKernelGGL(actor_head_sample_kernel, g1((size_t)cnt * 32), dim3(256), 0, s, Out, obs, carry->lpf_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, hp, seed,
                          (uint32_t)(c.env_id_offset + n0), step_index, argmax, cnt, action_d + (size_t)n0 * KBJ_NU, logp_d + n0);
     else if (n == 1)
       hipLaunchKernelGGL(critic_value_kernel, g1(cnt), dim3(256), 0, s, Out, 40, cnt, value_d + n0);

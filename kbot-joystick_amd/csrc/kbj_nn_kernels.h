@@ -54,15 +54,17 @@ __device__ __forceinline__ void nn_threefry(uint32_t k0, uint32_t k1, uint32_t c
   o0 = x0; o1 = x1;
 }
 
-// ---- actor head at rollout time (train.py:924-941, 1545-1572): one thread per env ---------------------------------
+// ---- actor head at rollout time (train.py:924-941, 1545-1572): 32 lanes per env, one per joint (20 active) --------------
+// (one thread per env walked the 20 joints serially - threefry, log, cos, softplus each - on 128 wavefronts: 48 us on the rollout's
+// critical chain; per joint it is 10 us)
 struct HeadParams { float min_std, max_std, var_scale, alpha; };
 __global__ void actor_head_sample_kernel(const float* __restrict__ out /*[N][40]*/, const float* __restrict__ obs /*[N][68]*/,
                                          float* __restrict__ lpf /*[N][20]*/, const float* __restrict__ joint_bias, HeadParams hp, uint32_t seed,
                                          uint32_t env_off, uint32_t step, int argmax, int N, float* __restrict__ action, float* __restrict__ logp) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  if (n >= N) return;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = tid >> 5, j = tid & 31;
   float lp = 0;
-  for (int j = 0; j < KBJ_NU; ++j) {
+  if (n < N && j < KBJ_NU) {
     float mean = out[n * 40 + j] + joint_bias[j] + (j >= 10 ? obs[(size_t)n * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
     float sd = fminf((softplusf_(out[n * 40 + KBJ_NU + j]) + hp.min_std) * hp.var_scale, hp.max_std);
     float y0 = lpf[n * KBJ_NU + j];
@@ -77,9 +79,10 @@ __global__ void actor_head_sample_kernel(const float* __restrict__ out /*[N][40]
     }
     action[n * KBJ_NU + j] = a;
     float z = (a - y) / sd;
-    lp += -0.5f * z * z - logf(sd) - 0.5f * kLog2Pi;
+    lp = -0.5f * z * z - logf(sd) - 0.5f * kLog2Pi;
   }
-  logp[n] = lp;
+  for (int o = 16; o > 0; o >>= 1) lp += __shfl_xor(lp, o);   // sum over the env's 32 lanes (inactive ones hold 0)
+  if (n < N && j == 0) logp[n] = lp;
 }
 
 // value_d[n] = out[n][0]
