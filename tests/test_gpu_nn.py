@@ -17,7 +17,7 @@ def _setup(N, B, T, H, **kw):
     return m, cfg, ctx, torch, buffers
 
 
-@pytest.mark.parametrize("H", [64, 256])
+@pytest.mark.parametrize("H", [64, 128, 256])     # 128 = the reference dataclass default (train.py:78-81), 256 = the launch value
 def test_policy_step_matches_oracle(H):
     N = 96
     m, cfg, ctx, torch, buffers = _setup(N, 32, 4, H)
@@ -90,7 +90,7 @@ def _synthetic_traj(torch, buffers, N, T, H, seed=0, mirror=False):
     return tr
 
 
-@pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (256, 40, 32, 9), (256, 512, 512, 100)])   # the last one = the BASELINE minibatch
+@pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (128, 70, 35, 6), (256, 40, 32, 9), (256, 512, 512, 100)])   # the last one = the BASELINE minibatch
 def test_ppo_grad_matches_autograd(H, N, B, T):
     m, cfg, ctx, torch, buffers = _setup(N, B, T, H)
     from oracle import nn as ON
