@@ -120,6 +120,8 @@ template <class T> int dalloc(kbj_ctx* ctx, NnWs& w, T** p, size_t count) {
   return 0;
 }
 
+int g_splitk_wgs = 768;   // target number of workgroups of a split-K weight-gradient GEMM (KBJ_SPLITK_WGS)
+
 inline dim3 g1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 // y = x W^T + b  (x [M][K] lda, W [N][K])
@@ -138,7 +140,7 @@ void linear_bwd_weight(hipStream_t s, const float* dy, int lddy, const float* x,
   bool big = Nout >= 128 && Nin >= 128;
   int ts = big ? 128 : 64;
   int tiles = ((Nout + ts - 1) / ts) * ((Nin + ts - 1) / ts);
-  int sk = std::max(2, std::min(256, 768 / std::max(1, tiles)));
+  int sk = std::max(2, std::min(256, g_splitk_wgs / std::max(1, tiles)));
   sk = std::max(2, std::min(sk, (R + 255) / 256));
   GemmArgs g{dy, x, dW, nullptr, Nout, Nin, R, lddy, ldx, lddw, 1, sk, nullptr};  // always the atomic path: accumulates into dW
   gemm_launch<false, false>(s, g, big ? 1 : 0);
@@ -154,7 +156,7 @@ void linear_bwd_weight2(hipStream_t s, const float* dy, int lddy, const float* x
     return;
   }
   int tiles = ((Nout + ts - 1) / ts) * (2 * Nin / ts);
-  int sk = std::max(2, std::min(256, 768 / std::max(1, tiles)));
+  int sk = std::max(2, std::min(256, g_splitk_wgs / std::max(1, tiles)));
   sk = std::max(2, std::min(sk, (R + 255) / 256));
   GemmArgs g{dy, x1, dW1, nullptr, Nout, 2 * Nin, R, lddy, ldx, lddw, 1, sk, nullptr};
   g.B2 = x2; g.C2 = dW2; g.n1 = Nin;
@@ -298,6 +300,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
   if (getenv("KBJ_SEQ_STAMPS")) { if (dalloc(ctx, *w, &w->seq_stamps, (size_t)T * 6)) return -1; }
   if (hipMemset(w->seq_err, 0, 4 * sizeof(unsigned)) != hipSuccess) return kbj_fail(ctx, "hipMemset seq_err");
+  g_splitk_wgs = getenv("KBJ_SPLITK_WGS") ? atoi(getenv("KBJ_SPLITK_WGS")) : 768;
   g_seq_uw = getenv("KBJ_SEQ_UW") ? atoi(getenv("KBJ_SEQ_UW")) : 2;
   if (g_seq_uw != 1 && g_seq_uw != 2) return kbj_fail(ctx, "KBJ_SEQ_UW must be 1 or 2");
   g_seq_drop = getenv("KBJ_DEBUG_DROP_SEQ_WG") ? atoi(getenv("KBJ_DEBUG_DROP_SEQ_WG")) : 0;
@@ -718,7 +721,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
         // (the bias terms follow from db_0 at the end).
         float* Z = w.Zeff[n];
         const int ts = H >= 128 ? 128 : 64;
-        int sk = std::max(2, std::min(768 / ((4 * H / ts) * (H / ts + (o.nin + ts - 1) / ts)), (R + 255) / 256));
+        int sk = std::max(2, std::min(g_splitk_wgs / ((4 * H / ts) * (H / ts + (o.nin + ts - 1) / ts)), (R + 255) / 256));
         GemmArgs g{dG, t.Hm[0], grad_d + o.w_hh[0], nullptr, 4 * H, H + o.nin, R, 4 * H, H, H, 1, sk, nullptr};
         g.B2 = t.obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = o.ld_obs;
         gemm_launch<false, false>(ws, g, H >= 128 ? 1 : 0);
