@@ -137,6 +137,10 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW;
   constexpr int LDH = H + 4;
   constexpr int NUG = H / UNITS;
+#ifndef KBJ_SEQ_XSPLIT_NUM
+#define KBJ_SEQ_XSPLIT_NUM 4   // eighths of the input projection's k-steps issued before the flag poll (the rest hides the tile fetch)
+#endif
+  constexpr int XSPLIT = (H / 4) * KBJ_SEQ_XSPLIT_NUM / 8;
   __shared__ __attribute__((aligned(16))) float hs[SEQ_ROWS * LDH];
   __shared__ __attribute__((aligned(16))) float xs[FUSE ? SEQ_ROWS * LDH : 4];
   __shared__ float gbuf[4][SEQ_ROWS][UNITS + 1];
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     f32x4m acc0 = {bias_col, bias_col, bias_col, bias_col}, acc1 = acc0;
     if (FUSE) {   // first half of the input projection: runs while the partners' flags travel
 #pragma unroll
-      for (int s = 0; s < H / 8; ++s) {
+      for (int s = 0; s < XSPLIT; ++s) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
       }
@@ -223,7 +227,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
                   // tile's LDS stores - and the vmcnt wait in front of them - above these MFMAs)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = H / 8; s < H / 4; ++s) {
+      for (int s = XSPLIT; s < H / 4; ++s) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
       }
