@@ -137,7 +137,13 @@ class HumanoidWalkingTask:
     the gradient all-reduce before each optimizer step.
     """
 
-    def __init__(self, config: HumanoidWalkingTaskConfig, device: Optional[torch.device] = None, rank: int = 0, world_size: int = 1):
+    def __init__(self, config: HumanoidWalkingTaskConfig, device: Optional[torch.device] = None, rank: int = 0, world_size: int = 1,
+                 extra_rewards: Optional[dict] = None):
+        """extra_rewards: {name: term} of Python reward terms in ksim's Reward protocol (`scale`, `get_reward(trajectory)` or the stateful
+        pair), evaluated on `TrajectoryView` after every rollout and added to the built-in stack's reward (host/traj_view.py)."""
+        self.extra_rewards = dict(extra_rewards or {})
+        self._extra_carries: dict = {}
+        self.extra_reward_means: dict = {}
         if not torch.cuda.is_available():
             raise B.KbjError("HumanoidWalkingTask needs a HIP device (no CPU fallback)")
         self.config = config
@@ -190,6 +196,9 @@ class HumanoidWalkingTask:
     def rollout(self):
         """T control steps of all envs, trajectory + rewards on the device."""
         self.ctx.rollout(self.params, self.carry.c, self.config.seed, self.iteration * self.T, self.traj.c)
+        if self.extra_rewards:
+            from .traj_view import TrajectoryView, apply_extra_rewards
+            self.extra_reward_means = apply_extra_rewards(self.extra_rewards, self._extra_carries, TrajectoryView(self.traj, self.T), self.traj.reward)
 
     def update(self):
         """GAE, then num_passes x (N / B) minibatch steps: BPTT gradient, all-reduce, AdamW."""

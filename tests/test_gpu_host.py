@@ -98,6 +98,55 @@ def test_edited_reward_table_matches_oracle(model):
     ctx.close()
 
 
+def test_python_reward_terms_on_the_trajectory_view():
+    """f3: a user-written term in ksim's Reward protocol runs on the stored trajectory (torch, GPU) and is added before GAE. The view's
+    semantics are checked by restating two built-in terms in Python against the kernel's own components."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    from kbot_joystick_amd.host.traj_view import TrajectoryView
+
+    class Alive:                                                     # stateless (train.py:161-165 protocol)
+        scale = 0.25
+        def get_reward(self, traj):
+            return (traj.done == 0).float()
+
+    class StepsSinceDone:                                            # stateful (train.py:135-154 protocol): carry = steps since the last done
+        scale = 0.01
+        def initial_carry(self, n, device):
+            return torch.zeros(n, device=device)
+        def get_reward_stateful(self, traj, carry):
+            out = torch.empty(traj.T, traj.N, device=carry.device)
+            for t in range(traj.T):
+                carry = torch.where(traj.done[t] != 0, torch.zeros_like(carry), carry + 1)
+                out[t] = carry
+            return out, carry
+
+    cfg = _small(log_reward_components=True)
+    plain = HumanoidWalkingTask(cfg)
+    task = HumanoidWalkingTask(cfg, extra_rewards={"alive": Alive(), "since_done": StepsSinceDone()})
+    plain.rollout(); task.rollout()
+    torch.cuda.synchronize()
+    view = TrajectoryView(task.traj, task.T)
+    want = plain.traj.reward + 0.25 * (view.done == 0).float()
+    carry, extra = torch.zeros(task.N, device="cuda"), torch.zeros_like(want)
+    for t in range(task.T):
+        carry = torch.where(view.done[t] != 0, torch.zeros_like(carry), carry + 1); extra[t] = carry
+    assert torch.allclose(task.traj.reward, want + 0.01 * extra, atol=1e-6)
+    assert set(task.extra_reward_means) == {"alive", "since_done"}
+    # the view against the kernel: angvel (train.py:301-306) and torque (train.py:503-506) restated in torch
+    k = task.kcfg
+    comps = task.traj.comps
+    angvel = torch.exp(-(view.base_qvel[..., 5] - view.command[..., 2]).abs() / k.rew_angvel_err)
+    assert torch.allclose(angvel, comps[..., constants.REWARD_NAMES.index("angvel")], atol=1e-5)
+    zc = view.command[..., :3].norm(dim=-1) < 1e-3
+    torque = torch.where(zc, torch.exp(-view.ctrl.abs() / k.rew_torque_err).mean(-1), torch.ones_like(view.base_z))
+    assert torch.allclose(torque, comps[..., constants.REWARD_NAMES.index("torque")], atol=1e-5)
+    task.update()                                                    # GAE and the update run on the augmented reward
+    torch.cuda.synchronize()
+    assert torch.isfinite(task.params).all()
+    plain.ctx.close(); task.ctx.close()
+
+
 def test_validation_is_deterministic_and_leaves_training_untouched():
     import torch
     from kbot_joystick_amd.host.task import HumanoidWalkingTask
