@@ -11,7 +11,6 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
-python3 $R/bench.py --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
 rocprofv3 --kernel-trace --stats -d $O/stats -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1 || exit 1
 python3 $R/tools/rocprof_summary.py $O/stats/run_results.db > $O/kernel_stats.md || exit 1
 python3 $R/tools/pmc_sq.py $O/pmc_bench --set hbm --set mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_bench.txt 2>&1 || exit 1
@@ -23,4 +22,7 @@ rm -rf $O/stats $O/pmc_bench $O/pmc_env
 python3 $R/tools/bench_env.py 8192 > $O/bench_env.txt 2>&1
 python3 $R/tools/env_stamps.py > $O/env_stamps.txt 2>&1
 python3 $R/tools/bench_ppo.py > $O/bench_ppo.txt 2>&1
+# the bench line last, with this run's traffic profile in place (bench.py reports traffic only from a profile of the same sources)
+cp $O/pmc_traffic.json $R/profiles/pmc_traffic.json
+python3 $R/bench.py --steps 10 --warmup 3 > $O/bench_n1.json 2> $O/bench_n1.err || exit 1
 echo done
