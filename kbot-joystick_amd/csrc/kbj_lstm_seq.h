@@ -59,6 +59,7 @@ struct SeqBwdArgs {
   int T, B;
   float* db;             // optional [4H]: bias gradient accumulated with atomics (column sums of dG)
   unsigned spin_limit = SEQ_SPIN_LIMIT;
+  long long* stamps = nullptr;   // optional [T][10] shader-clock stamps of workgroup 0 (diagnostics)
 };
 
 // gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each; shared with the rollout cell kernel)
@@ -300,7 +301,11 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   constexpr int NUG = H / UNITS;
   // one gate chunk of dG_{t+1} at a time: a single 33 KB buffer (plus pbuf) keeps the workgroup at 42 KB of LDS so that two
   // recurrences (actor + critic) AND two GEMM workgroups fit on a CU together (profiles/r01: double buffering starved the GEMMs)
+#ifdef KBJ_SEQ_BWD_DEEP
+  __shared__ __attribute__((aligned(16))) float ds[2 * SEQ_ROWS * LDH];
+#else
   __shared__ __attribute__((aligned(16))) float ds[SEQ_ROWS * LDH];
+#endif
   __shared__ float pbuf[4][SEQ_ROWS][UNITS + 1];                     // per-wave partial sums of dh
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, uh = tid >> 8;   // wave: k quarter, uh: 16-unit half
@@ -311,6 +316,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
+  if (a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x] = wall_clock64();   // per-workgroup entry / loop start / exit
   constexpr int KW = H / 4;        // k range of one wave inside a gate chunk
   constexpr int KS = KW / 4;       // k-steps per (wave, gate chunk)
   // B operands: for gate chunk c and k-step s: B[k][col] = Whh[c H + wave KW + 4 s + (lane>>4)][u0 + col]
@@ -342,8 +348,12 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
     }
   };
   fetch_inputs(T - 1);
+  if (a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 1] = wall_clock64();
+#define SEQ_BSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 10 + (k)] = clock64(); } while (0)
   for (int t = T - 1; t >= 0; --t) {
     const bool last = t == T - 1;
+    SEQ_BSTAMP(0);
+    if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 10 + 9] = wall_clock64();   // constant-rate counter: gives the shader clock the stamps tick at
     float dhm[2] = {0.0f, 0.0f};
     float act[2][4], tc[2], cprev[2], dha[2], kp[2];
     auto prefetch = [&]() {
@@ -354,8 +364,30 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
     if (last) prefetch();
     else {
       if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)(T - 1 - t), a.err, &flag, a.spin_limit)) return;
+      SEQ_BSTAMP(1);
       f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
       const float* src = a.dG + (size_t)(t + 1) * B * 4 * H;
+#ifdef KBJ_SEQ_BWD_DEEP
+      SeqTile<H, NTH> tile[2];
+      tile[0].load(src, 4 * H, r0, B);
+      tile[1].load(src + H, 4 * H, r0, B);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float* buf = ds + (c & 1) * (SEQ_ROWS * LDH);
+        tile[c & 1].to_lds(buf, r0, B);
+        if (c < 2) tile[c & 1].load(src + (c + 2) * H, 4 * H, r0, B);
+        else if (c == 3) prefetch();
+        __syncthreads();
+        SEQ_BSTAMP(2 + c);
+        const float* a0p = buf + (lane & 15) * LDH + wave * KW + (lane >> 4);
+        const float* a1p = a0p + 16 * LDH;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * s], wreg[c][s], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * s], wreg[c][s], acc1, 0, 0, 0);
+        }
+      }
+#else
       SeqTile<H, NTH> tile;
       tile.load(src, 4 * H, r0, B);
 #pragma unroll
@@ -367,6 +399,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
         else prefetch();   // own inputs of the next step: issued behind the LAST payload wait (vector-memory operations retire in order, so
                            // anything issued between a chunk's loads and its wait is waited for too); they land during the cell and the hand-off
         __syncthreads();
+        SEQ_BSTAMP(2 + c);
         const float* a0p = buf + (lane & 15) * LDH + wave * KW + (lane >> 4);
         const float* a1p = a0p + 16 * LDH;
 #pragma unroll
@@ -375,12 +408,14 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * s], wreg[c][s], acc1, 0, 0, 0);
         }
       }
+#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pbuf[wave][(lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc0[r];
         pbuf[wave][16 + (lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc1[r];
       }
       __syncthreads();
+      SEQ_BSTAMP(6);
 #pragma unroll
       for (int i = 0; i < 2; ++i) dhm[i] = pbuf[0][erow[i]][eunit[i]] + pbuf[1][erow[i]][eunit[i]] + pbuf[2][erow[i]][eunit[i]] + pbuf[3][erow[i]][eunit[i]];
     }
@@ -400,7 +435,9 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       bsum[i][0] += d0; bsum[i][1] += d1; bsum[i][2] += d2; bsum[i][3] += d3;
       dcm[i] = dc * fg;
     }
+    SEQ_BSTAMP(7);
     seq_publish(a.counters + rg * NUG + ug, (unsigned)(T - t));
+    SEQ_BSTAMP(8);
   }
   // bias gradient = column sums of dG over all rows and steps: reduce this workgroup's 32 rows in LDS, one atomic per column
   if (a.db) {
@@ -418,6 +455,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       atomicAdd(a.db + k * H + u0 + u, s);
     }
   }
+  if (a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 2] = wall_clock64();
 }
 
 }  // namespace kbj

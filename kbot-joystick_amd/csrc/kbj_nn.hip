@@ -47,6 +47,7 @@ struct NnWs {
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
   long long* seq_stamps = nullptr;   // diagnostics (KBJ_SEQ_STAMPS=1): per-step clock stamps of one workgroup
+  long long* seq_bstamps = nullptr;  // same for a backward recurrence (KBJ_SEQ_BSTAMPS = 1 + net + 2 * layer)
   std::vector<void*> allocs;
 };
 
@@ -183,8 +184,7 @@ template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
   hipLaunchKernelGGL((lstm_seq_bwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
-int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {
-  hipMemsetAsync(a.counters, 0, 256 * sizeof(unsigned), st);
+int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {   // a.counters: zeroed by the caller
   KbjKernelTimer timer(st, a.X ? KBJ_KIND_SEQ_FWD_FUSED : KBJ_KIND_SEQ_FWD, (a.X ? 2.0 : 1.0) * 2.0 * a.T * a.B * 4.0 * H * H);
   switch (H * 10 + g_seq_uw) {
     case 641: seq_fwd_launch<64, 1>(st, a); break;
@@ -197,8 +197,7 @@ int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {
   }
   return 0;
 }
-int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {
-  hipMemsetAsync(a.counters, 0, 256 * sizeof(unsigned), st);
+int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {   // a.counters: zeroed by the caller
   KbjKernelTimer timer(st, KBJ_KIND_SEQ_BWD, 2.0 * a.T * a.B * 4.0 * H * H);
   switch (H * 10 + g_seq_uw) {
     case 641: seq_bwd_launch<64, 1>(st, a); break;
@@ -224,6 +223,30 @@ int kbj_nn_check_errors(kbj_ctx* ctx) {
       for (int t = 1; t < w->T - 1; ++t) { for (int k = 0; k < 5; ++k) d[k] += (double)(st[t * 6 + k + 1] - st[t * 6 + k]); d[5] += (double)(st[(t + 1) * 6] - st[t * 6 + 5]); }
       fprintf(stderr, "[kbj seq_fwd stamps, cycles/step] prefetch+wait %.0f stage %.0f mfma %.0f cell %.0f publish %.0f bulk-store %.0f\n",
               d[0] / (w->T - 2), d[1] / (w->T - 2), d[2] / (w->T - 2), d[3] / (w->T - 2), d[4] / (w->T - 2), d[5] / (w->T - 2));
+    }
+  }
+  if (w->seq_bstamps) {
+    std::vector<long long> st((size_t)w->T * 10 + 768);
+    if (hipMemcpy(st.data(), w->seq_bstamps, st.size() * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess && w->T > 3) {
+      double d[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      int cnt = 0;
+      for (int t = w->T - 3; t >= 1; --t, ++cnt) { for (int k = 0; k < 8; ++k) d[k] += (double)(st[t * 10 + k + 1] - st[t * 10 + k]); d[8] += (double)(st[(t - 1) * 10] - st[t * 10 + 8]); }
+      fprintf(stderr, "[kbj seq_bwd stamps, cycles/step] wait %.0f chunk0-staged %.0f chunk1 %.0f chunk2 %.0f chunk3 %.0f last-mfma+reduce %.0f cell %.0f publish %.0f loop %.0f\n",
+              d[0] / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt, d[4] / cnt, d[5] / cnt, d[6] / cnt, d[7] / cnt, d[8] / cnt);
+      double ticks = (double)(st[1 * 10] - st[(w->T - 3) * 10]), wall = (double)(st[1 * 10 + 9] - st[(w->T - 3) * 10 + 9]);
+      int wall_khz = 0;
+      hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device);
+      if (wall_khz > 0) {   // per-workgroup entry / loop start / exit on the constant-rate clock
+        const long long* g = st.data() + (size_t)w->T * 10;
+        int nwg = ((w->B + SEQ_ROWS - 1) / SEQ_ROWS) * (w->H / (SEQ_UNITS * g_seq_uw));
+        if (nwg > 256) nwg = 256;
+        long long e0 = g[0], e1 = g[0], l1 = g[1], x0 = g[2], x1 = g[2];
+        for (int i = 1; i < nwg; ++i) { e0 = std::min(e0, g[3 * i]); e1 = std::max(e1, g[3 * i]); l1 = std::max(l1, g[3 * i + 1]); x0 = std::min(x0, g[3 * i + 2]); x1 = std::max(x1, g[3 * i + 2]); }
+        const double us = 1e3 / wall_khz;
+        fprintf(stderr, "[kbj seq_bwd stamps] %d workgroups: last entry +%.1f us, last loop start +%.1f us, first exit +%.1f us, last exit +%.1f us (from the first entry)\n", nwg,
+                (e1 - e0) * us, (l1 - e0) * us, (x0 - e0) * us, (x1 - e0) * us);
+      }
+      if (wall > 0 && wall_khz > 0) fprintf(stderr, "[kbj seq_bwd stamps] %.2f us/step, stamp counter at %.0f MHz\n", wall / wall_khz * 1e3 / cnt, ticks / wall * wall_khz * 1e-3);
     }
   }
   unsigned e[2] = {0, 0};
@@ -296,9 +319,10 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->Weff, 4 * H * KBJ_LD_ACTOR) || dalloc(ctx, *w, &w->beff, 4 * H)) return -1;
   for (int n = 0; n < w->nnets; ++n) if (dalloc(ctx, *w, &w->Zeff[n], 4 * H * w->net[n & 1].ld_obs)) return -1;
   if (hipMemset(w->Weff, 0, 4 * H * KBJ_LD_ACTOR * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset Weff");
-  if (dalloc(ctx, *w, &w->seq_counters, 1024)) return -1;
+  if (dalloc(ctx, *w, &w->seq_counters, 4 * 4 * 256)) return -1;   // [phase: fwd l0, fwd l1, bwd l0, bwd l1][net][row group x unit group]
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
   if (getenv("KBJ_SEQ_STAMPS")) { if (dalloc(ctx, *w, &w->seq_stamps, (size_t)T * 6)) return -1; }
+  if (getenv("KBJ_SEQ_BSTAMPS")) { if (dalloc(ctx, *w, &w->seq_bstamps, (size_t)T * 10 + 768)) return -1; }
   if (hipMemset(w->seq_err, 0, 4 * sizeof(unsigned)) != hipSuccess) return kbj_fail(ctx, "hipMemset seq_err");
   g_splitk_wgs = getenv("KBJ_SPLITK_WGS") ? atoi(getenv("KBJ_SPLITK_WGS")) : 768;
   g_seq_uw = getenv("KBJ_SEQ_UW") ? atoi(getenv("KBJ_SEQ_UW")) : 2;
@@ -561,6 +585,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // ---- gather the minibatch: the large critic observation block on the critic's stream, everything else on the caller's ----
   static const bool one_stream = getenv("KBJ_ONE_STREAM") != nullptr;   // diagnostics: serialise the two nets
   hipStream_t ns[2] = {ctx->stream, one_stream ? ctx->stream : ctx->stream2};
+  // hand-off counters of all eight (sixteen with the mirror branches) recurrence launches of this call: one clear, ahead of both lanes
+  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, 4 * 4 * 256 * sizeof(unsigned), s));
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   auto gather = [&](hipStream_t st, const float* src, int wdt, int lds, float* dst, int ldd) {
@@ -591,15 +617,16 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), s));
   hipLaunchKernelGGL(adv_stats_kernel, dim3(32), dim3(256), 0, s, w.adv, R, w.stats);
   KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), s));
-  // the critic's lane needs keep / carries (gathered above on the caller's stream) before its first recurrence
+  // the critic's lane needs keep / carries (gathered above on the caller's stream) before its first recurrence - not before its input
+  // projection, which only reads its own gather: the wait sits in front of the recurrences below
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream));
-  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));
   if (w.mirror)   // mirrored observation rows: actor's on the caller's stream, critic's behind its gather
     for (int k = 0; k < 2; ++k)
       hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)R * w.net[k].ld_obs), dim3(256), 0, ns[k], w.tb[k].obs, w.tb[2 + k].obs, (size_t)R, w.net[k].ld_obs, w.mtab[k]);
   // ---- forward through time: actor on the caller's stream, critic on the context's second stream (the recurrences are
   // latency bound, so the two nets overlap) ----
   static const bool fold_actor = getenv("KBJ_FOLD_ACTOR") ? atoi(getenv("KBJ_FOLD_ACTOR")) != 0 : true;
+  static const int bstamp_sel = getenv("KBJ_SEQ_BSTAMPS") ? atoi(getenv("KBJ_SEQ_BSTAMPS")) : 0;
   static const int stamp_sel = getenv("KBJ_SEQ_STAMPS") ? atoi(getenv("KBJ_SEQ_STAMPS")) : 1;   // diagnostics: 1 + net + 2 * layer picks the stamped forward launch
   const int stamp_net = (stamp_sel - 1) & 1, stamp_layer = ((stamp_sel - 1) >> 1) & 1;
   static const bool fold_critic = getenv("KBJ_FOLD_CRITIC") ? atoi(getenv("KBJ_FOLD_CRITIC")) != 0 : false;   // backward only (475 > H inputs)
@@ -617,7 +644,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     hipLaunchKernelGGL(matvec_kernel, dim3((4 * H + 3) / 4), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
     // each accumulator is cleared on the lane whose side stream later accumulates into it (actor-type nets: the caller's stream,
     // critic-type nets with KBJ_FOLD_CRITIC: the second stream), so the clear is always ordered before the split-K atomics
-    for (int n = 0; n < w.nnets; ++n) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), ns[n & 1]));
+    for (int n = 0; n < w.nnets; ++n)
+      if ((n & 1) == 0 || fold_critic) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), ns[n & 1]));
   }
   // Launch order is layer-major over the nets (nets 2, 3 = mirror branches, same weights, queued behind nets 0, 1 on the same two
   // streams). KBJ_ALIGN=1 makes the two lanes wait for each other before every recurrence phase, so that recurrences only ever
@@ -634,6 +662,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     if (!(fold_actor && (n & 1) == 0))   // actor-type nets: layer-0 gates come straight from the observations
       linear_fwd(ns[n & 1], w.tb[n].obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, w.tb[n].X0, H, R, H, o.nin, 0);
   }
+  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));   // keep / carries gathered on the caller's stream
   for (int l = 0; l < 2; ++l) {
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
@@ -645,7 +674,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
-      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * n, w.seq_err, T, B, (n == stamp_net && l == stamp_layer) ? w.seq_stamps : nullptr};
+      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * (4 * l + n), w.seq_err, T, B, (n == stamp_net && l == stamp_layer) ? w.seq_stamps : nullptr};
       if (fuse_ih && !(fold_actor && (n & 1) == 0 && l == 0)) {   // K = H input projections ride inside the recurrence (kbj_lstm_seq.h FUSE)
         fa.X = l == 0 ? t.X0 : t.Hout[0]; fa.Wih = params_d + o.w_ih[l]; fa.bias = params_d + o.b[l];
       }
@@ -656,37 +685,42 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     const NetOff& o = w.net[n & 1];
     linear_fwd(ns[n & 1], w.tb[n].Hout[1], H, params_d + o.w_out, H, params_d + o.b_out, w.tb[n].Out, 40, R, o.nout, H, 0);
   }
-  KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  // heads: everything that needs one net only runs on that net's lane (the actor's head chain hides behind the critic's last recurrence);
+  // the lanes meet for the loss kernels alone and part again right behind them
   HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
   hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.tb[0].obs, w.joint_bias_d, hp, R, w.y, w.sd);
   hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0, hp, T, B, w.y);
   hipLaunchKernelGGL(gaussian_logp_kernel, g1(R), dim3(256), 0, s, w.y, w.sd, w.act, R, w.logp, w.ent);
-  hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, s, w.tb[1].Out, 40, R, w.value);
+  hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, ns[1], w.tb[1].Out, 40, R, w.value);
+  if (w.mirror) {
+    hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[2].Out, w.tb[2].obs, w.joint_bias_d, hp, R, w.y_m, w.sd_m);
+    hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0_m, hp, T, B, w.y_m);
+    hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, ns[1], w.tb[3].Out, 40, R, w.value_m);
+  }
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   // ---- loss ----
   PpoParams pp{c.clip_param, c.value_clip, c.value_loss_coef, c.entropy_coef, c.log_ratio_clip, c.adv_eps};
   hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, s, w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
                      w.stats + 2);
-  if (w.mirror) {   // aux losses between each net and its mirror branch (train.py:1463-1481)
-    hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[2].Out, w.tb[2].obs, w.joint_bias_d, hp, R, w.y_m, w.sd_m);
-    hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0_m, hp, T, B, w.y_m);
-    hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, s, w.tb[3].Out, 40, R, w.value_m);
+  if (w.mirror)   // aux losses between each net and its mirror branch (train.py:1463-1481)
     hipLaunchKernelGGL(mirror_loss_kernel, g1(R), dim3(256), 0, s, w.y, w.y_m, w.value, w.value_m, c.actor_mirror_loss_scale, c.critic_mirror_loss_scale, R, w.dy, w.dy_m,
                        w.dvalue, w.dvalue_m, w.stats + 2);
-  }
-  hipLaunchKernelGGL(ppo_metrics_kernel, dim3(1), dim3(1), 0, s, w.stats + 2, w.stats, pp, R, metrics_d);
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  // the metrics line is nobody's input: off the critical lanes (the side lane joins the caller's stream at the end of the call)
+  if (!one_stream) { hipEventRecord(ctx->ev_side[0], s); hipStreamWaitEvent(ctx->side[0], ctx->ev_side[0], 0); }
+  hipLaunchKernelGGL(ppo_metrics_kernel, dim3(1), dim3(1), 0, one_stream ? s : ctx->side[0], w.stats + 2, w.stats, pp, R, metrics_d);
   // ---- backward ---- (dOut needs no clearing: the actor head writes all 40 columns, the critic's GEMMs read column 0 only)
   hipLaunchKernelGGL(actor_head_bwd_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.y, w.sd, w.act, w.dlogp,
                      w.mirror ? w.dy : (const float*)nullptr, -c.entropy_coef / (float)R, hp, R, w.tb[0].dOut);
   hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, hp, T, B, w.tb[0].dOut);
-  KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[1].dOut, 40 * sizeof(float), w.dvalue, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, s));
+  KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[1].dOut, 40 * sizeof(float), w.dvalue, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, ns[1]));
   if (w.mirror) {   // the mirror actor only sees the aux gradient on its filtered mean (no log-prob, no entropy term)
     hipLaunchKernelGGL(actor_head_bwd_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[2].Out, w.y_m, w.sd_m, w.y_m, w.zeroR, w.dy_m, 0.0f, hp, R, w.tb[2].dOut);
     hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, hp, T, B, w.tb[2].dOut);
-    KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[3].dOut, 40 * sizeof(float), w.dvalue_m, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, s));
+    KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[3].dOut, 40 * sizeof(float), w.dvalue_m, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, ns[1]));
   }
-  KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   // The critical path of a net is dOut -> dH -> (recurrence, dX) per layer. Weight/bias gradients hang off it: they go to the
   // net's side stream so the throughput-bound split-K GEMMs run beside the dX GEMMs in the GEMM phases.
   auto side_of = [&](int n) { return one_stream ? ns[n & 1] : ctx->side[n & 1]; };
@@ -706,7 +740,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
-      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + 256 * n, w.seq_err, T, B, grad_d + o.b[l]};
+      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + 256 * (4 * (2 + l) + n), w.seq_err, T, B, grad_d + o.b[l]};
+      if (w.seq_bstamps && bstamp_sel == 1 + n + 2 * l) ba.stamps = w.seq_bstamps;
       if (seq_bwd(ctx, ns[n & 1], H, ba)) return -1;
     }
     for (int n = 0; n < w.nnets; ++n) {
