@@ -44,6 +44,8 @@ struct SeqFwdArgs {
   const float* X = nullptr;     // [T][B][H] layer input
   const float* Wih = nullptr;   // [4H][H]
   const float* bias = nullptr;  // [4H]
+  int ldx = 0, ldw = 0;         // row strides of X and Wih (0: H)
+  int kx = 0;                   // valid input columns (0: all KX); columns beyond are taken as zero whatever the buffers hold
 };
 
 struct SeqBwdArgs {
@@ -97,7 +99,9 @@ __device__ __forceinline__ void seq_publish(unsigned* my_flag, unsigned steps_do
 // payload tile: rows [r0, r0+32) x H floats of a handed-off [B][ld] array, 16-byte buffer loads with the sc1 bit
 // (aux = 16: bypass this CU's L1; counted by the compiler's s_waitcnt), then written to LDS as [32][H+4]
 template <int H, int NTH> struct SeqTile {
-  static constexpr int NV = SEQ_ROWS * (H / 4) / NTH;
+  static constexpr int NQ = SEQ_ROWS * (H / 4);          // 16-byte elements of the tile
+  static constexpr int NV = (NQ + NTH - 1) / NTH;
+  static constexpr bool EXACT = NQ % NTH == 0;
   f32x4m v[NV];
   __device__ __forceinline__ void load(const float* src, int ld, int r0, int B) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -114,7 +118,9 @@ template <int H, int NTH> struct SeqTile {
   __device__ __forceinline__ void load_plain(const float* src, int ld, int r0, int B) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
+      int q = threadIdx.x + NTH * i;
+      if (!EXACT && q >= NQ) q = 0;
+      int row = q / (H / 4), c4 = q % (H / 4), r = r0 + row;
       v[i] = *reinterpret_cast<const f32x4m*>(src + (size_t)(r < B ? r : 0) * ld + 4 * c4);
     }
   }
@@ -122,7 +128,20 @@ template <int H, int NTH> struct SeqTile {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4);
+      if (!EXACT && q >= NQ) continue;
       *reinterpret_cast<f32x4m*>(lds + row * (H + 4) + 4 * c4) = r0 + row < B ? v[i] : f32x4m{0, 0, 0, 0};
+    }
+  }
+  // the same with columns >= ncol forced to zero (padded input rows whose padding is not ours to trust)
+  __device__ __forceinline__ void to_lds_cols(float* lds, int ldl, int r0, int B, int ncol) const {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4);
+      if (!EXACT && q >= NQ) continue;
+      f32x4m x = v[i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (r0 + row >= B || 4 * c4 + j >= ncol) x[j] = 0.0f;
+      *reinterpret_cast<f32x4m*>(lds + row * ldl + 4 * c4) = x;
     }
   }
 };
@@ -133,17 +152,20 @@ template <int H, int NTH> struct SeqTile {
 // FUSE: the layer's input projection x_t W_ih^T + b (no dependence on the recurrence) is computed inside the step instead of by a
 // GEMM launch in front of it: its MFMAs are split in two halves placed before the flag poll and behind the issue of the h-tile loads,
 // where the matrix pipe otherwise idles through the hand-off latency; W_ih's slice sits in a second set of 64 B-operand registers.
-template <int H, int UW, bool FUSE = false>
+// KX: width of the fused input (H for a hidden layer; the padded observation row when the actor's layer-0 gates come straight from the
+// observations through the folded weight W_ih0 W_in - 17 k-steps instead of a GEMM launch and a 210 MB round trip of G)
+template <int H, int UW, bool FUSE = false, int KX = H>
 __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW;
-  constexpr int LDH = H + 4;
+  constexpr int LDH = H + 4, KXS = KX / 4;
+  constexpr int LDX = KX % 64 == 4 ? KX : KX + 4;   // row stride = 4 mod 64 words: the 16 rows of an A fragment land in 16 different bank groups
   constexpr int NUG = H / UNITS;
 #ifndef KBJ_SEQ_XSPLIT_NUM
 #define KBJ_SEQ_XSPLIT_NUM 4   // eighths of the input projection's k-steps issued before the flag poll (the rest hides the tile fetch)
 #endif
-  constexpr int XSPLIT = (H / 4) * KBJ_SEQ_XSPLIT_NUM / 8;
+  constexpr int XSPLIT = KXS * KBJ_SEQ_XSPLIT_NUM / 8;
   __shared__ __attribute__((aligned(16))) float hs[SEQ_ROWS * LDH];
-  __shared__ __attribute__((aligned(16))) float xs[FUSE ? SEQ_ROWS * LDH : 4];
+  __shared__ __attribute__((aligned(16))) float xs[FUSE ? SEQ_ROWS * LDX : 4];
   __shared__ float gbuf[4][SEQ_ROWS][UNITS + 1];
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, gate = (tid >> 6) & 3, uh = tid >> 8;
@@ -161,13 +183,14 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
 #pragma unroll
     for (int s = 0; s < H / 4; ++s) wreg[s] = wrow[4 * s];
   }
-  float wxreg[FUSE ? H / 4 : 1];
+  float wxreg[FUSE ? KXS : 1];
   float bias_col = 0.0f;
+  const int ldx = a.ldx ? a.ldx : H, kxv = a.kx ? a.kx : KX;
   if (FUSE) {
     const int grow = gate * H + u0 + SEQ_UNITS * uh + (lane & 15);
-    const float* wrow = a.Wih + (size_t)grow * H + (lane >> 4);
+    const float* wrow = a.Wih + (size_t)grow * (a.ldw ? a.ldw : H) + (lane >> 4);
 #pragma unroll
-    for (int s = 0; s < H / 4; ++s) wxreg[s] = wrow[4 * s];
+    for (int s = 0; s < KXS; ++s) wxreg[s] = 4 * s + (lane >> 4) < kxv ? wrow[4 * s] : 0.0f;
     bias_col = a.bias[grow];
   }
   // the two (row, unit) elements of this thread in the cell epilogue and their cell state
@@ -199,12 +222,12 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   fetch_inputs(0);
   const float* a0p = hs + (lane & 15) * LDH + (lane >> 4);
   const float* a1p = a0p + 16 * LDH;
-  const float* x0p = xs + (lane & 15) * LDH + (lane >> 4);
-  const float* x1p = x0p + 16 * LDH;
+  const float* x0p = xs + (lane & 15) * LDX + (lane >> 4);
+  const float* x1p = x0p + 16 * LDX;
   if (FUSE) {   // x_0 tile
-    SeqTile<H, NTH> xt;
-    xt.load_plain(a.X, H, r0, B);
-    xt.to_lds(xs, r0, B);
+    SeqTile<KX, NTH> xt;
+    xt.load_plain(a.X, ldx, r0, B);
+    if (KX == H) xt.to_lds(xs, r0, B); else xt.to_lds_cols(xs, LDX, r0, B, kxv);
     __syncthreads();
   }
   for (int t = 0; t < T; ++t) {
@@ -228,7 +251,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
                   // tile's LDS stores - and the vmcnt wait in front of them - above these MFMAs)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = XSPLIT; s < H / 4; ++s) {
+      for (int s = XSPLIT; s < KXS; ++s) {
         acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
       }
@@ -250,8 +273,8 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
         a.Cm[o1 + (size_t)B * H] = cm[i];
       }
     }
-    SeqTile<H, NTH> xt;
-    if (FUSE && t + 1 < T) xt.load_plain(a.X + (size_t)(t + 1) * B * H, H, r0, B);   // next step's input tile rides behind the recurrent MFMAs
+    SeqTile<KX, NTH> xt;
+    if (FUSE && t + 1 < T) xt.load_plain(a.X + (size_t)(t + 1) * B * ldx, ldx, r0, B);   // next step's input tile rides behind the recurrent MFMAs
     __syncthreads();
     SEQ_STAMP(2);
 #pragma unroll
@@ -264,7 +287,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
       gbuf[gate][(lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc0[r];
       gbuf[gate][16 + (lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc1[r];
     }
-    if (FUSE && t + 1 < T) xt.to_lds(xs, r0, B);   // every wave is past its reads of xs (they precede this step's barrier above)
+    if (FUSE && t + 1 < T) { if (KX == H) xt.to_lds(xs, r0, B); else xt.to_lds_cols(xs, LDX, r0, B, kxv); }   // every wave is past its reads of xs (they precede this step's barrier above)
     __syncthreads();
     SEQ_STAMP(3);
 #pragma unroll

@@ -175,7 +175,8 @@ template <int H, int UW> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a0
   a.spin_limit = g_seq_spin_limit;
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
   if (g_seq_drop > 0 && grid > 1) { --g_seq_drop; --grid; }
-  if (a.X) hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, true>), dim3(grid), dim3(256 * UW), 0, s, a);   // input projection fused
+  if (a.X && a.ldx == KBJ_LD_ACTOR) hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, true, KBJ_LD_ACTOR>), dim3(grid), dim3(256 * UW), 0, s, a);   // gates from the observation rows
+  else if (a.X) hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, true>), dim3(grid), dim3(256 * UW), 0, s, a);   // input projection fused
   else hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, false>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
 template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0) {
@@ -185,7 +186,7 @@ template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0
   hipLaunchKernelGGL((lstm_seq_bwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
 int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {   // a.counters: zeroed by the caller
-  KbjKernelTimer timer(st, a.X ? KBJ_KIND_SEQ_FWD_FUSED : KBJ_KIND_SEQ_FWD, (a.X ? 2.0 : 1.0) * 2.0 * a.T * a.B * 4.0 * H * H);
+  KbjKernelTimer timer(st, a.X ? (a.ldx == KBJ_LD_ACTOR ? KBJ_KIND_SEQ_FWD_OBS : KBJ_KIND_SEQ_FWD_FUSED) : KBJ_KIND_SEQ_FWD, 2.0 * a.T * a.B * 4.0 * H * (H + (a.X ? (a.kx ? a.kx : H) : 0)));
   switch (H * 10 + g_seq_uw) {
     case 641: seq_fwd_launch<64, 1>(st, a); break;
     case 642: seq_fwd_launch<64, 2>(st, a); break;
@@ -634,6 +635,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // the h-tile fetch where the matrix pipe idles (kbj_lstm_seq.h FUSE): a fused launch takes 1.11 instead of 0.88 ms, the 0.41-0.48 ms
   // GEMM in front of it and its 210 MB round trip of G disappear: ppo_grad 7.72 -> 7.47 ms. KBJ_SEQ_FUSE=0: separate GEMMs.
   static const bool fuse_ih = getenv("KBJ_SEQ_FUSE") ? atoi(getenv("KBJ_SEQ_FUSE")) != 0 : true;
+  // the folded actor layer 0 the same way (observation row x Weff inside the recurrence, 17 k-steps): KBJ_SEQ_FUSE_OBS=0 keeps the GEMM
+  static const bool fuse_obs = fuse_ih && w.net[0].ld_obs == KBJ_LD_ACTOR && (getenv("KBJ_SEQ_FUSE_OBS") ? atoi(getenv("KBJ_SEQ_FUSE_OBS")) != 0 : true);
   if (fold_actor) {
     // The actor's input projection (65 -> H, no activation) feeds only layer 0's input GEMM, so gates_0 = obs (W_ih0 W_in)^T +
     // (W_ih0 b_in + b_0): a 65-deep contraction instead of 65 -> H -> 4H (6.8 instead of 28.5 GFLOP per minibatch forward, and
@@ -667,7 +670,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
-      if (fold_actor && (n & 1) == 0 && l == 0) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, KBJ_LD_ACTOR, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0);
+      if (fold_actor && (n & 1) == 0 && l == 0) { if (!fuse_obs) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, KBJ_LD_ACTOR, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0); }
       else if (!fuse_ih) linear_fwd(ns[n & 1], l == 0 ? t.X0 : t.Hout[0], H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
     }
     align();
@@ -675,7 +678,9 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
       SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * (4 * l + n), w.seq_err, T, B, (n == stamp_net && l == stamp_layer) ? w.seq_stamps : nullptr};
-      if (fuse_ih && !(fold_actor && (n & 1) == 0 && l == 0)) {   // K = H input projections ride inside the recurrence (kbj_lstm_seq.h FUSE)
+      if (fold_actor && (n & 1) == 0 && l == 0) {
+        if (fuse_obs) { fa.X = t.obs; fa.ldx = o.ld_obs; fa.Wih = w.Weff; fa.ldw = KBJ_LD_ACTOR; fa.bias = w.beff; fa.kx = o.nin; }   // gates_0 = obs Weff^T + beff inside the recurrence
+      } else if (fuse_ih) {   // K = H input projections ride inside the recurrence (kbj_lstm_seq.h FUSE)
         fa.X = l == 0 ? t.X0 : t.Hout[0]; fa.Wih = params_d + o.w_ih[l]; fa.bias = params_d + o.b[l];
       }
       if (seq_fwd(ctx, ns[n & 1], H, fa)) return -1;
@@ -685,31 +690,34 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     const NetOff& o = w.net[n & 1];
     linear_fwd(ns[n & 1], w.tb[n].Hout[1], H, params_d + o.w_out, H, params_d + o.b_out, w.tb[n].Out, 40, R, o.nout, H, 0);
   }
-  // heads: everything that needs one net only runs on that net's lane (the actor's head chain hides behind the critic's last recurrence);
-  // the lanes meet for the loss kernels alone and part again right behind them
+  // heads and losses: the policy terms need the actor only, the value terms the critic only (the mirror terms likewise), so each lane
+  // computes its own and the two chains stay independent through the whole call: the shorter actor chain runs ahead, and its
+  // recurrences meet the critic's GEMM phases instead of the critic's recurrences
   HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
+  PpoParams pp{c.clip_param, c.value_clip, c.value_loss_coef, c.entropy_coef, c.log_ratio_clip, c.adv_eps};
   hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.tb[0].obs, w.joint_bias_d, hp, R, w.y, w.sd);
   hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0, hp, T, B, w.y);
   hipLaunchKernelGGL(gaussian_logp_kernel, g1(R), dim3(256), 0, s, w.y, w.sd, w.act, R, w.logp, w.ent);
+  hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, s, w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
+                     w.stats + 2, one_stream ? 0 : 1);
   hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, ns[1], w.tb[1].Out, 40, R, w.value);
-  if (w.mirror) {
+  hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, ns[1], w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
+                     w.stats + 2, one_stream ? 3 : 2);
+  if (w.mirror) {   // aux losses between each net and its mirror branch (train.py:1463-1481)
     hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[2].Out, w.tb[2].obs, w.joint_bias_d, hp, R, w.y_m, w.sd_m);
     hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0_m, hp, T, B, w.y_m);
-    hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, ns[1], w.tb[3].Out, 40, R, w.value_m);
-  }
-  KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-  // ---- loss ----
-  PpoParams pp{c.clip_param, c.value_clip, c.value_loss_coef, c.entropy_coef, c.log_ratio_clip, c.adv_eps};
-  hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, s, w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
-                     w.stats + 2);
-  if (w.mirror)   // aux losses between each net and its mirror branch (train.py:1463-1481)
     hipLaunchKernelGGL(mirror_loss_kernel, g1(R), dim3(256), 0, s, w.y, w.y_m, w.value, w.value_m, c.actor_mirror_loss_scale, c.critic_mirror_loss_scale, R, w.dy, w.dy_m,
-                       w.dvalue, w.dvalue_m, w.stats + 2);
-  KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
-  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  // the metrics line is nobody's input: off the critical lanes (the side lane joins the caller's stream at the end of the call)
-  if (!one_stream) { hipEventRecord(ctx->ev_side[0], s); hipStreamWaitEvent(ctx->side[0], ctx->ev_side[0], 0); }
+                       w.dvalue, w.dvalue_m, w.stats + 2, one_stream ? 0 : 1);
+    hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, ns[1], w.tb[3].Out, 40, R, w.value_m);
+    hipLaunchKernelGGL(mirror_loss_kernel, g1(R), dim3(256), 0, ns[1], w.y, w.y_m, w.value, w.value_m, c.actor_mirror_loss_scale, c.critic_mirror_loss_scale, R, w.dy, w.dy_m,
+                       w.dvalue, w.dvalue_m, w.stats + 2, one_stream ? 3 : 2);
+  }
+  // the metrics line is nobody's input: a side lane computes it once both halves of the loss are in (it joins the caller's stream at the end)
+  if (!one_stream) {
+    hipEvent_t ea = ctx->ev_pool[ctx->ev_next++ & 31], eb = ctx->ev_pool[ctx->ev_next++ & 31];
+    hipEventRecord(ea, ns[0]); hipEventRecord(eb, ns[1]);
+    hipStreamWaitEvent(ctx->side[0], ea, 0); hipStreamWaitEvent(ctx->side[0], eb, 0);
+  }
   hipLaunchKernelGGL(ppo_metrics_kernel, dim3(1), dim3(1), 0, one_stream ? s : ctx->side[0], w.stats + 2, w.stats, pp, R, metrics_d);
   // ---- backward ---- (dOut needs no clearing: the actor head writes all 40 columns, the critic's GEMMs read column 0 only)
   hipLaunchKernelGGL(actor_head_bwd_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.y, w.sd, w.act, w.dlogp,

@@ -230,11 +230,14 @@ struct PpoParams { float clip, vclip, vcoef, ecoef, lrclip, adv_eps; };
 __global__ void ppo_loss_kernel(const float* __restrict__ logp, const float* __restrict__ value, const float* __restrict__ ent,
                                 const float* __restrict__ logp_old, const float* __restrict__ value_old, const float* __restrict__ adv,
                                 const float* __restrict__ target, const double* __restrict__ stats, PpoParams pp, int R,
-                                float* __restrict__ dlogp, float* __restrict__ dvalue, double* __restrict__ macc) {
+                                float* __restrict__ dlogp, float* __restrict__ dvalue, double* __restrict__ macc, int part) {
+  // part: 1 = policy terms (surrogate, entropy, clip fraction, KL: inputs logp / ent / adv), 2 = value terms (inputs value / target), 3 = both.
+  // The two halves share no data, so each runs on its own net's lane and the actor and critic chains never wait for each other.
   __shared__ double red[6][256];
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   double m[6] = {0, 0, 0, 0, 0, 0};
-  if (r < R) {
+  const float inv = 1.0f / R;
+  if (r < R && (part & 1)) {
     float mean = (float)(stats[0] / R);
     float var = fmaxf((float)(stats[1] / R) - mean * mean, 0.0f);
     float a = (adv[r] - mean) / (sqrtf(var) + pp.adv_eps);
@@ -245,19 +248,21 @@ __global__ void ppo_loss_kernel(const float* __restrict__ logp, const float* __r
     float s1 = ratio * a, s2 = rc * a;
     bool unclipped = s1 <= s2;
     float surr = unclipped ? s1 : s2;
-    float inv = 1.0f / R;
     dlogp[r] = (unclipped && fabsf(d) < pp.lrclip) ? -inv * a * ratio : 0.0f;
+    m[0] = -surr; m[2] = ent[r]; m[3] = fabsf(ratio - 1) > pp.clip ? 1.0 : 0.0; m[4] = -d;
+  }
+  if (r < R && (part & 2)) {
     float v = value[r], vo = value_old[r], tg = target[r];
     float dv = v - vo, dvc = fminf(fmaxf(dv, -pp.vclip), pp.vclip), vcl = vo + dvc;
     float e1 = (v - tg) * (v - tg), e2 = (vcl - tg) * (vcl - tg);
     float gv = e1 >= e2 ? (v - tg) : ((fabsf(dv) < pp.vclip) ? (vcl - tg) : 0.0f);
     dvalue[r] = pp.vcoef * inv * gv;
-    m[0] = -surr; m[1] = 0.5f * fmaxf(e1, e2); m[2] = ent[r]; m[3] = fabsf(ratio - 1) > pp.clip ? 1.0 : 0.0; m[4] = -d; m[5] = 0;
+    m[1] = 0.5f * fmaxf(e1, e2);
   }
   for (int k = 0; k < 6; ++k) red[k][threadIdx.x] = m[k];
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) for (int k = 0; k < 5; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0) for (int k = 0; k < 5; ++k) atomicAdd(&macc[k], red[k][0]);
+  if (threadIdx.x == 0) for (int k = 0; k < 5; ++k) if (k == 1 ? (part & 2) : (part & 1)) atomicAdd(&macc[k], red[k][0]);
 }
 // metrics[10] = loss, policy, value, entropy, clipfrac, kl, adv_mean, adv_std, action_mirror_loss, value_mirror_loss
 __global__ void ppo_metrics_kernel(const double* __restrict__ macc, const double* __restrict__ stats, PpoParams pp, int R, float* __restrict__ metrics) {
@@ -296,23 +301,25 @@ __global__ void actor_head_lpf_kernel(const float* __restrict__ out, const float
 // value terms to dvalue / writes dvalue_m. macc[5], macc[6] accumulate the two loss sums.
 __global__ void mirror_loss_kernel(const float* __restrict__ y, const float* __restrict__ ym, const float* __restrict__ v, const float* __restrict__ vm,
                                    float sa, float sc, int R, float* __restrict__ dy, float* __restrict__ dym, float* __restrict__ dvalue,
-                                   float* __restrict__ dvalue_m, double* __restrict__ macc) {
+                                   float* __restrict__ dvalue_m, double* __restrict__ macc, int part) {   // part: 1 = actor term, 2 = critic term (as ppo_loss_kernel)
   int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   float ca = sa / (20.0f * R), la = 0;
-  for (int i = 0; i < KBJ_NU; ++i) {
+  if (part & 1) for (int i = 0; i < KBJ_NU; ++i) {
     int s = i < 5 ? i + 5 : (i < 10 ? i - 5 : i);
     float e = y[(size_t)r * KBJ_NU + i] + ym[(size_t)r * KBJ_NU + s];     // y_i - (-y_m[s(i)])
     la += e * e;
     dy[(size_t)r * KBJ_NU + i] = 2 * ca * e;
     dym[(size_t)r * KBJ_NU + s] = 2 * ca * e;
   }
-  float ev = v[r] - vm[r];
-  float gv = 2 * sc / R * ev;
-  dvalue[r] += gv;
-  dvalue_m[r] = -gv;
-  atomicAdd(&macc[5], (double)(sa * la / 20.0f));
-  atomicAdd(&macc[6], (double)(sc * ev * ev));
+  if (part & 1) atomicAdd(&macc[5], (double)(sa * la / 20.0f));
+  if (part & 2) {
+    float ev = v[r] - vm[r];
+    float gv = 2 * sc / R * ev;
+    dvalue[r] += gv;
+    dvalue_m[r] = -gv;
+    atomicAdd(&macc[6], (double)(sc * ev * ev));
+  }
 }
 
 // actor head backward: per (b, j) thread, reverse scan through the low-pass recursion.
