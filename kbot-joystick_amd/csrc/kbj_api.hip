@@ -163,7 +163,7 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
       "kbj::gemm_f32_kernel<2, 1, false, false, 2, 4>", "kbj::gemm_f32_kernel<2, 1, false, true, 2, 4>", "kbj::gemm_f32_kernel<2, 1, true, false, 2, 4>",
       "kbj::gemm_f32_kernel<2, 1, true, true, 2, 4>",   "kbj::gemm_f32_kernel<1, 1, false, false, 2, 2>", "kbj::gemm_f32_kernel<1, 1, false, true, 2, 2>",
       "kbj::gemm_f32_kernel<1, 1, true, false, 2, 2>",  "kbj::gemm_f32_kernel<1, 1, true, true, 2, 2>",   "kbj::lstm_seq_fwd_kernel", "kbj::lstm_seq_bwd_kernel", "env_step_kernel", "kbj::lstm_seq_fwd_kernel",
-      "kbj::lstm_seq_fwd_kernel"};
+      "kbj::lstm_seq_fwd_kernel", "kbj::lstm_step_kernel", "kbj::lstm_step_kernel"};
   for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
     kbj_kernel_stat& st = ctx->kstats[k];
     const int uw = getenv("KBJ_SEQ_UW") ? atoi(getenv("KBJ_SEQ_UW")) : 2;
@@ -171,6 +171,8 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
     else if (k == KBJ_KIND_SEQ_FWD || k == KBJ_KIND_SEQ_FWD_FUSED || k == KBJ_KIND_SEQ_FWD_OBS)   // as rocprofv3 prints the template arguments
       snprintf(st.name, sizeof(st.name), "%s<%d, %d, %s, %d>", names[k], ctx->cfg_h.hidden_size, uw, k == KBJ_KIND_SEQ_FWD ? "false" : "true",
                k == KBJ_KIND_SEQ_FWD_OBS ? KBJ_LD_ACTOR : ctx->cfg_h.hidden_size);
+    else if (k == KBJ_KIND_LSTM_STEP || k == KBJ_KIND_LSTM_STEP_OBS)
+      snprintf(st.name, sizeof(st.name), "%s<%d, 2, %d>", names[k], ctx->cfg_h.hidden_size, k == KBJ_KIND_LSTM_STEP_OBS ? KBJ_LD_ACTOR : ctx->cfg_h.hidden_size);
     else snprintf(st.name, sizeof(st.name), "%s", names[k]);
     st.launches = 0; st.total_ms = 0; st.flops = 0;
   }

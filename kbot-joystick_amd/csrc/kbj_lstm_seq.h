@@ -481,4 +481,98 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   if (a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 2] = wall_clock64();
 }
 
+// ---- one LSTM layer step for MANY independent rows (rollout: 8192 envs, no recurrence inside the launch) ------------------------------
+// Same register-resident weight slices and fused cell as the forward recurrence above, but the loop runs over row groups instead of
+// time: workgroup (chunk, ug) keeps the 128 gate columns of its 32 hidden units as MFMA B operands (W_ih and W_hh slices, 128 VGPRs)
+// and walks the row groups chunk, chunk + nchunk, ...: stage the x and h tiles of 32 rows through LDS, 2 x (KX + H) / 4 MFMAs per
+// wavefront, exchange the four gates through LDS, apply the cell, store h and c. One launch replaces the [x | h] GEMM, its 33 MB gate
+// round trip and the cell kernel of a rollout layer; the weights are read once per workgroup instead of once per output tile.
+// Hout must not alias Hin (the other unit groups of a row group still read the full h rows); C is updated in place.
+struct StepArgs {
+  const float* X; int ldx, kx;   // layer input [M][ldx]; columns >= kx count as zero (kx = 0: all KX)
+  const float* Wih; int ldw;     // [4H][ldw]
+  const float* Whh;              // [4H][H]
+  const float* bias;             // [4H]
+  const float* Hin;              // [M][H]
+  float* Hout;                   // [M][H]
+  float* C;                      // [M][H], in place
+  int M;
+};
+template <int H, int UW, int KX = H>
+__global__ __launch_bounds__(256 * UW) void lstm_step_kernel(StepArgs a) {
+  constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW;
+  constexpr int LDH = H + 4, KXS = KX / 4, NUG = H / UNITS;
+  constexpr int LDX = KX % 64 == 4 ? KX : KX + 4;
+  __shared__ __attribute__((aligned(16))) float hs[SEQ_ROWS * LDH];
+  __shared__ __attribute__((aligned(16))) float xs[SEQ_ROWS * LDX];
+  __shared__ float gbuf[4][SEQ_ROWS][UNITS + 1];
+  const int tid = threadIdx.x, lane = tid & 63, gate = (tid >> 6) & 3, uh = tid >> 8;
+  const int ug = blockIdx.x % NUG, chunk = blockIdx.x / NUG, nchunk = gridDim.x / NUG;
+  const int u0 = ug * UNITS, M = a.M, nrg = (M + SEQ_ROWS - 1) / SEQ_ROWS;
+  const int kxv = a.kx ? a.kx : KX;
+  const int grow = gate * H + u0 + SEQ_UNITS * uh + (lane & 15);
+  float wreg[H / 4], wxreg[KXS];
+  {
+    const float* wrow = a.Whh + (size_t)grow * H + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < H / 4; ++s) wreg[s] = wrow[4 * s];
+    const float* xrow = a.Wih + (size_t)grow * a.ldw + (lane >> 4);
+#pragma unroll
+    for (int s = 0; s < KXS; ++s) wxreg[s] = 4 * s + (lane >> 4) < kxv ? xrow[4 * s] : 0.0f;
+  }
+  const float bias_col = a.bias[grow];
+  int erow[2], eunit[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { int e = tid + NTH * i; erow[i] = e / UNITS; eunit[i] = e % UNITS; }
+  const float* a0p = hs + (lane & 15) * LDH + (lane >> 4);
+  const float* a1p = a0p + 16 * LDH;
+  const float* x0p = xs + (lane & 15) * LDX + (lane >> 4);
+  const float* x1p = x0p + 16 * LDX;
+  SeqTile<KX, NTH> xt;
+  SeqTile<H, NTH> ht;
+  float cn[2] = {0.0f, 0.0f};
+  auto fetch = [&](int rg) {   // tiles and cell state of row group rg into registers (they land behind the previous group's MFMAs)
+    const int r0 = rg * SEQ_ROWS;
+    xt.load_plain(a.X, a.ldx, r0, M);
+    ht.load_plain(a.Hin, H, r0, M);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { int r = r0 + erow[i]; cn[i] = r < M ? a.C[(size_t)r * H + u0 + eunit[i]] : 0.0f; }
+  };
+  int rg = chunk;
+  if (rg < nrg) fetch(rg);
+  for (; rg < nrg; rg += nchunk) {
+    const int r0 = rg * SEQ_ROWS;
+    if (KX == H) xt.to_lds(xs, r0, M); else xt.to_lds_cols(xs, LDX, r0, M, kxv);
+    ht.to_lds(hs, r0, M);
+    const float cp[2] = {cn[0], cn[1]};
+    __syncthreads();
+    if (rg + nchunk < nrg) fetch(rg + nchunk);
+    f32x4m acc0 = {bias_col, bias_col, bias_col, bias_col}, acc1 = acc0;
+#pragma unroll
+    for (int s = 0; s < KXS; ++s) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int s = 0; s < H / 4; ++s) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * s], wreg[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * s], wreg[s], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      gbuf[gate][(lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc0[r];
+      gbuf[gate][16 + (lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc1[r];
+    }
+    __syncthreads();   // every wavefront is past its fragment reads of xs / hs: the next group's tiles may overwrite them
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = erow[i], u = eunit[i], r = r0 + row;
+      float ig = seq_sigmoid(gbuf[0][row][u]), fg = seq_sigmoid(gbuf[1][row][u]), gg = seq_tanh(gbuf[2][row][u]), og = seq_sigmoid(gbuf[3][row][u]);
+      float c = fg * cp[i] + ig * gg;
+      if (r < M) { a.Hout[(size_t)r * H + u0 + u] = og * seq_tanh(c); a.C[(size_t)r * H + u0 + u] = c; }
+    }
+    // gbuf is rewritten only behind the next group's first barrier, which every wavefront reaches after these reads
+  }
+}
+
 }  // namespace kbj

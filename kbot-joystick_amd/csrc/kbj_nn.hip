@@ -35,6 +35,7 @@ struct NnWs {
   int nnets = 2;
   MirrorEntry* mtab[2] = {nullptr, nullptr};
   float *rObsM[2] = {nullptr, nullptr};   // rollout: mirrored observation rows [N][ld]
+  float* rH[4][2] = {};                    // rollout: the h planes' ping-pong partners [N][H] per (net, layer)
   float *y_m = nullptr, *sd_m = nullptr, *value_m = nullptr, *lpf0_m = nullptr, *dy = nullptr, *dy_m = nullptr, *dvalue_m = nullptr, *zeroR = nullptr;
   // training
   TrainBufs tb[4];
@@ -212,6 +213,25 @@ int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {   // a.c
   return 0;
 }
 
+// one LSTM layer step over many rows (kbj_lstm_seq.h lstm_step_kernel): grid = unit groups x row chunks, about one workgroup per CU
+int lstm_step(kbj_ctx* ctx, hipStream_t st, int H, const StepArgs& a) {
+  const bool obs = a.ldx == KBJ_LD_ACTOR && a.ldw == KBJ_LD_ACTOR;
+  KbjKernelTimer timer(st, obs ? KBJ_KIND_LSTM_STEP_OBS : KBJ_KIND_LSTM_STEP, 2.0 * a.M * 4.0 * H * (H + (a.kx ? a.kx : H)));
+  const int nug = H / (SEQ_UNITS * 2), nrg = (a.M + SEQ_ROWS - 1) / SEQ_ROWS;
+  const int nch = std::max(1, std::min(nrg, 256 / nug));
+  dim3 grid(nug * nch), block(512);
+  switch (H * 2 + (obs ? 1 : 0)) {
+    case 128: hipLaunchKernelGGL((lstm_step_kernel<64, 2>), grid, block, 0, st, a); break;
+    case 129: hipLaunchKernelGGL((lstm_step_kernel<64, 2, KBJ_LD_ACTOR>), grid, block, 0, st, a); break;
+    case 256: hipLaunchKernelGGL((lstm_step_kernel<128, 2>), grid, block, 0, st, a); break;
+    case 257: hipLaunchKernelGGL((lstm_step_kernel<128, 2, KBJ_LD_ACTOR>), grid, block, 0, st, a); break;
+    case 512: hipLaunchKernelGGL((lstm_step_kernel<256, 2>), grid, block, 0, st, a); break;
+    case 513: hipLaunchKernelGGL((lstm_step_kernel<256, 2, KBJ_LD_ACTOR>), grid, block, 0, st, a); break;
+    default: return kbj_fail(ctx, "LSTM step kernels are built for hidden_size 64, 128, 256");
+  }
+  return 0;
+}
+
 }  // namespace
 
 int kbj_nn_check_errors(kbj_ctx* ctx) {
@@ -274,6 +294,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
     if (dalloc(ctx, *w, &w->rX[n], N * H)) return -1;
     if (dalloc(ctx, *w, &w->rG[n], N * 4 * H)) return -1;
     if (dalloc(ctx, *w, &w->rOut[n], N * 40)) return -1;
+    if (dalloc(ctx, *w, &w->rH[n][0], N * H) || dalloc(ctx, *w, &w->rH[n][1], N * H)) return -1;
   }
   if (dalloc(ctx, *w, &w->joint_bias_d, KBJ_NU)) return -1;
   if (hipMemcpy(w->joint_bias_d, ctx->model_h.joint_bias, KBJ_NU * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return kbj_fail(ctx, "hipMemcpy joint_bias");
@@ -379,11 +400,38 @@ namespace {
 
 // One control step of the nets [net_lo, net_hi) (0 actor, 1 critic, 2/3 their mirror branches) for the env rows [n0, n0 + cnt) on
 // stream s. All pointers are those of env row 0.
-void policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, int net_hi, int n0, int cnt, const float* actor_obs_d, const float* critic_obs_d,
-                 kbj_carry* carry, uint32_t seed, uint32_t step_index, int argmax, float* action_d, float* logp_d, float* value_d) {
+// Rollout-time layer steps run in lstm_step_kernel (fused [x | h] product + cell). Its output h cannot alias its input, so every h
+// plane of the carry has a ping-pong partner in the workspace: a call with parity 0 reads the caller's planes and writes the partners,
+// parity 1 the other way round. kbj_rollout alternates per control step; the caller's arrays hold the state again when it returns.
+// KBJ_ROLLOUT_STEP=0 (diagnostics): the previous form, one GEMM over [x | h] plus a cell kernel per layer, in place.
+bool rollout_step_kernel() {
+  static const bool on = getenv("KBJ_ROLLOUT_STEP") ? atoi(getenv("KBJ_ROLLOUT_STEP")) != 0 : true;
+  return on;
+}
+float* h_plane(NnWs& w, float* hc, int n, int l, int n0, bool partner) {
+  return (partner ? w.rH[n][l] : hc + (size_t)(2 * l) * w.N * w.H) + (size_t)n0 * w.H;
+}
+
+// The actor's input projection (65 -> H, no activation) feeds only layer 0's input product, so gates_0 = obs (W_ih0 W_in)^T +
+// (W_ih0 b_in + b_0), as in kbj_ppo_grad: prepares w.Weff / w.beff for these parameters and returns w.Weff (null: not folded)
+const float* fold_actor_weights(kbj_ctx* ctx, hipStream_t s, const float* params_d) {
+  NnWs& w = *ws_of(ctx);
+  const int H = w.H;
+  if (!rollout_step_kernel() || w.net[0].ld_obs != KBJ_LD_ACTOR || (getenv("KBJ_FOLD_ACTOR") && atoi(getenv("KBJ_FOLD_ACTOR")) == 0)) return nullptr;
+  const NetOff& oa = w.net[0];
+  GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, KBJ_LD_ACTOR, 0, 1, nullptr};
+  gemm_launch<true, false>(s, g);
+  hipLaunchKernelGGL(matvec_kernel, dim3((4 * H + 3) / 4), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
+  return w.Weff;
+}
+
+// weff: the folded actor input weights (W_ih0 W_in, bias in w.beff) when the caller has prepared them for these parameters, else null
+int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, int net_hi, int n0, int cnt, const float* actor_obs_d, const float* critic_obs_d,
+                kbj_carry* carry, uint32_t seed, uint32_t step_index, int argmax, float* action_d, float* logp_d, float* value_d, int parity, const float* weff) {
   NnWs& w = *ws_of(ctx);
   const kbj_config& c = ctx->cfg_h;
   const int N = w.N, H = w.H;
+  const bool fused = rollout_step_kernel();
   const float* obs_base[2] = {actor_obs_d, critic_obs_d};
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
@@ -400,11 +448,21 @@ void policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo,
       hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)cnt * o.ld_obs), dim3(256), 0, s, obs, obs_m, (size_t)cnt, o.ld_obs, w.mtab[k]);
       obs = obs_m;
     }
-    linear_fwd(s, obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, X, H, cnt, H, o.nin, 0);
+    const bool folded = fused && weff && k == 0 && o.ld_obs == KBJ_LD_ACTOR;   // actor-type net: layer-0 gates straight from the observation row
+    if (!folded) linear_fwd(s, obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, X, H, cnt, H, o.nin, 0);
     const float* x = X;
     for (int l = 0; l < 2; ++l) {
-      float* h = hc[n] + (size_t)(2 * l) * N * H + (size_t)n0 * H;
       float* cc = hc[n] + (size_t)(2 * l + 1) * N * H + (size_t)n0 * H;
+      if (fused) {
+        const float* h_in = h_plane(w, hc[n], n, l, n0, parity != 0);
+        float* h_out = h_plane(w, hc[n], n, l, n0, parity == 0);
+        StepArgs sa{x, H, 0, params_d + o.w_ih[l], H, params_d + o.w_hh[l], params_d + o.b[l], h_in, h_out, cc, cnt};
+        if (l == 0 && folded) { sa.X = obs; sa.ldx = o.ld_obs; sa.kx = o.nin; sa.Wih = weff; sa.ldw = KBJ_LD_ACTOR; sa.bias = w.beff; }
+        if (lstm_step(ctx, s, H, sa)) return -1;
+        x = h_out;
+        continue;
+      }
+      float* h = hc[n] + (size_t)(2 * l) * N * H + (size_t)n0 * H;
       {  // gates = [x | h] [W_ih | W_hh]^T + b as ONE launch over the concatenated contraction (no read-modify-write of G)
         GemmArgs g{x, params_d + o.w_ih[l], G, params_d + o.b[l], cnt, 4 * H, 2 * H, H, H, 4 * H, 0, 1, nullptr};
         g.A2 = h; g.B2 = params_d + o.w_hh[l]; g.k1 = H;
@@ -425,17 +483,34 @@ void policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo,
     else
       hipLaunchKernelGGL(actor_head_lpf_kernel, g1((size_t)cnt * KBJ_NU), dim3(256), 0, s, Out, obs, carry->lpf_mirror_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, c.lpf_alpha, cnt);
   }
+  return 0;
 }
 
-// carry <- 0 where done, for the nets [net_lo, net_hi) and env rows [n0, n0 + cnt)
-void carry_reset_nets(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, int n0, int cnt, kbj_carry* carry, const float* done_d, int done_stride) {
+// carry <- 0 where done, for the nets [net_lo, net_hi) and env rows [n0, n0 + cnt); parity as policy_nets: which copy of the h planes is live
+void carry_reset_nets(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, int n0, int cnt, kbj_carry* carry, const float* done_d, int done_stride, int parity) {
   NnWs& w = *ws_of(ctx);
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   float* lpf[4] = {carry->lpf_d, nullptr, carry->lpf_mirror_d, nullptr};
+  const bool partner = parity != 0 && rollout_step_kernel();
   size_t n = (size_t)4 * cnt * w.H;
+  for (int k = net_lo; k < net_hi; ++k) {
+    CarryPlanes cp;
+    for (int l = 0; l < 2; ++l) {
+      cp.p[2 * l] = h_plane(w, hc[k], k, l, n0, partner);
+      cp.p[2 * l + 1] = hc[k] + (size_t)(2 * l + 1) * w.N * w.H + (size_t)n0 * w.H;
+    }
+    hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, s, cp, cnt, w.H, lpf[k] ? lpf[k] + (size_t)n0 * KBJ_NU : nullptr, done_d + (size_t)n0 * done_stride, done_stride);
+  }
+}
+
+// the h planes of nets [net_lo, net_hi) back from their ping-pong partners into the caller's arrays
+int carry_h_home(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, kbj_carry* carry) {
+  NnWs& w = *ws_of(ctx);
+  float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   for (int k = net_lo; k < net_hi; ++k)
-    hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, s, hc[k] + (size_t)n0 * w.H, 4, (size_t)w.N * w.H, cnt, w.H, lpf[k] ? lpf[k] + (size_t)n0 * KBJ_NU : nullptr,
-                       done_d + (size_t)n0 * done_stride, done_stride);
+    for (int l = 0; l < 2; ++l)
+      KBJ_HIP(ctx, hipMemcpyAsync(hc[k] + (size_t)(2 * l) * w.N * w.H, w.rH[k][l], (size_t)w.N * w.H * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return 0;
 }
 
 }  // namespace
@@ -472,7 +547,9 @@ int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_
   KbjTimed timed(ctx, true);
   if (w.mirror && (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d))
     return kbj_fail(ctx, "kbj_policy_step: the mirror losses are enabled, the carry needs the mirror-branch arrays");
-  policy_nets(ctx, ctx->stream, params_d, 0, w.nnets, 0, w.N, actor_obs_d, critic_obs_d, carry, seed, step_index, argmax, action_d, logp_d, value_d);
+  if (policy_nets(ctx, ctx->stream, params_d, 0, w.nnets, 0, w.N, actor_obs_d, critic_obs_d, carry, seed, step_index, argmax, action_d, logp_d, value_d, 0,
+                  fold_actor_weights(ctx, ctx->stream, params_d))) return -1;
+  if (rollout_step_kernel() && carry_h_home(ctx, ctx->stream, 0, w.nnets, carry)) return -1;   // the new h sits in the partners: bring it home
   KBJ_CHECK_LAUNCH(ctx, "kbj_policy_step");
   return 0;
 }
@@ -482,7 +559,7 @@ int kbj_carry_reset(kbj_ctx* ctx, kbj_carry* carry, const float* done_d, int don
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
   if (w.mirror && (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d)) return kbj_fail(ctx, "kbj_carry_reset: mirror-branch carry arrays are NULL");
-  carry_reset_nets(ctx, ctx->stream, 0, w.nnets, 0, w.N, carry, done_d, done_stride);
+  carry_reset_nets(ctx, ctx->stream, 0, w.nnets, 0, w.N, carry, done_d, done_stride, 0);
   KBJ_CHECK_LAUNCH(ctx, "carry_reset_kernel");
   return 0;
 }
@@ -523,6 +600,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
   const int lanes = (pipe_mode == 1 && N >= 256 && N % 2 == 0) ? 2 : 1;
   hipStream_t ls[2] = {ctx->stream, ctx->stream2};                      // actor + env of each half
   hipStream_t cs[2] = {serial ? ctx->stream : ctx->side[0], serial ? ctx->stream : ctx->side[1]};   // critic + mirror branches of each half
+  const float* weff = fold_actor_weights(ctx, s, params_d);   // once: the parameters are fixed for the whole rollout
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
   if (lanes == 2) KBJ_HIP(ctx, hipStreamWaitEvent(ls[1], ctx->ev_fork, 0));
   if (!serial) for (int h = 0; h < lanes; ++h) KBJ_HIP(ctx, hipStreamWaitEvent(cs[h], ctx->ev_fork, 0));
@@ -534,17 +612,17 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
     float* act = tr->action_d + (size_t)t * N * KBJ_NU;
     for (int h = 0; h < lanes; ++h) {
       const int n0 = h * cnt;
-      policy_nets(ctx, ls[h], params_d, 0, 1, n0, cnt, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N);
-      policy_nets(ctx, cs[h], params_d, 1, w.nnets, n0, cnt, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N);
+      if (policy_nets(ctx, ls[h], params_d, 0, 1, n0, cnt, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
+      if (policy_nets(ctx, cs[h], params_d, 1, w.nnets, n0, cnt, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
       int rc = kbj_env_step_range(ctx, ls[h], n0, cnt, act, aux_t, tr->actor_obs_d + (size_t)(t + 1) * N * la, tr->critic_obs_d + (size_t)(t + 1) * N * lc,
                                   tr->aux_d + (size_t)(t + 1) * N * lx);
       if (rc) return rc;
-      carry_reset_nets(ctx, ls[h], 0, 1, n0, cnt, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE);
+      carry_reset_nets(ctx, ls[h], 0, 1, n0, cnt, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE, (t + 1) & 1);   // the planes step t + 1 reads
       if (!serial) {   // the side lane needs this step's done flags and the next critic observation
         KBJ_HIP(ctx, hipEventRecord(ctx->ev_side[h], ls[h]));
         KBJ_HIP(ctx, hipStreamWaitEvent(cs[h], ctx->ev_side[h], 0));
       }
-      carry_reset_nets(ctx, cs[h], 1, w.nnets, n0, cnt, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE);
+      carry_reset_nets(ctx, cs[h], 1, w.nnets, n0, cnt, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE, (t + 1) & 1);
     }
   }
   KBJ_CHECK_LAUNCH(ctx, "kbj_rollout");
@@ -558,6 +636,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
       KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     }
   }
+  if (rollout_step_kernel() && (T & 1) && carry_h_home(ctx, s, 0, w.nnets, carry)) return -1;   // an odd number of steps leaves the live h planes in the partners
   return kbj_rewards(ctx, tr->aux_d, T, tr->reward_d, tr->reward_comps_d);
 }
 

@@ -91,14 +91,15 @@ __global__ void critic_value_kernel(const float* __restrict__ out, int ld, int N
   if (n < N) value[n] = out[(size_t)n * ld];
 }
 
-// carry <- carry * (done == 0) (train.py:1502-1506): hc [depth*2][N][H], lpf [N][20]
-__global__ void carry_reset_kernel(float* __restrict__ hc, int planes, size_t plane_stride, int cnt, int H, float* __restrict__ lpf, const float* __restrict__ done,
-                                   int stride) {
+// carry <- carry * (done == 0) (train.py:1502-1506): four [cnt][H] planes (h0, c0, h1, c1 - the h planes may live in the rollout's
+// ping-pong scratch), lpf [cnt][20]
+struct CarryPlanes { float* p[4]; };
+__global__ void carry_reset_kernel(CarryPlanes hc, int cnt, int H, float* __restrict__ lpf, const float* __restrict__ done, int stride) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   int per = cnt * H;
-  if (idx < planes * per) {
+  if (idx < 4 * per) {
     int p = idx / per, r = idx % per;
-    if (done[(size_t)(r / H) * stride] != 0) hc[(size_t)p * plane_stride + r] = 0;
+    if (done[(size_t)(r / H) * stride] != 0) hc.p[p][r] = 0;
   }
   if (lpf && idx < cnt * KBJ_NU) { int n = idx / KBJ_NU; if (done[(size_t)n * stride] != 0) lpf[idx] = 0; }
 }
