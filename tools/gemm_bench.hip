@@ -45,13 +45,21 @@ double run(const char* name, int M, int N, int K, int splitk, int force_big, flo
   return us;
 }
 
-int main() {
+int main(int argc, char** argv) {
+  const int only = argc > 1 ? atoi(argv[1]) : 0;   // 1..4: that shape alone, without the checks (for counter passes)
   size_t big = (size_t)51200 * 1024;
   float *A, *B, *C;
   CK(hipMalloc(&A, big * 4)); CK(hipMalloc(&B, big * 4)); CK(hipMalloc(&C, big * 4));
   std::vector<float> h(big);
   for (size_t i = 0; i < big; ++i) h[i] = (float)((rand() & 0xFFFF) - 32768) / 32768.0f;
   CK(hipMemcpy(A, h.data(), big * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B, h.data() + 777, (big - 777) * 4, hipMemcpyHostToDevice));
+  if (only) {
+    if (only == 1) run<true, true>("fwd ih (R x 4H x H)", 51200, 1024, 256, 1, -1, A, B, C, false);
+    if (only == 2) run<true, false>("dx (R x H x 4H)", 51200, 256, 1024, 1, -1, A, B, C, false);
+    if (only == 3) run<false, false>("dW pair (4H x 2H x R) sk24", 1024, 512, 51200, 24, 1, A, B, C, false);
+    if (only == 4) run<true, true>("square 4096", 4096, 4096, 4096, 1, -1, A, B, C, false);
+    return 0;
+  }
   run<true, true>("check fwd small", 300, 200, 100, 1, -1, A, B, C, true);
   run<true, false>("check dx small", 300, 200, 100, 1, -1, A, B, C, true);
   run<false, false>("check dW small", 200, 136, 3000, 4, -1, A, B, C, true);
