@@ -36,6 +36,7 @@ extern "C" {
 #define KBJ_NOBS_ACTOR   65
 #define KBJ_NOBS_CRITIC  475
 #define KBJ_LD_ACTOR     68
+#define KBJ_MAX_DEPTH    4   /* LSTM layers per net the library's workspaces are laid out for */
 #define KBJ_LD_CRITIC    476
 
 typedef struct kbj_model {
@@ -97,7 +98,7 @@ typedef struct kbj_config {
   int32_t solver_iterations; /* 8 */
   int32_t ls_iterations;     /* 8 */
   int32_t hidden_size;       /* 256 launch / 128 dataclass default */
-  int32_t depth;             /* 2 */
+  int32_t depth;             /* LSTM layers per net, 1..KBJ_MAX_DEPTH (train.py:82-85: 2) */
   int32_t batch_size;        /* envs per minibatch */
   int32_t num_passes;
   int32_t command_mode;      /* 0 = UnifiedCommand sampler (train.py:710-785); 1 = fixed command */

@@ -56,9 +56,9 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   if (!topology_ok(ctx->model_h, why)) { delete ctx; return kbj_fail(nullptr, "kbj_create: " + why); }
   if (cfg->num_envs <= 0 || cfg->substeps <= 0 || cfg->rollout_len <= 0) { delete ctx; return kbj_fail(nullptr, "kbj_create: bad config sizes"); }
   if (cfg->solver_newton != 1) { delete ctx; return kbj_fail(nullptr, "kbj_create: only the Newton solver is implemented on the GPU (solver_newton = 1)"); }
-  if ((cfg->hidden_size != 64 && cfg->hidden_size != 128 && cfg->hidden_size != 256) || cfg->depth != 2) {
+  if ((cfg->hidden_size != 64 && cfg->hidden_size != 128 && cfg->hidden_size != 192 && cfg->hidden_size != 256) || cfg->depth < 1 || cfg->depth > KBJ_MAX_DEPTH) {
     delete ctx;
-    return kbj_fail(nullptr, "kbj_create: the kernels are built for hidden_size 64, 128 or 256 and depth 2 (train.py:78-85 defaults 128 / 2, launch 256)");
+    return kbj_fail(nullptr, "kbj_create: the kernels are built for hidden_size 64, 128, 192 or 256 and depth 1..4 (train.py:78-85 defaults 128 / 2, launch 256 / 2)");
   }
   ctx->device = device;
   ctx->stream = (hipStream_t)hip_stream;

@@ -14,17 +14,19 @@ using namespace kbj;
 
 namespace {
 
+constexpr int MAXD = KBJ_MAX_DEPTH;   // LSTM layers per net (config.depth = 1..MAXD; train.py:82-85 default 2)
+
 struct NetOff {  // float offsets into the flat parameter vector (kbj.h layout = equinox leaf order)
-  size_t w_in, b_in, w_ih[2], w_hh[2], b[2], w_out, b_out;
+  size_t w_in, b_in, w_ih[MAXD], w_hh[MAXD], b[MAXD], w_out, b_out;
   int nin, nout, ld_obs;
 };
 
 struct TrainBufs {  // per net, minibatch-sized
-  float *obs, *X0, *G[2], *Hm[2], *Hout[2], *Cm[2], *TanhC[2], *Out, *dOut, *dHa, *dHb, *dGl[2];
+  float *obs, *X0, *G[MAXD], *Hm[MAXD], *Hout[MAXD], *Cm[MAXD], *TanhC[MAXD], *Out, *dOut, *dHa, *dHb, *dGl[MAXD];
 };
 
 struct NnWs {
-  int H = 0, N = 0, B = 0, T = 0;
+  int H = 0, N = 0, B = 0, T = 0, D = 2;
   NetOff net[2];
   size_t nparams = 0, nactor = 0;
   // rollout scratch
@@ -35,7 +37,7 @@ struct NnWs {
   int nnets = 2;
   MirrorEntry* mtab[2] = {nullptr, nullptr};
   float *rObsM[2] = {nullptr, nullptr};   // rollout: mirrored observation rows [N][ld]
-  float* rH[4][2] = {};                    // rollout: the h planes' ping-pong partners [N][H] per (net, layer)
+  float* rH[4][MAXD] = {};                  // rollout: the h planes' ping-pong partners [N][H] per (net, layer)
   float *y_m = nullptr, *sd_m = nullptr, *value_m = nullptr, *lpf0_m = nullptr, *dy = nullptr, *dy_m = nullptr, *dvalue_m = nullptr, *zeroR = nullptr;
   // training
   TrainBufs tb[4];
@@ -54,7 +56,8 @@ struct NnWs {
 
 NnWs* ws_of(kbj_ctx* ctx) { return reinterpret_cast<NnWs*>(ctx->nn_ws); }
 
-void layout_params(NnWs& w, int H) {
+void layout_params(NnWs& w, int H, int D) {
+  w.D = D;
   size_t off = 0;
   for (int n = 0; n < 2; ++n) {
     NetOff& o = w.net[n];
@@ -63,7 +66,7 @@ void layout_params(NnWs& w, int H) {
     o.nout = n == 0 ? 2 * KBJ_NU : 1;
     o.w_in = off; off += (size_t)H * o.nin;
     o.b_in = off; off += H;
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < D; ++l) {
       o.w_ih[l] = off; off += (size_t)4 * H * H;
       o.w_hh[l] = off; off += (size_t)4 * H * H;
       o.b[l] = off; off += (size_t)4 * H;
@@ -193,9 +196,11 @@ int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {   // a.c
     case 642: seq_fwd_launch<64, 2>(st, a); break;
     case 1281: seq_fwd_launch<128, 1>(st, a); break;
     case 1282: seq_fwd_launch<128, 2>(st, a); break;
+    case 1921: seq_fwd_launch<192, 1>(st, a); break;
+    case 1922: seq_fwd_launch<192, 2>(st, a); break;
     case 2561: seq_fwd_launch<256, 1>(st, a); break;
     case 2562: seq_fwd_launch<256, 2>(st, a); break;
-    default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 256");
+    default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 192, 256");
   }
   return 0;
 }
@@ -206,9 +211,11 @@ int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {   // a.c
     case 642: seq_bwd_launch<64, 2>(st, a); break;
     case 1281: seq_bwd_launch<128, 1>(st, a); break;
     case 1282: seq_bwd_launch<128, 2>(st, a); break;
+    case 1921: seq_bwd_launch<192, 1>(st, a); break;
+    case 1922: seq_bwd_launch<192, 2>(st, a); break;
     case 2561: seq_bwd_launch<256, 1>(st, a); break;
     case 2562: seq_bwd_launch<256, 2>(st, a); break;
-    default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 256");
+    default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 192, 256");
   }
   return 0;
 }
@@ -225,9 +232,11 @@ int lstm_step(kbj_ctx* ctx, hipStream_t st, int H, const StepArgs& a) {
     case 129: hipLaunchKernelGGL((lstm_step_kernel<64, 2, KBJ_LD_ACTOR>), grid, block, 0, st, a); break;
     case 256: hipLaunchKernelGGL((lstm_step_kernel<128, 2>), grid, block, 0, st, a); break;
     case 257: hipLaunchKernelGGL((lstm_step_kernel<128, 2, KBJ_LD_ACTOR>), grid, block, 0, st, a); break;
+    case 384: hipLaunchKernelGGL((lstm_step_kernel<192, 2>), grid, block, 0, st, a); break;
+    case 385: hipLaunchKernelGGL((lstm_step_kernel<192, 2, KBJ_LD_ACTOR>), grid, block, 0, st, a); break;
     case 512: hipLaunchKernelGGL((lstm_step_kernel<256, 2>), grid, block, 0, st, a); break;
     case 513: hipLaunchKernelGGL((lstm_step_kernel<256, 2, KBJ_LD_ACTOR>), grid, block, 0, st, a); break;
-    default: return kbj_fail(ctx, "LSTM step kernels are built for hidden_size 64, 128, 256");
+    default: return kbj_fail(ctx, "LSTM step kernels are built for hidden_size 64, 128, 192, 256");
   }
   return 0;
 }
@@ -286,7 +295,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
   const kbj_config& c = ctx->cfg_h;
   w->H = c.hidden_size; w->N = c.num_envs; w->B = c.batch_size; w->T = c.rollout_len;
   if (w->B <= 0 || w->B > w->N) return kbj_fail(ctx, "kbj_create: batch_size must be in [1, num_envs]");
-  layout_params(*w, w->H);
+  layout_params(*w, w->H, ctx->cfg_h.depth);
   size_t N = w->N, H = w->H, B = w->B, T = w->T;
   w->mirror = c.actor_mirror_loss_scale != 0.0f || c.critic_mirror_loss_scale != 0.0f;
   w->nnets = w->mirror ? 4 : 2;
@@ -294,7 +303,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
     if (dalloc(ctx, *w, &w->rX[n], N * H)) return -1;
     if (dalloc(ctx, *w, &w->rG[n], N * 4 * H)) return -1;
     if (dalloc(ctx, *w, &w->rOut[n], N * 40)) return -1;
-    if (dalloc(ctx, *w, &w->rH[n][0], N * H) || dalloc(ctx, *w, &w->rH[n][1], N * H)) return -1;
+    for (int l = 0; l < w->D; ++l) if (dalloc(ctx, *w, &w->rH[n][l], N * H)) return -1;
   }
   if (dalloc(ctx, *w, &w->joint_bias_d, KBJ_NU)) return -1;
   if (hipMemcpy(w->joint_bias_d, ctx->model_h.joint_bias, KBJ_NU * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) return kbj_fail(ctx, "hipMemcpy joint_bias");
@@ -317,7 +326,8 @@ int kbj_nn_create(kbj_ctx* ctx) {
     TrainBufs& t = w->tb[n];
     if (dalloc(ctx, *w, &t.obs, R * w->net[n & 1].ld_obs)) return -1;
     if (dalloc(ctx, *w, &t.X0, R * H)) return -1;
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < w->D; ++l) {
+      if (dalloc(ctx, *w, &t.dGl[l], R * 4 * H)) return -1;
       if (dalloc(ctx, *w, &t.G[l], R * 4 * H)) return -1;
       if (dalloc(ctx, *w, &t.Hm[l], (T + 1) * B * H)) return -1;
       if (dalloc(ctx, *w, &t.Hout[l], R * H)) return -1;
@@ -328,8 +338,6 @@ int kbj_nn_create(kbj_ctx* ctx) {
     if (dalloc(ctx, *w, &t.dOut, R * 40)) return -1;
     if (dalloc(ctx, *w, &t.dHa, R * H)) return -1;
     if (dalloc(ctx, *w, &t.dHb, R * H)) return -1;
-    if (dalloc(ctx, *w, &t.dGl[0], R * 4 * H)) return -1;
-    if (dalloc(ctx, *w, &t.dGl[1], R * 4 * H)) return -1;
   }
   float** small[] = {&w->keep, &w->logp_old, &w->val_old, &w->adv, &w->target, &w->logp, &w->ent, &w->value, &w->dlogp, &w->dvalue};
   for (float** p : small) if (dalloc(ctx, *w, p, R)) return -1;
@@ -341,7 +349,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->Weff, 4 * H * KBJ_LD_ACTOR) || dalloc(ctx, *w, &w->beff, 4 * H)) return -1;
   for (int n = 0; n < w->nnets; ++n) if (dalloc(ctx, *w, &w->Zeff[n], 4 * H * w->net[n & 1].ld_obs)) return -1;
   if (hipMemset(w->Weff, 0, 4 * H * KBJ_LD_ACTOR * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset Weff");
-  if (dalloc(ctx, *w, &w->seq_counters, 4 * 4 * 256)) return -1;   // [phase: fwd l0, fwd l1, bwd l0, bwd l1][net][row group x unit group]
+  if (dalloc(ctx, *w, &w->seq_counters, 2 * MAXD * 4 * 256)) return -1;   // [phase: forward layer l = l, backward layer l = D + l][net][row group x unit group]
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
   if (getenv("KBJ_SEQ_STAMPS")) { if (dalloc(ctx, *w, &w->seq_stamps, (size_t)T * 6)) return -1; }
   if (getenv("KBJ_SEQ_BSTAMPS")) { if (dalloc(ctx, *w, &w->seq_bstamps, (size_t)T * 10 + 768)) return -1; }
@@ -368,6 +376,8 @@ int kbj_nn_create(kbj_ctx* ctx) {
       case 642: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<64, 2>, threads, 0); break;
       case 1281: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<128, 1>, threads, 0); break;
       case 1282: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<128, 2>, threads, 0); break;
+      case 1921: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<192, 1>, threads, 0); break;
+      case 1922: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<192, 2>, threads, 0); break;
       case 2561: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 1>, threads, 0); break;
       case 2562: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 2>, threads, 0); break;
       default: return kbj_fail(ctx, "kbj_create: hidden_size must be 64, 128 or 256 (persistent LSTM kernels)");
@@ -451,7 +461,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
     const bool folded = fused && weff && k == 0 && o.ld_obs == KBJ_LD_ACTOR;   // actor-type net: layer-0 gates straight from the observation row
     if (!folded) linear_fwd(s, obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, X, H, cnt, H, o.nin, 0);
     const float* x = X;
-    for (int l = 0; l < 2; ++l) {
+    for (int l = 0; l < w.D; ++l) {
       float* cc = hc[n] + (size_t)(2 * l + 1) * N * H + (size_t)n0 * H;
       if (fused) {
         const float* h_in = h_plane(w, hc[n], n, l, n0, parity != 0);
@@ -492,10 +502,11 @@ void carry_reset_nets(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, int n
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   float* lpf[4] = {carry->lpf_d, nullptr, carry->lpf_mirror_d, nullptr};
   const bool partner = parity != 0 && rollout_step_kernel();
-  size_t n = (size_t)4 * cnt * w.H;
+  size_t n = (size_t)2 * w.D * cnt * w.H;
   for (int k = net_lo; k < net_hi; ++k) {
     CarryPlanes cp;
-    for (int l = 0; l < 2; ++l) {
+    cp.n = 2 * w.D;
+    for (int l = 0; l < w.D; ++l) {
       cp.p[2 * l] = h_plane(w, hc[k], k, l, n0, partner);
       cp.p[2 * l + 1] = hc[k] + (size_t)(2 * l + 1) * w.N * w.H + (size_t)n0 * w.H;
     }
@@ -508,7 +519,7 @@ int carry_h_home(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, kbj_carry*
   NnWs& w = *ws_of(ctx);
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   for (int k = net_lo; k < net_hi; ++k)
-    for (int l = 0; l < 2; ++l)
+    for (int l = 0; l < w.D; ++l)
       KBJ_HIP(ctx, hipMemcpyAsync(hc[k] + (size_t)(2 * l) * w.N * w.H, w.rH[k][l], (size_t)w.N * w.H * sizeof(float), hipMemcpyDeviceToDevice, s));
   return 0;
 }
@@ -517,8 +528,8 @@ int carry_h_home(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, kbj_carry*
 
 extern "C" {
 
-size_t kbj_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size); return w.nparams; }
-size_t kbj_actor_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size); return w.nactor; }
+size_t kbj_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size, cfg->depth); return w.nparams; }
+size_t kbj_actor_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size, cfg->depth); return w.nactor; }
 
 int kbj_init_params(kbj_ctx* ctx, uint32_t seed, float* params_d) {
   if (!ctx || !params_d) return kbj_fail(ctx, "kbj_init_params: null argument");
@@ -532,7 +543,7 @@ int kbj_init_params(kbj_ctx* ctx, uint32_t seed, float* params_d) {
   for (int n = 0; n < 2; ++n) {
     const NetOff& o = w.net[n];
     fill(o.w_in, (size_t)H * o.nin, o.nin); fill(o.b_in, H, o.nin);
-    for (int l = 0; l < 2; ++l) { fill(o.w_ih[l], (size_t)4 * H * H, H); fill(o.w_hh[l], (size_t)4 * H * H, H); fill(o.b[l], (size_t)4 * H, H); }
+    for (int l = 0; l < w.D; ++l) { fill(o.w_ih[l], (size_t)4 * H * H, H); fill(o.w_hh[l], (size_t)4 * H * H, H); fill(o.b[l], (size_t)4 * H, H); }
     fill(o.w_out, (size_t)o.nout * H, H); fill(o.b_out, o.nout, H);
   }
   KBJ_CHECK_LAUNCH(ctx, "init_uniform_kernel");
@@ -579,7 +590,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
   KBJ_HIP(ctx, hipMemcpyAsync(tr->actor_obs_d, tr->actor_obs_d + (size_t)T * N * la, N * la * sizeof(float), hipMemcpyDeviceToDevice, s));
   KBJ_HIP(ctx, hipMemcpyAsync(tr->critic_obs_d, tr->critic_obs_d + (size_t)T * N * lc, N * lc * sizeof(float), hipMemcpyDeviceToDevice, s));
   KBJ_HIP(ctx, hipMemcpyAsync(tr->aux_d, tr->aux_d + (size_t)T * N * lx, N * lx * sizeof(float), hipMemcpyDeviceToDevice, s));
-  size_t hcb = (size_t)4 * N * H * sizeof(float);
+  size_t hcb = (size_t)2 * w.D * N * H * sizeof(float);
   KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_actor_hc_d, carry->actor_hc_d, hcb, hipMemcpyDeviceToDevice, s));
   KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_critic_hc_d, carry->critic_hc_d, hcb, hipMemcpyDeviceToDevice, s));
   KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_lpf_d, carry->lpf_d, (size_t)N * KBJ_NU * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -666,7 +677,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   static const bool one_stream = getenv("KBJ_ONE_STREAM") != nullptr;   // diagnostics: serialise the two nets
   hipStream_t ns[2] = {ctx->stream, one_stream ? ctx->stream : ctx->stream2};
   // hand-off counters of all eight (sixteen with the mirror branches) recurrence launches of this call: one clear, ahead of both lanes
-  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, 4 * 4 * 256 * sizeof(unsigned), s));
+  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, 2 * MAXD * 4 * 256 * sizeof(unsigned), s));
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   auto gather = [&](hipStream_t st, const float* src, int wdt, int lds, float* dst, int ldd) {
@@ -685,7 +696,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   GatherCarryArgs gc;
   gc.nplanes = 0;
   for (int n = 0; n < w.nnets; ++n)
-    for (int l = 0; l < 2; ++l) {  // carry at the start of the trajectory: [N][H] planes h, c of every layer
+    for (int l = 0; l < w.D; ++l) {  // carry at the start of the trajectory: [N][H] planes h, c of every layer
       gc.src[gc.nplanes] = carry0[n] + (size_t)(2 * l) * N * H; gc.dst[gc.nplanes++] = w.tb[n].Hm[l];
       gc.src[gc.nplanes] = carry0[n] + (size_t)(2 * l + 1) * N * H; gc.dst[gc.nplanes++] = w.tb[n].Cm[l];
     }
@@ -745,12 +756,13 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       linear_fwd(ns[n & 1], w.tb[n].obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, w.tb[n].X0, H, R, H, o.nin, 0);
   }
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));   // keep / carries gathered on the caller's stream
-  for (int l = 0; l < 2; ++l) {
+  const int D = w.D;
+  for (int l = 0; l < D; ++l) {
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
       if (fold_actor && (n & 1) == 0 && l == 0) { if (!fuse_obs) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, KBJ_LD_ACTOR, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0); }
-      else if (!fuse_ih) linear_fwd(ns[n & 1], l == 0 ? t.X0 : t.Hout[0], H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
+      else if (!fuse_ih) linear_fwd(ns[n & 1], l == 0 ? t.X0 : t.Hout[l - 1], H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
     }
     align();
     for (int n = 0; n < w.nnets; ++n) {
@@ -760,14 +772,14 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       if (fold_actor && (n & 1) == 0 && l == 0) {
         if (fuse_obs) { fa.X = t.obs; fa.ldx = o.ld_obs; fa.Wih = w.Weff; fa.ldw = KBJ_LD_ACTOR; fa.bias = w.beff; fa.kx = o.nin; }   // gates_0 = obs Weff^T + beff inside the recurrence
       } else if (fuse_ih) {   // K = H input projections ride inside the recurrence (kbj_lstm_seq.h FUSE)
-        fa.X = l == 0 ? t.X0 : t.Hout[0]; fa.Wih = params_d + o.w_ih[l]; fa.bias = params_d + o.b[l];
+        fa.X = l == 0 ? t.X0 : t.Hout[l - 1]; fa.Wih = params_d + o.w_ih[l]; fa.bias = params_d + o.b[l];
       }
       if (seq_fwd(ctx, ns[n & 1], H, fa)) return -1;
     }
   }
   for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
-    linear_fwd(ns[n & 1], w.tb[n].Hout[1], H, params_d + o.w_out, H, params_d + o.b_out, w.tb[n].Out, 40, R, o.nout, H, 0);
+    linear_fwd(ns[n & 1], w.tb[n].Hout[D - 1], H, params_d + o.w_out, H, params_d + o.b_out, w.tb[n].Out, 40, R, o.nout, H, 0);
   }
   // heads and losses: the policy terms need the actor only, the value terms the critic only (the mirror terms likewise), so each lane
   // computes its own and the two chains stay independent through the whole call: the shorter actor chain runs ahead, and its
@@ -818,16 +830,16 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     TrainBufs& t = w.tb[n];
     linear_bwd_input(ns[n & 1], t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
     fork_side(n);
-    linear_bwd_weight(side_of(n), t.dOut, 40, t.Hout[1], H, grad_d + o.w_out, H, o.nout, H, R);
+    linear_bwd_weight(side_of(n), t.dOut, 40, t.Hout[D - 1], H, grad_d + o.w_out, H, o.nout, H, R);
     hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 64), dim3(256), 0, side_of(n), t.dOut, R, o.nout, 40, grad_d + o.b_out);
     dh_above[n] = t.dHa; dx_out[n] = t.dHb;
   }
-  for (int l = 1; l >= 0; --l) {
+  for (int l = D - 1; l >= 0; --l) {
     align();
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
-      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + 256 * (4 * (2 + l) + n), w.seq_err, T, B, grad_d + o.b[l]};
+      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + 256 * (4 * (D + l) + n), w.seq_err, T, B, grad_d + o.b[l]};
       if (w.seq_bstamps && bstamp_sel == 1 + n + 2 * l) ba.stamps = w.seq_bstamps;
       if (seq_bwd(ctx, ns[n & 1], H, ba)) return -1;
     }
@@ -842,11 +854,11 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
         // one launch, then two small products carry Z back to the stored parameters: dW_in += W_ih0^T Z, dW_ih0 += Z W_in^T
         // (the bias terms follow from db_0 at the end).
         float* Z = w.Zeff[n];
-        const int ts = H >= 128 ? 128 : 64;
+        const int ts = H % 128 == 0 ? 128 : 64;   // the column split (n1 = H) must fall on a tile boundary
         int sk = std::max(2, std::min(g_splitk_wgs / ((4 * H / ts) * (H / ts + (o.nin + ts - 1) / ts)), (R + 255) / 256));
         GemmArgs g{dG, t.Hm[0], grad_d + o.w_hh[0], nullptr, 4 * H, H + o.nin, R, 4 * H, H, H, 1, sk, nullptr};
         g.B2 = t.obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = o.ld_obs;
-        gemm_launch<false, false>(ws, g, H >= 128 ? 1 : 0);
+        gemm_launch<false, false>(ws, g, ts == 128 ? 1 : 0);
         GemmArgs g1a{params_d + o.w_ih[0], Z, grad_d + o.w_in, nullptr, H, o.nin, 4 * H, H, o.ld_obs, o.nin, 1, 1, nullptr};
         gemm_launch<false, false>(ws, g1a);
         GemmArgs g2a{Z, params_d + o.w_in, grad_d + o.w_ih[0], nullptr, 4 * H, H, o.nin, o.ld_obs, o.nin, H, 1, 1, nullptr};
@@ -854,7 +866,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
         continue;
       }
       linear_bwd_input(s, dG, 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
-      linear_bwd_weight2(ws, dG, 4 * H, t.Hm[l], l == 0 ? t.X0 : t.Hout[0], H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
+      linear_bwd_weight2(ws, dG, 4 * H, t.Hm[l], l == 0 ? t.X0 : t.Hout[l - 1], H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
       std::swap(dh_above[n], dx_out[n]);
     }
   }

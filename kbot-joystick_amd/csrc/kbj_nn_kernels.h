@@ -91,13 +91,13 @@ __global__ void critic_value_kernel(const float* __restrict__ out, int ld, int N
   if (n < N) value[n] = out[(size_t)n * ld];
 }
 
-// carry <- carry * (done == 0) (train.py:1502-1506): four [cnt][H] planes (h0, c0, h1, c1 - the h planes may live in the rollout's
-// ping-pong scratch), lpf [cnt][20]
-struct CarryPlanes { float* p[4]; };
+// carry <- carry * (done == 0) (train.py:1502-1506): 2 x depth [cnt][H] planes (h0, c0, h1, c1, ... - the h planes may live in the
+// rollout's ping-pong scratch), lpf [cnt][20]
+struct CarryPlanes { float* p[2 * KBJ_MAX_DEPTH]; int n; };
 __global__ void carry_reset_kernel(CarryPlanes hc, int cnt, int H, float* __restrict__ lpf, const float* __restrict__ done, int stride) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   int per = cnt * H;
-  if (idx < 4 * per) {
+  if (idx < hc.n * per) {
     int p = idx / per, r = idx % per;
     if (done[(size_t)(r / H) * stride] != 0) hc.p[p][r] = 0;
   }
@@ -154,7 +154,7 @@ __global__ void gather_small_kernel(GatherSmallArgs a, const int* __restrict__ i
   else a.keep_o[r] = a.aux[src * KBJ_AUX_SIZE + KBJ_AUX_DONE] != 0 ? 0.0f : 1.0f;
 }
 // the carries at the start of the trajectory: up to 16 [N][H] planes and 2 [N][20] low-pass states, one launch (blockIdx.y = plane)
-struct GatherCarryArgs { const float* src[18]; float* dst[18]; int nplanes, nlpf; };
+struct GatherCarryArgs { const float* src[8 * KBJ_MAX_DEPTH + 2]; float* dst[8 * KBJ_MAX_DEPTH + 2]; int nplanes, nlpf; };   // 4 nets x depth x (h, c) + 2 low-pass states
 __global__ void gather_carry_kernel(GatherCarryArgs a, const int* __restrict__ idx, int B, int H) {
   int p = blockIdx.y;
   int w = p < a.nplanes ? H : KBJ_NU;

@@ -65,6 +65,27 @@ def test_checkpoint_resume_is_bit_identical(tmp_path, mirror):
         t.ctx.close()
 
 
+@pytest.mark.parametrize("H,D", [(192, 3), (128, 1)])
+def test_task_runs_with_other_depths_and_hidden_sizes(tmp_path, H, D):
+    """The reference's model fields hidden_size / depth (train.py:78-85) through the whole task: iterations run, the checkpoint carries
+    depth x (h, c) planes and the exported actor advertises carry_size = depth * 2 * hidden + 20 (convert.py:71)."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    from kbot_joystick_amd.host import ckpt
+    t = HumanoidWalkingTask(_small(hidden_size=H, depth=D, num_passes=2))
+    for _ in range(2):
+        t.train_iteration()
+    assert bool(torch.isfinite(t.metrics).all()) and bool(torch.isfinite(t.params).all())
+    assert tuple(t.carry.actor_hc.shape) == (D, 2, 64, H) and float(t.carry.actor_hc.abs().sum()) > 0
+    path = str(tmp_path / "ckpt.bin")
+    t.save_checkpoint(path)
+    flat = ckpt.load_ckpt(path, "model", hidden_size=H, depth=D)
+    assert flat.shape[0] == sum(L.param_count(H, D)) and np.array_equal(flat, t.params.cpu().numpy())
+    mv = t.load_ckpt(path, part="model")[0]
+    assert mv.depth == D and len(mv.actor.rnns) == D and mv.carry_size == D * 2 * H + 20
+    t.ctx.close()
+
+
 def test_edited_reward_table_matches_oracle(model):
     """f3: scales / error scales are data (kbj_config), not kernel literals: a user-edited stack gives the oracle's numbers."""
     import torch

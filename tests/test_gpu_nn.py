@@ -70,21 +70,21 @@ def test_policy_step_matches_oracle(H, N):                                      
     ctx.close()
 
 
-def _synthetic_traj(torch, buffers, N, T, H, seed=0, mirror=False):
+def _synthetic_traj(torch, buffers, N, T, H, seed=0, mirror=False, depth=2):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    tr = buffers.TrajBuffers(T, N, H, 2, "cuda:0", mirror=mirror)
+    tr = buffers.TrajBuffers(T, N, H, depth, "cuda:0", mirror=mirror)
     tr.actor_obs[:, :, :65] = (torch.randn(T + 1, N, 65, generator=g) * 0.5).cuda()
     tr.critic_obs[:, :, :475] = (torch.randn(T + 1, N, 475, generator=g) * 0.5).cuda()
     tr.action.copy_(torch.randn(T, N, 20, generator=g) * 0.3)
     done = (torch.rand(T, N, generator=g) < 0.15).float() * torch.where(torch.rand(T, N, generator=g) < 0.5, -1.0, 1.0)
     tr.aux[:T, :, L.AUX["DONE"]] = done.cuda()
     tr.reward.copy_(torch.rand(T, N, generator=g))
-    tr.carry0_actor_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
-    tr.carry0_critic_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
+    tr.carry0_actor_hc.copy_(torch.randn(depth, 2, N, H, generator=g) * 0.3)
+    tr.carry0_critic_hc.copy_(torch.randn(depth, 2, N, H, generator=g) * 0.3)
     tr.carry0_lpf.copy_(torch.randn(N, 20, generator=g) * 0.2)
     if mirror:
-        tr.carry0_actor_mirror_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
-        tr.carry0_critic_mirror_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
+        tr.carry0_actor_mirror_hc.copy_(torch.randn(depth, 2, N, H, generator=g) * 0.3)
+        tr.carry0_critic_mirror_hc.copy_(torch.randn(depth, 2, N, H, generator=g) * 0.3)
         tr.carry0_lpf_mirror.copy_(torch.randn(N, 20, generator=g) * 0.2)
     return tr
 
@@ -148,6 +148,77 @@ def test_ppo_grad_matches_autograd(H, N, B, T):
         ON.adamw_step(cfg, p_o, m_o, v_o, gg.clone(), step, 0.5)
     ctx.synchronize()
     assert (params.cpu().double() - p_o).abs().max() < 1e-6
+    ctx.close()
+
+
+@pytest.mark.parametrize("H,D", [(192, 2), (128, 1), (64, 3), (256, 4)])
+def test_other_depths_and_hidden_sizes_match_oracle(H, D):
+    """`hidden_size` and `depth` are user fields of the reference config (train.py:78-85). The library serves hidden 64 / 128 / 192 / 256
+    and depth 1..4: one policy step (mode, value, every carry plane) and one minibatch gradient against the torch oracle / autograd."""
+    N, B, T = 70, 35, 6
+    m, cfg, ctx, torch, buffers = _setup(N, B, T, H, depth=D)
+    from oracle import nn as ON
+    P = ctx.param_count()
+    assert P == ON.param_count(H, D)
+    params = torch.zeros(P, device="cuda:0")
+    ctx.init_params(4, params)
+    p64 = params.detach().cpu().double()
+    pd = ON.unflatten(p64, H, D)
+    jb = torch.tensor(list(m.joint_bias), dtype=torch.float64)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    # ---- policy step ----
+    aobs = torch.zeros(N, L.LD_ACTOR); aobs[:, :65] = torch.randn(N, 65, generator=g)
+    cobs = torch.zeros(N, L.LD_CRITIC); cobs[:, :475] = torch.randn(N, 475, generator=g)
+    carry = buffers.CarryBuffers(N, H, D, "cuda:0")
+    carry.actor_hc.copy_(torch.randn(D, 2, N, H, generator=g) * 0.5)
+    carry.critic_hc.copy_(torch.randn(D, 2, N, H, generator=g) * 0.5)
+    carry.lpf.copy_(torch.randn(N, 20, generator=g) * 0.3)
+    hc_a0, hc_c0, lpf0 = carry.actor_hc.cpu().double(), carry.critic_hc.cpu().double(), carry.lpf.cpu().double()
+    action, logp, value = torch.zeros(N, 20, device="cuda:0"), torch.zeros(N, device="cuda:0"), torch.zeros(N, device="cuda:0")
+    ctx.policy_step(params, aobs.cuda(), cobs.cuda(), carry.c, 7, 5, True, action, logp, value)
+    ctx.synchronize()
+    out_a, ca = ON.net_forward(pd, "actor", aobs[:, :65].double(), [[hc_a0[l, 0], hc_a0[l, 1]] for l in range(D)], D)
+    mean, std, lpf1 = ON.actor_head(out_a, aobs.double(), lpf0, jb, cfg)
+    out_c, cc = ON.net_forward(pd, "critic", cobs[:, :475].double(), [[hc_c0[l, 0], hc_c0[l, 1]] for l in range(D)], D)
+    assert (action.cpu().double() - mean).abs().max() < 2e-5
+    assert (value.cpu().double() - out_c[:, 0]).abs().max() < 2e-5
+    for l in range(D):
+        for k in range(2):
+            assert (carry.actor_hc[l, k].cpu().double() - ca[l][k]).abs().max() < 1e-5
+            assert (carry.critic_hc[l, k].cpu().double() - cc[l][k]).abs().max() < 1e-5
+    # ---- one minibatch gradient ----
+    tr = _synthetic_traj(torch, buffers, N, T, H, depth=D)
+    idx = torch.randperm(N, generator=g)[:B].int()
+    ao, co = tr.actor_obs[:T].cpu().double(), tr.critic_obs[:T].cpu().double()
+    act, done = tr.action.cpu().double(), tr.done.cpu().double()
+    with torch.no_grad():
+        c_a = [[tr.carry0_actor_hc[l, k].cpu().double() for k in range(2)] for l in range(D)]
+        c_c = [[tr.carry0_critic_hc[l, k].cpu().double() for k in range(2)] for l in range(D)]
+        lp, v, en, *_ = ON.ppo_variables(pd, cfg, jb, ao, co, act, done, c_a, c_c, tr.carry0_lpf.cpu().double(), D)
+    tr.logp.copy_((lp + 0.3 * torch.randn(T, N, generator=g).double()).float())
+    tr.value.copy_((v + 0.3 * torch.randn(T, N, generator=g).double()).float())
+    ctx.gae(tr.c, tr.adv, tr.target)
+    grad, metrics = torch.zeros(P, device="cuda:0"), torch.zeros(10, device="cuda:0")
+    ctx.ppo_grad(params, tr.c, idx.cuda(), B, tr.adv, tr.target, grad, metrics)
+    ctx.synchronize()
+    adv_o, tgt_o = ON.gae(tr.value.cpu().double(), tr.reward.cpu().double(), done, cfg.gamma, cfg.lam)
+    pf = p64.clone().requires_grad_(True)
+    pdg = ON.unflatten(pf, H, D)
+    ii = idx.long()
+    c_a = [[tr.carry0_actor_hc[l, k].cpu().double()[ii] for k in range(2)] for l in range(D)]
+    c_c = [[tr.carry0_critic_hc[l, k].cpu().double()[ii] for k in range(2)] for l in range(D)]
+    lp, v, en, *_ = ON.ppo_variables(pdg, cfg, jb, ao[:, ii], co[:, ii], act[:, ii], done[:, ii], c_a, c_c, tr.carry0_lpf.cpu().double()[ii], D)
+    loss, mt = ON.ppo_loss(cfg, lp, v, en, tr.logp.cpu().double()[:, ii], tr.value.cpu().double()[:, ii], adv_o[:, ii], tgt_o[:, ii])
+    loss.backward()
+    go, gg = pf.grad, grad.cpu().double()
+    assert abs(float(metrics[0]) - float(loss.detach())) < 2e-4 * (1 + abs(float(loss.detach())))
+    off = 0
+    for name, shp in ON.param_shapes(H, D):
+        n = int(np.prod(shp))
+        a, b = gg[off:off + n], go[off:off + n]
+        assert (a - b).abs().max() / (b.abs().max() + 1e-12) < 2e-3, name
+        off += n
+    assert off == P and (gg - go).norm() / go.norm() < 1e-4
     ctx.close()
 
 
