@@ -125,6 +125,7 @@ template <class T> int dalloc(kbj_ctx* ctx, NnWs& w, T** p, size_t count) {
   return 0;
 }
 
+int g_fold_sk = 8;        // k slices of the small W_ih0^T Z product of the folded input projections (KBJ_FOLD_SK)
 int g_splitk_wgs = 768;   // target number of workgroups of a split-K weight-gradient GEMM (KBJ_SPLITK_WGS)
 
 inline dim3 g1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
@@ -355,6 +356,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (getenv("KBJ_SEQ_BSTAMPS")) { if (dalloc(ctx, *w, &w->seq_bstamps, (size_t)T * 10 + 768)) return -1; }
   if (hipMemset(w->seq_err, 0, 4 * sizeof(unsigned)) != hipSuccess) return kbj_fail(ctx, "hipMemset seq_err");
   g_splitk_wgs = getenv("KBJ_SPLITK_WGS") ? atoi(getenv("KBJ_SPLITK_WGS")) : 768;
+  g_fold_sk = getenv("KBJ_FOLD_SK") ? std::max(1, atoi(getenv("KBJ_FOLD_SK"))) : 8;
   g_seq_uw = getenv("KBJ_SEQ_UW") ? atoi(getenv("KBJ_SEQ_UW")) : 2;
   if (g_seq_uw != 1 && g_seq_uw != 2) return kbj_fail(ctx, "KBJ_SEQ_UW must be 1 or 2");
   g_seq_drop = getenv("KBJ_DEBUG_DROP_SEQ_WG") ? atoi(getenv("KBJ_DEBUG_DROP_SEQ_WG")) : 0;
@@ -831,7 +833,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     linear_bwd_input(ns[n & 1], t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
     fork_side(n);
     linear_bwd_weight(side_of(n), t.dOut, 40, t.Hout[D - 1], H, grad_d + o.w_out, H, o.nout, H, R);
-    hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 64), dim3(256), 0, side_of(n), t.dOut, R, o.nout, 40, grad_d + o.b_out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 512), dim3(256), 0, side_of(n), t.dOut, R, o.nout, 40, grad_d + o.b_out);
     dh_above[n] = t.dHa; dx_out[n] = t.dHb;
   }
   for (int l = D - 1; l >= 0; --l) {
@@ -859,7 +861,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
         GemmArgs g{dG, t.Hm[0], grad_d + o.w_hh[0], nullptr, 4 * H, H + o.nin, R, 4 * H, H, H, 1, sk, nullptr};
         g.B2 = t.obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = o.ld_obs;
         gemm_launch<false, false>(ws, g, ts == 128 ? 1 : 0);
-        GemmArgs g1a{params_d + o.w_ih[0], Z, grad_d + o.w_in, nullptr, H, o.nin, 4 * H, H, o.ld_obs, o.nin, 1, 1, nullptr};
+        // (a 4H-deep contraction on a handful of output tiles: split over k so that it is a short kernel, not a 130 us tail on 32 workgroups)
+        GemmArgs g1a{params_d + o.w_ih[0], Z, grad_d + o.w_in, nullptr, H, o.nin, 4 * H, H, o.ld_obs, o.nin, 1, g_fold_sk, nullptr};
         gemm_launch<false, false>(ws, g1a);
         GemmArgs g2a{Z, params_d + o.w_in, grad_d + o.w_ih[0], nullptr, 4 * H, H, o.nin, o.ld_obs, o.nin, H, 1, 1, nullptr};
         gemm_launch<true, true>(ws, g2a);
@@ -876,7 +879,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     hipStream_t s = ns[n & 1];
     if (!(fold_actor && ((n & 1) == 0 || fold_critic))) {   // input projection (dh_above now holds dX0)
       linear_bwd_weight(s, dh_above[n], H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
-      hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, 64), dim3(256), 0, s, dh_above[n], R, H, H, grad_d + o.b_in);
+      hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, 512), dim3(256), 0, s, dh_above[n], R, H, H, grad_d + o.b_in);
     }
     if (!one_stream) { hipEventRecord(ctx->ev_side[n & 1], ctx->side[n & 1]); hipStreamWaitEvent(s, ctx->ev_side[n & 1], 0); }
   }
