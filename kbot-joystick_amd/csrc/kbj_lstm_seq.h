@@ -324,11 +324,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   constexpr int NUG = H / UNITS;
   // one gate chunk of dG_{t+1} at a time: a single 33 KB buffer (plus pbuf) keeps the workgroup at 42 KB of LDS so that two
   // recurrences (actor + critic) AND two GEMM workgroups fit on a CU together (profiles/r01: double buffering starved the GEMMs)
-#ifdef KBJ_SEQ_BWD_DEEP
-  __shared__ __attribute__((aligned(16))) float ds[2 * SEQ_ROWS * LDH];
-#else
   __shared__ __attribute__((aligned(16))) float ds[SEQ_ROWS * LDH];
-#endif
   __shared__ float pbuf[4][SEQ_ROWS][UNITS + 1];                     // per-wave partial sums of dh
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, uh = tid >> 8;   // wave: k quarter, uh: 16-unit half
@@ -390,27 +386,6 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       SEQ_BSTAMP(1);
       f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
       const float* src = a.dG + (size_t)(t + 1) * B * 4 * H;
-#ifdef KBJ_SEQ_BWD_DEEP
-      SeqTile<H, NTH> tile[2];
-      tile[0].load(src, 4 * H, r0, B);
-      tile[1].load(src + H, 4 * H, r0, B);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float* buf = ds + (c & 1) * (SEQ_ROWS * LDH);
-        tile[c & 1].to_lds(buf, r0, B);
-        if (c < 2) tile[c & 1].load(src + (c + 2) * H, 4 * H, r0, B);
-        else if (c == 3) prefetch();
-        __syncthreads();
-        SEQ_BSTAMP(2 + c);
-        const float* a0p = buf + (lane & 15) * LDH + wave * KW + (lane >> 4);
-        const float* a1p = a0p + 16 * LDH;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * s], wreg[c][s], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * s], wreg[c][s], acc1, 0, 0, 0);
-        }
-      }
-#else
       SeqTile<H, NTH> tile;
       tile.load(src, 4 * H, r0, B);
 #pragma unroll
@@ -431,7 +406,6 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
           acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * s], wreg[c][s], acc1, 0, 0, 0);
         }
       }
-#endif
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         pbuf[wave][(lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc0[r];
