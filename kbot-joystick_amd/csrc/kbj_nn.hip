@@ -682,6 +682,23 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, 2 * MAXD * 4 * 256 * sizeof(unsigned), s));
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  static const bool fold_actor = getenv("KBJ_FOLD_ACTOR") ? atoi(getenv("KBJ_FOLD_ACTOR")) != 0 : true;
+  static const bool fold_critic = getenv("KBJ_FOLD_CRITIC") ? atoi(getenv("KBJ_FOLD_CRITIC")) != 0 : false;   // backward only (475 > H inputs)
+  // (first on the actor's lane, ahead of the gathers: the two small launches depend on the parameters only, and behind the gathers they
+  // queue for CU slots behind the 800 workgroups of the critic's input projection - 87 us on the actor's chain instead of ~25)
+  if (fold_actor) {
+    // The actor's input projection (65 -> H, no activation) feeds only layer 0's input GEMM, so gates_0 = obs (W_ih0 W_in)^T +
+    // (W_ih0 b_in + b_0): a 65-deep contraction instead of 65 -> H -> 4H (6.8 instead of 28.5 GFLOP per minibatch forward, and
+    // 6.8 instead of 55 GFLOP backward). Same function, different rounding order (inside the parity tolerances).
+    const NetOff& oa = w.net[0];
+    GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, KBJ_LD_ACTOR, 0, 1, nullptr};
+    gemm_launch<true, false>(s, g);
+    hipLaunchKernelGGL(matvec_kernel, dim3((4 * H + 3) / 4), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
+    // each accumulator is cleared on the lane whose side stream later accumulates into it (actor-type nets: the caller's stream,
+    // critic-type nets with KBJ_FOLD_CRITIC: the second stream), so the clear is always ordered before the split-K atomics
+    for (int n = 0; n < w.nnets; ++n)
+      if ((n & 1) == 0 || fold_critic) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), ns[n & 1]));
+  }
   auto gather = [&](hipStream_t st, const float* src, int wdt, int lds, float* dst, int ldd) {
     if (wdt % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && ((size_t)src & 15) == 0 && ((size_t)dst & 15) == 0)
       hipLaunchKernelGGL(gather_rows4_kernel, g1((size_t)R * (wdt / 4)), dim3(256), 0, st, reinterpret_cast<const float4*>(src), idx, T, N, B, wdt / 4, lds / 4, ldd / 4,
@@ -718,30 +735,15 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)R * w.net[k].ld_obs), dim3(256), 0, ns[k], w.tb[k].obs, w.tb[2 + k].obs, (size_t)R, w.net[k].ld_obs, w.mtab[k]);
   // ---- forward through time: actor on the caller's stream, critic on the context's second stream (the recurrences are
   // latency bound, so the two nets overlap) ----
-  static const bool fold_actor = getenv("KBJ_FOLD_ACTOR") ? atoi(getenv("KBJ_FOLD_ACTOR")) != 0 : true;
   static const int bstamp_sel = getenv("KBJ_SEQ_BSTAMPS") ? atoi(getenv("KBJ_SEQ_BSTAMPS")) : 0;
   static const int stamp_sel = getenv("KBJ_SEQ_STAMPS") ? atoi(getenv("KBJ_SEQ_STAMPS")) : 1;   // diagnostics: 1 + net + 2 * layer picks the stamped forward launch
   const int stamp_net = (stamp_sel - 1) & 1, stamp_layer = ((stamp_sel - 1) >> 1) & 1;
-  static const bool fold_critic = getenv("KBJ_FOLD_CRITIC") ? atoi(getenv("KBJ_FOLD_CRITIC")) != 0 : false;   // backward only (475 > H inputs)
   // forward: the K = H input projections (x W_ih^T + b) run inside the persistent recurrence, their MFMAs placed around the flag poll and
   // the h-tile fetch where the matrix pipe idles (kbj_lstm_seq.h FUSE): a fused launch takes 1.11 instead of 0.88 ms, the 0.41-0.48 ms
   // GEMM in front of it and its 210 MB round trip of G disappear: ppo_grad 7.72 -> 7.47 ms. KBJ_SEQ_FUSE=0: separate GEMMs.
   static const bool fuse_ih = getenv("KBJ_SEQ_FUSE") ? atoi(getenv("KBJ_SEQ_FUSE")) != 0 : true;
   // the folded actor layer 0 the same way (observation row x Weff inside the recurrence, 17 k-steps): KBJ_SEQ_FUSE_OBS=0 keeps the GEMM
   static const bool fuse_obs = fuse_ih && w.net[0].ld_obs == KBJ_LD_ACTOR && (getenv("KBJ_SEQ_FUSE_OBS") ? atoi(getenv("KBJ_SEQ_FUSE_OBS")) != 0 : true);
-  if (fold_actor) {
-    // The actor's input projection (65 -> H, no activation) feeds only layer 0's input GEMM, so gates_0 = obs (W_ih0 W_in)^T +
-    // (W_ih0 b_in + b_0): a 65-deep contraction instead of 65 -> H -> 4H (6.8 instead of 28.5 GFLOP per minibatch forward, and
-    // 6.8 instead of 55 GFLOP backward). Same function, different rounding order (inside the parity tolerances).
-    const NetOff& oa = w.net[0];
-    GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, KBJ_LD_ACTOR, 0, 1, nullptr};
-    gemm_launch<true, false>(s, g);
-    hipLaunchKernelGGL(matvec_kernel, dim3((4 * H + 3) / 4), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
-    // each accumulator is cleared on the lane whose side stream later accumulates into it (actor-type nets: the caller's stream,
-    // critic-type nets with KBJ_FOLD_CRITIC: the second stream), so the clear is always ordered before the split-K atomics
-    for (int n = 0; n < w.nnets; ++n)
-      if ((n & 1) == 0 || fold_critic) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), ns[n & 1]));
-  }
   // Launch order is layer-major over the nets (nets 2, 3 = mirror branches, same weights, queued behind nets 0, 1 on the same two
   // streams). KBJ_ALIGN=1 makes the two lanes wait for each other before every recurrence phase, so that recurrences only ever
   // run next to recurrences and GEMMs next to GEMMs (diagnostic; no measurable difference).
@@ -779,8 +781,13 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       if (seq_fwd(ctx, ns[n & 1], H, fa)) return -1;
     }
   }
+  // Without the mirror branches the critic's one-output head, the value half of the loss and the head's backward are ONE kernel on the
+  // critic's lane (critic_head_kernel: ~30 us instead of two degenerate GEMMs and three small kernels, ~220 us, on the longer chain).
+  static const bool fused_critic_head_on = !(getenv("KBJ_FUSED_CRITIC_HEAD") && atoi(getenv("KBJ_FUSED_CRITIC_HEAD")) == 0);
+  const bool fused_critic_head = fused_critic_head_on && !w.mirror && w.net[1].nout == 1;
   for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
+    if (n == 1 && fused_critic_head) continue;
     linear_fwd(ns[n & 1], w.tb[n].Hout[D - 1], H, params_d + o.w_out, H, params_d + o.b_out, w.tb[n].Out, 40, R, o.nout, H, 0);
   }
   // heads and losses: the policy terms need the actor only, the value terms the critic only (the mirror terms likewise), so each lane
@@ -793,9 +800,21 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipLaunchKernelGGL(gaussian_logp_kernel, g1(R), dim3(256), 0, s, w.y, w.sd, w.act, R, w.logp, w.ent);
   hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, s, w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
                      w.stats + 2, one_stream ? 0 : 1);
-  hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, ns[1], w.tb[1].Out, 40, R, w.value);
-  hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, ns[1], w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
-                     w.stats + 2, one_stream ? 3 : 2);
+  if (fused_critic_head) {
+    const NetOff& oc = w.net[1];
+    TrainBufs& tc = w.tb[1];
+    const dim3 grid(2048), block(256);
+#define KBJ_CRITIC_HEAD(V) hipLaunchKernelGGL((critic_head_kernel<V>), grid, block, 0, ns[1], tc.Hout[D - 1], params_d + oc.w_out, params_d + oc.b_out, w.val_old, w.target, \
+                                              pp, R, w.value, w.dvalue, tc.dOut, tc.dHa, w.stats + 2)
+    switch (H / 64) { case 1: KBJ_CRITIC_HEAD(1); break; case 2: KBJ_CRITIC_HEAD(2); break; case 3: KBJ_CRITIC_HEAD(3); break; default: KBJ_CRITIC_HEAD(4); break; }
+#undef KBJ_CRITIC_HEAD
+    if (one_stream) hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, s, w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
+                                       w.stats + 2, 1);   // (the actor's launch above was a no-op in this diagnostic mode)
+  } else {
+    hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, ns[1], w.tb[1].Out, 40, R, w.value);
+    hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, ns[1], w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
+                       w.stats + 2, one_stream ? 3 : 2);
+  }
   if (w.mirror) {   // aux losses between each net and its mirror branch (train.py:1463-1481)
     hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[2].Out, w.tb[2].obs, w.joint_bias_d, hp, R, w.y_m, w.sd_m);
     hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0_m, hp, T, B, w.y_m);
@@ -816,7 +835,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipLaunchKernelGGL(actor_head_bwd_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.y, w.sd, w.act, w.dlogp,
                      w.mirror ? w.dy : (const float*)nullptr, -c.entropy_coef / (float)R, hp, R, w.tb[0].dOut);
   hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, hp, T, B, w.tb[0].dOut);
-  KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[1].dOut, 40 * sizeof(float), w.dvalue, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, ns[1]));
+  if (!fused_critic_head) KBJ_HIP(ctx, hipMemcpy2DAsync(w.tb[1].dOut, 40 * sizeof(float), w.dvalue, sizeof(float), sizeof(float), R, hipMemcpyDeviceToDevice, ns[1]));
   if (w.mirror) {   // the mirror actor only sees the aux gradient on its filtered mean (no log-prob, no entropy term)
     hipLaunchKernelGGL(actor_head_bwd_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[2].Out, w.y_m, w.sd_m, w.y_m, w.zeroR, w.dy_m, 0.0f, hp, R, w.tb[2].dOut);
     hipLaunchKernelGGL(actor_head_train_bwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, hp, T, B, w.tb[2].dOut);
@@ -830,7 +849,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
     TrainBufs& t = w.tb[n];
-    linear_bwd_input(ns[n & 1], t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
+    if (!(n == 1 && fused_critic_head)) linear_bwd_input(ns[n & 1], t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
     fork_side(n);
     linear_bwd_weight(side_of(n), t.dOut, 40, t.Hout[D - 1], H, grad_d + o.w_out, H, o.nout, H, R);
     hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 512), dim3(256), 0, side_of(n), t.dOut, R, o.nout, 40, grad_d + o.b_out);

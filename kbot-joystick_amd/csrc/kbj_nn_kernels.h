@@ -265,6 +265,42 @@ __global__ void ppo_loss_kernel(const float* __restrict__ logp, const float* __r
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) for (int k = 0; k < 5; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o]; __syncthreads(); }
   if (threadIdx.x == 0) for (int k = 0; k < 5; ++k) if (k == 1 ? (part & 2) : (part & 1)) atomicAdd(&macc[k], red[k][0]);
 }
+// critic head, fused (one output, train.py:993-1004 + the value terms of the PPO loss): value = h w + b -> clipped value loss ->
+// dL/dvalue -> dL/dh = dL/dvalue * w, all in one pass over the top layer's output rows (one wavefront per row, VPL = H / 64 floats per
+// lane). Replaces a [R x H] x [H x 1] GEMM, the value gather, the value half of ppo_loss_kernel, a strided copy and a K = 1 GEMM on
+// the critic's critical chain. dout (leading dimension 40) receives dL/dvalue in column 0 for the output layer's weight / bias gradient.
+template <int VPL>
+__global__ void critic_head_kernel(const float* __restrict__ h, const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                   const float* __restrict__ value_old, const float* __restrict__ target, PpoParams pp, int R,
+                                   float* __restrict__ value, float* __restrict__ dvalue, float* __restrict__ dout, float* __restrict__ dh,
+                                   double* __restrict__ macc) {
+  constexpr int H = 64 * VPL;
+  __shared__ double red[4];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float wreg[VPL];
+#pragma unroll
+  for (int j = 0; j < VPL; ++j) wreg[j] = w_out[lane * VPL + j];
+  const float bias = b_out[0], inv = 1.0f / R;
+  double m1 = 0;
+  for (int r = blockIdx.x * 4 + wv; r < R; r += gridDim.x * 4) {
+    float x[VPL], s = 0;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) { x[j] = h[(size_t)r * H + lane * VPL + j]; s += x[j] * wreg[j]; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float v = s + bias, vo = value_old[r], tg = target[r];
+    const float dv = v - vo, dvc = fminf(fmaxf(dv, -pp.vclip), pp.vclip), vcl = vo + dvc;
+    const float e1 = (v - tg) * (v - tg), e2 = (vcl - tg) * (vcl - tg);
+    const float gv = e1 >= e2 ? (v - tg) : ((fabsf(dv) < pp.vclip) ? (vcl - tg) : 0.0f);
+    const float dval = pp.vcoef * inv * gv;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) dh[(size_t)r * H + lane * VPL + j] = dval * wreg[j];
+    if (lane == 0) { value[r] = v; dvalue[r] = dval; dout[(size_t)r * 40] = dval; m1 += 0.5f * fmaxf(e1, e2); }
+  }
+  if (lane == 0) red[wv] = m1;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&macc[1], red[0] + red[1] + red[2] + red[3]);
+}
 // metrics[10] = loss, policy, value, entropy, clipfrac, kl, adv_mean, adv_std, action_mirror_loss, value_mirror_loss
 __global__ void ppo_metrics_kernel(const double* __restrict__ macc, const double* __restrict__ stats, PpoParams pp, int R, float* __restrict__ metrics) {
   double pol = macc[0] / R, vl = macc[1] / R, en = macc[2] / R, ma = macc[5] / R, mc = macc[6] / R;
