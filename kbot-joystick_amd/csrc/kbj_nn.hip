@@ -683,7 +683,11 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   static const bool fold_actor = getenv("KBJ_FOLD_ACTOR") ? atoi(getenv("KBJ_FOLD_ACTOR")) != 0 : true;
-  static const bool fold_critic = getenv("KBJ_FOLD_CRITIC") ? atoi(getenv("KBJ_FOLD_CRITIC")) != 0 : false;   // backward only (475 > H inputs)
+  // The critic's input projection folds the same way in the BACKWARD pass only (475 > H inputs, so forward the two-step form is cheaper):
+  // Z = dG0^T obs beside dW_hh0 in one launch, then dW_in = W_ih0^T Z, dW_ih0 = Z W_in^T: 110 instead of 126 GFLOP in the tail phase and no
+  // dX0 -> dW_in -> bias-sum chain at its end. It did not pay while the lanes met at the loss (+0.1 ms); with independent, balanced lanes
+  // and the small products split over k it does: 6.55 -> 6.46 ms per minibatch. KBJ_FOLD_CRITIC=0: two-step form.
+  static const bool fold_critic = getenv("KBJ_FOLD_CRITIC") ? atoi(getenv("KBJ_FOLD_CRITIC")) != 0 : true;
   // (first on the actor's lane, ahead of the gathers: the two small launches depend on the parameters only, and behind the gathers they
   // queue for CU slots behind the 800 workgroups of the critic's input projection - 87 us on the actor's chain instead of ~25)
   if (fold_actor) {
