@@ -33,7 +33,8 @@ typedef struct kbj_ctx kbj_ctx;
 
 /* ---- lifetime ---------------------------------------------------------------------------- */
 /* replaces: HumanoidWalkingTask.launch(config) set-up — get_mujoco_model / metadata / mjx.put_model
- * (train.py:1079-1089, 1760-1792). model_blob is a kbj_model produced by the spec compiler. */
+ * (train.py:1079-1089, 1760-1792). model_blob is a kbj_model produced by the spec compiler.
+ * Model fields served (train.py:78-85): cfg->hidden_size in {64, 128, 192, 256}, cfg->depth in 1..KBJ_MAX_DEPTH; anything else fails here. */
 int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const kbj_config* cfg, int device, void* hip_stream);
 int kbj_destroy(kbj_ctx* ctx);
 const char* kbj_last_error(const kbj_ctx* ctx); /* ctx may be NULL: error of a failed kbj_create */
