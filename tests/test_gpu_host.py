@@ -65,18 +65,21 @@ def test_checkpoint_resume_is_bit_identical(tmp_path, mirror):
         t.ctx.close()
 
 
-@pytest.mark.parametrize("H,D", [(192, 3), (128, 1)])
-def test_task_runs_with_other_depths_and_hidden_sizes(tmp_path, H, D):
+@pytest.mark.parametrize("H,D,mirror", [(192, 3, False), (128, 1, False), (64, 3, True)])
+def test_task_runs_with_other_depths_and_hidden_sizes(tmp_path, H, D, mirror):
     """The reference's model fields hidden_size / depth (train.py:78-85) through the whole task: iterations run, the checkpoint carries
     depth x (h, c) planes and the exported actor advertises carry_size = depth * 2 * hidden + 20 (convert.py:71)."""
     import torch
     from kbot_joystick_amd.host.task import HumanoidWalkingTask
     from kbot_joystick_amd.host import ckpt
-    t = HumanoidWalkingTask(_small(hidden_size=H, depth=D, num_passes=2))
+    kw = dict(actor_mirror_loss_scale=1.0, critic_mirror_loss_scale=0.01) if mirror else {}
+    t = HumanoidWalkingTask(_small(hidden_size=H, depth=D, num_passes=2, **kw))
     for _ in range(2):
         t.train_iteration()
     assert bool(torch.isfinite(t.metrics).all()) and bool(torch.isfinite(t.params).all())
     assert tuple(t.carry.actor_hc.shape) == (D, 2, 64, H) and float(t.carry.actor_hc.abs().sum()) > 0
+    if mirror:
+        assert tuple(t.carry.actor_mirror_hc.shape) == (D, 2, 64, H) and float(t.carry.critic_mirror_hc.abs().sum()) > 0
     path = str(tmp_path / "ckpt.bin")
     t.save_checkpoint(path)
     flat = ckpt.load_ckpt(path, "model", hidden_size=H, depth=D)
