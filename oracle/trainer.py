@@ -21,12 +21,13 @@ class OracleTrainer:
         self.N, self.T, self.H, self.B = cfg.num_envs, cfg.rollout_len, cfg.hidden_size, cfg.batch_size
         self.dt = torch.float32 if precision == "f32" else torch.float64
         self.env = O.Oracle(model, cfg, seed, precision)
-        P = ON.param_count(self.H)
+        self.D = int(cfg.depth)
+        P = ON.param_count(self.H, self.D)
         self.params = torch.zeros(P, dtype=self.dt) if params is None else torch.tensor(params, dtype=self.dt)
         self.m, self.v = torch.zeros_like(self.params), torch.zeros_like(self.params)
         self.jb = torch.tensor(list(model.joint_bias), dtype=self.dt)
-        self.carry_a = ON.zero_carry(self.N, self.H, 2, self.dt)
-        self.carry_c = ON.zero_carry(self.N, self.H, 2, self.dt)
+        self.carry_a = ON.zero_carry(self.N, self.H, self.D, self.dt)
+        self.carry_c = ON.zero_carry(self.N, self.H, self.D, self.dt)
         self.lpf = torch.zeros(self.N, 20, dtype=self.dt)
         self.obs = self.env.reset_all()
         self.opt_step = 0
@@ -51,13 +52,13 @@ class OracleTrainer:
         act = np.zeros((T, N, 20), np.float32); logp = np.zeros((T, N), np.float32); value = np.zeros((T, N), np.float32)
         a_obs[0], c_obs[0], aux[0] = self.obs
         self.carry0 = ([[x.clone() for x in l] for l in self.carry_a], [[x.clone() for x in l] for l in self.carry_c], self.lpf.clone())
-        p = ON.unflatten(self.params, self.H)
+        p = ON.unflatten(self.params, self.H, self.D)
         with torch.no_grad():
             for t in range(T):
                 ao, co = torch.tensor(a_obs[t], dtype=self.dt), torch.tensor(c_obs[t], dtype=self.dt)
-                out_a, self.carry_a = ON.net_forward(p, "actor", ao[:, :65], self.carry_a)
+                out_a, self.carry_a = ON.net_forward(p, "actor", ao[:, :65], self.carry_a, self.D)
                 mean, std, self.lpf = ON.actor_head(out_a, ao, self.lpf, self.jb, self.cfg)
-                out_c, self.carry_c = ON.net_forward(p, "critic", co[:, :475], self.carry_c)
+                out_c, self.carry_c = ON.net_forward(p, "critic", co[:, :475], self.carry_c, self.D)
                 if actions is None:
                     a = mean + std * torch.tensor(self._normal(self.iteration * T + t), dtype=self.dt)
                 else:
@@ -79,14 +80,14 @@ class OracleTrainer:
         L, T = self.L, self.T
         tr = self.traj
         pf = self.params.clone().requires_grad_(True)
-        p = ON.unflatten(pf, self.H)
+        p = ON.unflatten(pf, self.H, self.D)
         ii = torch.as_tensor(idx, dtype=torch.long)
         tt = lambda a: torch.tensor(a, dtype=self.dt)
         done = tt(tr["aux"][:T, :, L.AUX["DONE"]])
         ca = [[x[ii] for x in l] for l in self.carry0[0]]
         cc = [[x[ii] for x in l] for l in self.carry0[1]]
         lp, v, en, *_ = ON.ppo_variables(p, self.cfg, self.jb, tt(tr["actor_obs"][:T])[:, ii], tt(tr["critic_obs"][:T])[:, ii],
-                                         tt(tr["action"])[:, ii], done[:, ii], ca, cc, self.carry0[2][ii])
+                                         tt(tr["action"])[:, ii], done[:, ii], ca, cc, self.carry0[2][ii], self.D)
         loss, metrics = ON.ppo_loss(self.cfg, lp, v, en, tt(tr["logp"])[:, ii], tt(tr["value"])[:, ii], adv[:, ii], target[:, ii])
         loss.backward()
         return pf.grad.detach(), {k: float(x.detach()) for k, x in metrics.items()}

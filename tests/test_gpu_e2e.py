@@ -59,11 +59,12 @@ def test_config0_full_iteration_matches_oracle():
     task.ctx.close()
 
 
-def test_training_iteration_matches_oracle():
+@pytest.mark.parametrize("H,D", [(64, 2), (128, 1)])     # (128, 1): another point of the reference's model fields (train.py:78-85), end to end
+def test_training_iteration_matches_oracle(H, D):
     import torch
     from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
     from oracle.trainer import OracleTrainer
-    cfg = launch_config(num_envs=8, batch_size=4, hidden_size=64, rollout_length_seconds=0.12, robot="kbot-headless", seed=5, num_passes=2)
+    cfg = launch_config(num_envs=8, batch_size=4, hidden_size=H, depth=D, rollout_length_seconds=0.12, robot="kbot-headless", seed=5, num_passes=2)
     task = HumanoidWalkingTask(cfg, device=torch.device("cuda", 0))
     params0 = task.params.cpu().numpy().copy()
     tr = OracleTrainer(task.model_blob, task.kcfg, seed=5, params=params0, precision="f32")
