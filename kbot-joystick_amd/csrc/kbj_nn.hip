@@ -420,7 +420,17 @@ bool rollout_step_kernel() {
   static const bool on = getenv("KBJ_ROLLOUT_STEP") ? atoi(getenv("KBJ_ROLLOUT_STEP")) != 0 : true;
   return on;
 }
+// Only the actor proper (net 0) sits on the rollout's critical chain (env -> actor -> env). The critic and the mirror branches run on side
+// lanes under the env kernel, where the only free resources are those of its last, partial round of wavefronts (8192 envs = 2.67 rounds
+// of 12 per CU: 168 VGPRs per SIMD and ~58 KB of LDS per CU for the last third of the kernel): a 64x64-tile GEMM workgroup (4 waves x 84
+// VGPRs, 37 KB) fits there, a layer-step workgroup (8 waves x 220 VGPRs) does not and would run into the next actor chain instead. So the
+// side-lane nets keep the GEMM + cell form on small tiles (414 vs 418 ms per iteration). KBJ_ROLLOUT_STEP_SIDE=1: layer-step kernels there too.
+bool net_uses_step_kernel(int n) {
+  static const bool side_on = getenv("KBJ_ROLLOUT_STEP_SIDE") && atoi(getenv("KBJ_ROLLOUT_STEP_SIDE")) != 0;
+  return rollout_step_kernel() && (n == 0 || side_on);
+}
 float* h_plane(NnWs& w, float* hc, int n, int l, int n0, bool partner) {
+  if (!net_uses_step_kernel(n)) partner = false;
   return (partner ? w.rH[n][l] : hc + (size_t)(2 * l) * w.N * w.H) + (size_t)n0 * w.H;
 }
 
@@ -443,7 +453,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
   NnWs& w = *ws_of(ctx);
   const kbj_config& c = ctx->cfg_h;
   const int N = w.N, H = w.H;
-  const bool fused = rollout_step_kernel();
+  const bool fused_any = rollout_step_kernel();
   const float* obs_base[2] = {actor_obs_d, critic_obs_d};
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
@@ -460,6 +470,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
       hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)cnt * o.ld_obs), dim3(256), 0, s, obs, obs_m, (size_t)cnt, o.ld_obs, w.mtab[k]);
       obs = obs_m;
     }
+    const bool fused = fused_any && net_uses_step_kernel(n);
     const bool folded = fused && weff && k == 0 && o.ld_obs == KBJ_LD_ACTOR;   // actor-type net: layer-0 gates straight from the observation row
     if (!folded) linear_fwd(s, obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, X, H, cnt, H, o.nin, 0);
     const float* x = X;
@@ -478,7 +489,8 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
       {  // gates = [x | h] [W_ih | W_hh]^T + b as ONE launch over the concatenated contraction (no read-modify-write of G)
         GemmArgs g{x, params_d + o.w_ih[l], G, params_d + o.b[l], cnt, 4 * H, 2 * H, H, H, 4 * H, 0, 1, nullptr};
         g.A2 = h; g.B2 = params_d + o.w_hh[l]; g.k1 = H;
-        gemm_launch<true, true>(s, g);
+        static const bool small_tiles = !(getenv("KBJ_ROLLOUT_GEMM_SMALL") && atoi(getenv("KBJ_ROLLOUT_GEMM_SMALL")) == 0);
+        gemm_launch<true, true>(s, g, (n > 0 && small_tiles && rollout_step_kernel()) ? 0 : -1);   // side-lane nets: 64x64 tiles (see net_uses_step_kernel)
       }
       CellFwdArgs2 ca;
       ca.a[0] = CellFwdArgs{G, cc, h, cc, nullptr, nullptr, nullptr, nullptr, cnt, H};
@@ -521,7 +533,7 @@ int carry_h_home(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, kbj_carry*
   NnWs& w = *ws_of(ctx);
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   for (int k = net_lo; k < net_hi; ++k)
-    for (int l = 0; l < w.D; ++l)
+    for (int l = 0; l < w.D && net_uses_step_kernel(k); ++l)
       KBJ_HIP(ctx, hipMemcpyAsync(hc[k] + (size_t)(2 * l) * w.N * w.H, w.rH[k][l], (size_t)w.N * w.H * sizeof(float), hipMemcpyDeviceToDevice, s));
   return 0;
 }
