@@ -516,7 +516,6 @@ void carry_reset_nets(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, int n
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   float* lpf[4] = {carry->lpf_d, nullptr, carry->lpf_mirror_d, nullptr};
   const bool partner = parity != 0 && rollout_step_kernel();
-  size_t n = (size_t)2 * w.D * cnt * w.H;
   for (int k = net_lo; k < net_hi; ++k) {
     CarryPlanes cp;
     cp.n = 2 * w.D;
@@ -524,7 +523,7 @@ void carry_reset_nets(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, int n
       cp.p[2 * l] = h_plane(w, hc[k], k, l, n0, partner);
       cp.p[2 * l + 1] = hc[k] + (size_t)(2 * l + 1) * w.N * w.H + (size_t)n0 * w.H;
     }
-    hipLaunchKernelGGL(carry_reset_kernel, g1(n), dim3(256), 0, s, cp, cnt, w.H, lpf[k] ? lpf[k] + (size_t)n0 * KBJ_NU : nullptr, done_d + (size_t)n0 * done_stride, done_stride);
+    hipLaunchKernelGGL(carry_reset_kernel, dim3((cnt + 3) / 4), dim3(256), 0, s, cp, cnt, w.H, lpf[k] ? lpf[k] + (size_t)n0 * KBJ_NU : nullptr, done_d + (size_t)n0 * done_stride, done_stride);
   }
 }
 

@@ -94,14 +94,13 @@ __global__ void critic_value_kernel(const float* __restrict__ out, int ld, int N
 // carry <- carry * (done == 0) (train.py:1502-1506): 2 x depth [cnt][H] planes (h0, c0, h1, c1, ... - the h planes may live in the
 // rollout's ping-pong scratch), lpf [cnt][20]
 struct CarryPlanes { float* p[2 * KBJ_MAX_DEPTH]; int n; };
+// one wavefront per env row: a single flag load decides, and only the (few) finished envs touch their planes
 __global__ void carry_reset_kernel(CarryPlanes hc, int cnt, int H, float* __restrict__ lpf, const float* __restrict__ done, int stride) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  int per = cnt * H;
-  if (idx < hc.n * per) {
-    int p = idx / per, r = idx % per;
-    if (done[(size_t)(r / H) * stride] != 0) hc.p[p][r] = 0;
-  }
-  if (lpf && idx < cnt * KBJ_NU) { int n = idx / KBJ_NU; if (done[(size_t)n * stride] != 0) lpf[idx] = 0; }
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= cnt || done[(size_t)row * stride] == 0.0f) return;
+  for (int p = 0; p < hc.n; ++p)
+    for (int k = lane; k < H; k += 64) hc.p[p][(size_t)row * H + k] = 0.0f;
+  if (lpf && lane < KBJ_NU) lpf[(size_t)row * KBJ_NU + lane] = 0.0f;
 }
 
 // ---- minibatch gathers ---------------------------------------------------------------------------------------------
