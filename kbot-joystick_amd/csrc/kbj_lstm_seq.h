@@ -25,6 +25,16 @@ typedef float f32x4m __attribute__((ext_vector_type(4)));
 
 constexpr int SEQ_ROWS = 32;   // rows per workgroup
 constexpr int SEQ_UNITS = 16;  // hidden units per workgroup
+// Backward-recurrence stamps (KBJ_SEQ_BSTAMPS) exist in diagnostics builds only (-DKBJ_SEQ_BSTAMPS_BUILD, `make bstamps`): the stamp code
+// costs 12 VGPRs (186 instead of 174), and at 2 x 192 per SIMD a weight-gradient GEMM workgroup (2 x 80) no longer fits beside a
+// backward-recurrence workgroup - 6.46 instead of 6.34 ms per minibatch.
+#ifdef KBJ_SEQ_BSTAMPS_BUILD
+#define SEQ_BSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 10 + (k)] = clock64(); } while (0)
+#define SEQ_BSTAMP_ON 1
+#else
+#define SEQ_BSTAMP(k) do { } while (0)
+#define SEQ_BSTAMP_ON 0
+#endif
 constexpr unsigned SEQ_SPIN_LIMIT = 1u << 24;   // default bound of every inter-workgroup spin (args.spin_limit; shorter under fault injection)
 
 struct SeqFwdArgs {
@@ -335,7 +345,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
-  if (a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x] = wall_clock64();   // per-workgroup entry / loop start / exit
+  if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x] = wall_clock64();   // per-workgroup entry / loop start / exit
   constexpr int KW = H / 4;        // k range of one wave inside a gate chunk
   constexpr int KS = KW / 4;       // k-steps per (wave, gate chunk)
   // B operands: for gate chunk c and k-step s: B[k][col] = Whh[c H + wave KW + 4 s + (lane>>4)][u0 + col]
@@ -367,12 +377,11 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
     }
   };
   fetch_inputs(T - 1);
-  if (a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 1] = wall_clock64();
-#define SEQ_BSTAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 10 + (k)] = clock64(); } while (0)
+  if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 1] = wall_clock64();
   for (int t = T - 1; t >= 0; --t) {
     const bool last = t == T - 1;
     SEQ_BSTAMP(0);
-    if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 10 + 9] = wall_clock64();   // constant-rate counter: gives the shader clock the stamps tick at
+    if (SEQ_BSTAMP_ON && a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 10 + 9] = wall_clock64();   // constant-rate counter: gives the shader clock the stamps tick at
     float dhm[2] = {0.0f, 0.0f};
     float act[2][4], tc[2], cprev[2], dha[2], kp[2];
     auto prefetch = [&]() {
@@ -452,7 +461,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
       atomicAdd(a.db + k * H + u0 + u, s);
     }
   }
-  if (a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 2] = wall_clock64();
+  if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 2] = wall_clock64();
 }
 
 // ---- one LSTM layer step for MANY independent rows (rollout: 8192 envs, no recurrence inside the launch) ------------------------------
