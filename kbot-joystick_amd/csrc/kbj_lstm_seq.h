@@ -214,7 +214,11 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     cm[i] = r < B ? a.Cm[(size_t)r * H + u0 + eunit[i]] : 0.0f;
   }
   float ig[2], fg[2], gg[2], og[2], tc[2], hh[2];  // results of the previous step, stored lazily
+#ifdef KBJ_SEQ_BSTAMPS_BUILD   // forward stamps (KBJ_SEQ_STAMPS): diagnostics build as well
 #define SEQ_STAMP(k) do { if (a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 6 + (k)] = clock64(); } while (0)
+#else
+#define SEQ_STAMP(k) do { } while (0)
+#endif
   // own inputs (input projection pre-activations, keep flags) are fetched ONE STEP AHEAD: their HBM latency hides behind
   // a whole step instead of stalling the cell
   float gxn[2][4], kpn[2];
