@@ -80,6 +80,13 @@ size_t kbj_actor_param_count(const kbj_config* cfg);
 /* replaces: get_model(InitParams(key)) (train.py:1278-1327): U(+-1/sqrt(fan_in)) init from a threefry stream */
 int kbj_init_params(kbj_ctx* ctx, uint32_t seed, float* params_d);
 
+/* The sagittal mirror of a PACKED observation row (mirror_obs / mirror_cmd / mirror_joints, train.py:1574-1756, applied to the rows
+ * run_actor / run_critic pack, train.py:1351-1433) as the table the kernels use: out[k] = mul[k] * in[src[k]] + add[k] (the affine part
+ * re-normalises joint positions whose source and destination joints have different biases / ranges). Host-only, needs no device:
+ * fills KBJ_LD_ACTOR (critic = 0) or KBJ_LD_CRITIC (critic != 0) entries and returns that count (< 0 on error).
+ * tests/test_ref_constants.py compares it with the table derived from the reference's source text. */
+int kbj_mirror_table(const void* model_blob, size_t model_bytes, int critic, int32_t* src_h, float* mul_h, float* add_h);
+
 /* Model carry (train.py:1049-1055, 1526-1543), device arrays owned by the caller:
  *   actor_hc_d / critic_hc_d [depth][2][N][H] (h then c per layer), lpf_d [N][20] */
 typedef struct kbj_carry {

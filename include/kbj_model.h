@@ -39,6 +39,30 @@ extern "C" {
 #define KBJ_MAX_DEPTH    4   /* LSTM layers per net the library's workspaces are laid out for */
 #define KBJ_LD_CRITIC    476
 
+/* Offsets of the pieces of a packed observation row, in the order run_actor / run_critic concatenate them (train.py:1367-1374,
+ * 1410-1430); the first 65 entries are common to both rows, the critic's privileged pieces follow. Divisors as train.py:1336, 1427.
+ * tests/test_ref_constants.py derives this table from the reference's source text (ast) and asserts it. */
+enum {
+  KBJ_OBS_JPOS     = 0,    /* [20] normalize_joint_pos(joint position) */
+  KBJ_OBS_JVEL     = 20,   /* [20] joint velocity / KBJ_OBS_JVEL_DIV */
+  KBJ_OBS_PG       = 40,   /* [5]  roll, pitch, unit projected gravity */
+  KBJ_OBS_GYRO     = 45,   /* [3]  */
+  KBJ_OBS_ZEROCMD  = 48,   /* [1]  |cmd[0:3]| < 1e-3 */
+  KBJ_OBS_CMD      = 49,   /* [16] unified command */
+  KBJ_OBS_TOUCH    = 65,   /* [2]  left, right foot touch (critic only from here) */
+  KBJ_OBS_FEETPOS  = 67,   /* [6]  */
+  KBJ_OBS_BASEPOS  = 73,   /* [3]  */
+  KBJ_OBS_BASEQUAT = 76,   /* [4]  */
+  KBJ_OBS_CINERT   = 80,   /* [23][10] */
+  KBJ_OBS_CVEL     = 310,  /* [23][6]  */
+  KBJ_OBS_LINVEL   = 448,  /* [3]  */
+  KBJ_OBS_ANGVEL   = 451,  /* [3]  */
+  KBJ_OBS_ACTFRC   = 454,  /* [20] actuator force / KBJ_OBS_ACTFRC_DIV */
+  KBJ_OBS_HEIGHT   = 474   /* [1]  */
+};
+#define KBJ_OBS_JVEL_DIV   10.0f
+#define KBJ_OBS_ACTFRC_DIV 4.0f
+
 typedef struct kbj_model {
   uint32_t magic, version;
   int32_t  nbody, nq, nv, nu, ncap, reserved0;

@@ -194,9 +194,9 @@ KBJ_DEV void task_write_obs(KbjShared& S, const kbj_model& m, const kbj_config& 
     float q = es[KBJ_ES_QPOS + 7 + u], v = es[KBJ_ES_QVEL + 6 + u];
     float qn = q + S.ep[KBJ_EP_JPBIAS + u] + (noise ? rng_uniform(rng, KBJ_RNG_OBS_NOISE, st, u, -c.jpos_noise, c.jpos_noise) : 0.0f);
     float vn = v + (noise ? rng_uniform(rng, KBJ_RNG_OBS_NOISE, st, 20 + u, -c.jvel_noise, c.jvel_noise) : 0.0f);
-    actor[u] = (qn - m.joint_bias[u]) / range; actor[20 + u] = vn / 10;
-    critic[u] = (q - m.joint_bias[u]) / range; critic[20 + u] = v / 10;
-    critic[454 + u] = S.qfrc_act[6 + u] / 4;
+    actor[KBJ_OBS_JPOS + u] = (qn - m.joint_bias[u]) / range; actor[KBJ_OBS_JVEL + u] = vn / KBJ_OBS_JVEL_DIV;
+    critic[KBJ_OBS_JPOS + u] = (q - m.joint_bias[u]) / range; critic[KBJ_OBS_JVEL + u] = v / KBJ_OBS_JVEL_DIV;
+    critic[KBJ_OBS_ACTFRC + u] = S.qfrc_act[6 + u] / KBJ_OBS_ACTFRC_DIV;
   }
   PFOR(w, 4) {
     if (w == 0) {  // lagged / biased / noisy projected gravity for the actor, clean one for the critic
@@ -207,22 +207,22 @@ KBJ_DEV void task_write_obs(KbjShared& S, const kbj_model& m, const kbj_config& 
         pgn[k] = pgl + S.ep[KBJ_EP_PGBIAS + k] + (noise ? c.pg_noise_std * rng_normal(rng, KBJ_RNG_OBS_NOISE, st, 43 + k) : 0.0f);
       }
       encode_pg(pgn, o);
-      for (int k = 0; k < 5; ++k) actor[40 + k] = o[k];
+      for (int k = 0; k < 5; ++k) actor[KBJ_OBS_PG + k] = o[k];
       encode_pg(S.pg, o);
-      for (int k = 0; k < 5; ++k) critic[40 + k] = o[k];
+      for (int k = 0; k < 5; ++k) critic[KBJ_OBS_PG + k] = o[k];
       for (int k = 0; k < 3; ++k) {
-        actor[45 + k] = S.gyro[k] + (noise ? c.gyro_noise_std * rng_normal(rng, KBJ_RNG_OBS_NOISE, st, 40 + k) : 0.0f);
-        critic[45 + k] = S.gyro[k];
+        actor[KBJ_OBS_GYRO + k] = S.gyro[k] + (noise ? c.gyro_noise_std * rng_normal(rng, KBJ_RNG_OBS_NOISE, st, 40 + k) : 0.0f);
+        critic[KBJ_OBS_GYRO + k] = S.gyro[k];
       }
     } else if (w == 1) {
-      actor[48] = zc; critic[48] = zc;
+      actor[KBJ_OBS_ZEROCMD] = zc; critic[KBJ_OBS_ZEROCMD] = zc;
       for (int k = KBJ_NOBS_ACTOR; k < KBJ_LD_ACTOR; ++k) actor[k] = 0;
       for (int k = KBJ_NOBS_CRITIC; k < KBJ_LD_CRITIC; ++k) critic[k] = 0;
-      critic[65] = S.touch[0]; critic[66] = S.touch[1];
+      critic[KBJ_OBS_TOUCH] = S.touch[0]; critic[KBJ_OBS_TOUCH + 1] = S.touch[1];
       aux[KBJ_AUX_TOUCH] = S.touch[0]; aux[KBJ_AUX_TOUCH + 1] = S.touch[1];
-      for (int k = 0; k < 3; ++k) { critic[73 + k] = es[KBJ_ES_QPOS + k]; critic[448 + k] = es[KBJ_ES_QVEL + k]; critic[451 + k] = es[KBJ_ES_QVEL + 3 + k]; }
-      for (int k = 0; k < 4; ++k) critic[76 + k] = es[KBJ_ES_QPOS + 3 + k];
-      critic[474] = S.xpos[1][2];  // BaseHeightObservation (train.py:706-707)
+      for (int k = 0; k < 3; ++k) { critic[KBJ_OBS_BASEPOS + k] = es[KBJ_ES_QPOS + k]; critic[KBJ_OBS_LINVEL + k] = es[KBJ_ES_QVEL + k]; critic[KBJ_OBS_ANGVEL + k] = es[KBJ_ES_QVEL + 3 + k]; }
+      for (int k = 0; k < 4; ++k) critic[KBJ_OBS_BASEQUAT + k] = es[KBJ_ES_QPOS + 3 + k];
+      critic[KBJ_OBS_HEIGHT] = S.xpos[1][2];  // BaseHeightObservation (train.py:706-707)
     } else if (w == 2) {  // FeetPositionObservation (train.py:682-699)
       float e[3], yq[4];
       quat_to_euler(S.xquat[1], e);
@@ -232,13 +232,13 @@ KBJ_DEV void task_write_obs(KbjShared& S, const kbj_model& m, const kbj_config& 
         int fb = f ? 12 : 7;
         float rel[3] = {S.xpos[fb][0] - S.xpos[1][0], S.xpos[fb][1] - S.xpos[1][1], S.xpos[fb][2] - S.xpos[1][2]}, o[3];
         rotate_by_quat(rel, yq, true, o);
-        for (int k = 0; k < 3; ++k) critic[67 + 3 * f + k] = o[k];
+        for (int k = 0; k < 3; ++k) critic[KBJ_OBS_FEETPOS + 3 * f + k] = o[k];
       }
     } else aux[KBJ_AUX_COMDIST] = task_com_distance(S);
   }
-  PFOR(k, KBJ_NCMD) { actor[49 + k] = cmd[k]; critic[49 + k] = cmd[k]; aux[KBJ_AUX_CMD + k] = cmd[k]; }
-  PFOR(k, 230) critic[80 + k] = S.cinert[1 + k / 10][k % 10];
-  PFOR(k, 138) critic[310 + k] = S.cvel[1 + k / 6][k % 6];
+  PFOR(k, KBJ_NCMD) { actor[KBJ_OBS_CMD + k] = cmd[k]; critic[KBJ_OBS_CMD + k] = cmd[k]; aux[KBJ_AUX_CMD + k] = cmd[k]; }
+  PFOR(k, 230) critic[KBJ_OBS_CINERT + k] = S.cinert[1 + k / 10][k % 10];
+  PFOR(k, 138) critic[KBJ_OBS_CVEL + k] = S.cvel[1 + k / 6][k % 6];
   KBJ_SYNC();
 }
 

@@ -37,6 +37,13 @@ constexpr int SEQ_UNITS = 16;  // hidden units per workgroup
 #endif
 constexpr unsigned SEQ_SPIN_LIMIT = 1u << 24;   // default bound of every inter-workgroup spin (args.spin_limit; shorter under fault injection)
 
+// Register budget of the backward recurrence: at <= 176 allocated VGPRs two of its waves AND two waves of a weight-gradient GEMM
+// workgroup (80) share a SIMD (2 x 176 + 2 x 80 = 512), which is what lets those GEMMs run beside the layer-0 recurrences (DESIGN.md
+// section 10); amdgpu_num_vgpr(N) makes hipcc allocate 2 N for a wave64 kernel.
+#ifndef KBJ_SEQ_BWD_NUM_VGPR
+#define KBJ_SEQ_BWD_NUM_VGPR 88
+#endif
+
 struct SeqFwdArgs {
   float* G;            // [T][B][4H] in: x W_ih^T + b, out: gate activations (i,f,g,o)
   const float* Whh;    // [4H][H]
@@ -106,8 +113,46 @@ __device__ __forceinline__ void seq_publish(unsigned* my_flag, unsigned steps_do
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(my_flag, steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 store, never a plain one
 }
+// k order of the register-resident products. The A operand of v_mfma_f32_16x16x4_f32 is one float per lane (row = lane & 15,
+// k slot g = lane >> 4); WHICH k a slot holds in a given step is free as long as the B registers (the weight slices) use the same
+// order. Fragments are fetched as 16-byte ds_read_b128 (k = 16 j + 4 g + p feeds step 4 j + p): a quarter of the LDS instructions of
+// the one-float form, and with a row stride = 8 (mod 16) words the 16 lanes of every b128 lane group fall on 64 distinct banks
+// (MI355X_MICROARCH.md, LDS: the former stride H + 4 with ds_read_b32 was 2-way conflicted on 32 banks, SQ_LDS_BANK_CONFLICT /
+// SQ_LDS_IDX_ACTIVE 0.39-0.46 in profiles/r02b_pmc_mfma.json). A width that is not a multiple of 16 (the 68-float observation
+// row) ends in single-float steps (k = 16 NB + 4 q + g).
+template <int K> struct SeqK {
+  static_assert(K % 4 == 0, "row width must be a multiple of 4");
+  static constexpr int NB = K / 16, REM = (K % 16) / 4, STEPS = 4 * NB + REM;
+  static constexpr int LD = (K + 7) / 16 * 16 + 8;   // smallest row stride >= K that is 8 (mod 16)
+  __host__ __device__ static constexpr int kidx(int s, int g) { return s < 4 * NB ? 16 * (s / 4) + 4 * g + (s % 4) : 16 * NB + 4 * (s - 4 * NB) + g; }
+  // acc0 / acc1 += A[rows 0-15 / 16-31][k of blocks jb..je) (and the tail steps when `tail`)] * w; lds: tile [32][LD], w: this lane's STEPS registers
+  template <bool TAIL>
+  __device__ static __forceinline__ void mma(const float* lds, int lane, const float* w, f32x4m& acc0, f32x4m& acc1, int jb, int je) {
+    const float* p0 = lds + (lane & 15) * LD + 4 * (lane >> 4);
+    const float* p1 = p0 + 16 * LD;
+#pragma unroll
+    for (int j = jb; j < je; ++j) {
+      const f32x4m a0 = *reinterpret_cast<const f32x4m*>(p0 + 16 * j), a1 = *reinterpret_cast<const f32x4m*>(p1 + 16 * j);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[q], w[4 * j + q], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[q], w[4 * j + q], acc1, 0, 0, 0);
+      }
+    }
+    if (TAIL) {
+      const float* r0 = lds + (lane & 15) * LD + 16 * NB + (lane >> 4);
+      const float* r1 = r0 + 16 * LD;
+#pragma unroll
+      for (int q = 0; q < REM; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(r0[4 * q], w[4 * NB + q], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(r1[4 * q], w[4 * NB + q], acc1, 0, 0, 0);
+      }
+    }
+  }
+};
+
 // payload tile: rows [r0, r0+32) x H floats of a handed-off [B][ld] array, 16-byte buffer loads with the sc1 bit
-// (aux = 16: bypass this CU's L1; counted by the compiler's s_waitcnt), then written to LDS as [32][H+4]
+// (aux = 16: bypass this CU's L1; counted by the compiler's s_waitcnt), then written to LDS as [32][SeqK<H>::LD]
 template <int H, int NTH> struct SeqTile {
   static constexpr int NQ = SEQ_ROWS * (H / 4);          // 16-byte elements of the tile
   static constexpr int NV = (NQ + NTH - 1) / NTH;
@@ -139,7 +184,7 @@ template <int H, int NTH> struct SeqTile {
     for (int i = 0; i < NV; ++i) {
       int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4);
       if (!EXACT && q >= NQ) continue;
-      *reinterpret_cast<f32x4m*>(lds + row * (H + 4) + 4 * c4) = r0 + row < B ? v[i] : f32x4m{0, 0, 0, 0};
+      *reinterpret_cast<f32x4m*>(lds + row * SeqK<H>::LD + 4 * c4) = r0 + row < B ? v[i] : f32x4m{0, 0, 0, 0};
     }
   }
   // the same with columns >= ncol forced to zero (padded input rows whose padding is not ours to trust)
@@ -167,16 +212,17 @@ template <int H, int NTH> struct SeqTile {
 template <int H, int UW, bool FUSE = false, int KX = H>
 __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW;
-  constexpr int LDH = H + 4, KXS = KX / 4;
-  constexpr int LDX = KX % 64 == 4 ? KX : KX + 4;   // row stride = 4 mod 64 words: the 16 rows of an A fragment land in 16 different bank groups
+  typedef SeqK<H> KH;
+  typedef SeqK<KX> KXK;
+  constexpr int LDH = KH::LD, KXS = KXK::STEPS, LDX = KXK::LD;   // row strides = 8 (mod 16) words: conflict-free ds_read_b128 fragments (SeqK)
   constexpr int NUG = H / UNITS;
 #ifndef KBJ_SEQ_XSPLIT_NUM
 #define KBJ_SEQ_XSPLIT_NUM 4   // eighths of the input projection's k-steps issued before the flag poll (the rest hides the tile fetch)
 #endif
-  constexpr int XSPLIT = KXS * KBJ_SEQ_XSPLIT_NUM / 8;
+  constexpr int XSPLIT = KXK::NB * KBJ_SEQ_XSPLIT_NUM / 8;   // in 16-k blocks
   __shared__ __attribute__((aligned(16))) float hs[SEQ_ROWS * LDH];
   __shared__ __attribute__((aligned(16))) float xs[FUSE ? SEQ_ROWS * LDX : 4];
-  __shared__ float gbuf[4][SEQ_ROWS][UNITS + 1];
+  __shared__ float gbuf[4][SEQ_ROWS][UNITS + 4];   // row stride = 4 (mod 8): the accumulator rows of lanes 0-15 / 16-31 (4 rows apart) fall on disjoint banks
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, gate = (tid >> 6) & 3, uh = tid >> 8;
   // XCD-aware mapping (speed only, the protocol is placement independent): workgroups b, b+8, b+16, ... share an XCD,
@@ -186,21 +232,21 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
-  // W_hh rows of this wave's gate for the 16 units, as B operands: B[k][col] = Whh[gate H + u0 + col][k]
+  // W_hh rows of this wave's gate for the 16 units, as B operands: B[k slot g][col] = Whh[gate H + u0 + col][KH::kidx(step, g)]
   float wreg[H / 4];
   {
-    const float* wrow = a.Whh + (size_t)(gate * H + u0 + SEQ_UNITS * uh + (lane & 15)) * H + (lane >> 4);
+    const float* wrow = a.Whh + (size_t)(gate * H + u0 + SEQ_UNITS * uh + (lane & 15)) * H;
 #pragma unroll
-    for (int s = 0; s < H / 4; ++s) wreg[s] = wrow[4 * s];
+    for (int s = 0; s < H / 4; ++s) wreg[s] = wrow[KH::kidx(s, lane >> 4)];
   }
   float wxreg[FUSE ? KXS : 1];
   float bias_col = 0.0f;
   const int ldx = a.ldx ? a.ldx : H, kxv = a.kx ? a.kx : KX;
   if (FUSE) {
     const int grow = gate * H + u0 + SEQ_UNITS * uh + (lane & 15);
-    const float* wrow = a.Wih + (size_t)grow * (a.ldw ? a.ldw : H) + (lane >> 4);
+    const float* wrow = a.Wih + (size_t)grow * (a.ldw ? a.ldw : H);
 #pragma unroll
-    for (int s = 0; s < KXS; ++s) wxreg[s] = 4 * s + (lane >> 4) < kxv ? wrow[4 * s] : 0.0f;
+    for (int s = 0; s < KXS; ++s) { const int k = KXK::kidx(s, lane >> 4); wxreg[s] = k < kxv ? wrow[k] : 0.0f; }
     bias_col = a.bias[grow];
   }
   // the two (row, unit) elements of this thread in the cell epilogue and their cell state
@@ -234,10 +280,6 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     }
   };
   fetch_inputs(0);
-  const float* a0p = hs + (lane & 15) * LDH + (lane >> 4);
-  const float* a1p = a0p + 16 * LDH;
-  const float* x0p = xs + (lane & 15) * LDX + (lane >> 4);
-  const float* x1p = x0p + 16 * LDX;
   if (FUSE) {   // x_0 tile
     SeqTile<KX, NTH> xt;
     xt.load_plain(a.X, ldx, r0, B);
@@ -251,11 +293,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     for (int i = 0; i < 2; ++i) { kp[i] = kpn[i]; for (int k = 0; k < 4; ++k) gx[i][k] = gxn[i][k]; }
     f32x4m acc0 = {bias_col, bias_col, bias_col, bias_col}, acc1 = acc0;
     if (FUSE) {   // first half of the input projection: runs while the partners' flags travel
-#pragma unroll
-      for (int s = 0; s < XSPLIT; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
-      }
+      KXK::template mma<false>(xs, lane, wxreg, acc0, acc1, 0, XSPLIT);
     }
     if (t > 0) { if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)t, a.err, &flag, a.spin_limit)) return; }
     SEQ_STAMP(1);
@@ -264,11 +302,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     if (FUSE) {   // second half of the input projection: hides the h-tile fetch (the scheduling fences keep the compiler from hoisting the
                   // tile's LDS stores - and the vmcnt wait in front of them - above these MFMAs)
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s = XSPLIT; s < KXS; ++s) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
-      }
+      KXK::template mma<true>(xs, lane, wxreg, acc0, acc1, XSPLIT, KXK::NB);
       __builtin_amdgcn_sched_barrier(0);
     }
     tile.to_lds(hs, r0, B);
@@ -291,11 +325,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     if (FUSE && t + 1 < T) xt.load_plain(a.X + (size_t)(t + 1) * B * ldx, ldx, r0, B);   // next step's input tile rides behind the recurrent MFMAs
     __syncthreads();
     SEQ_STAMP(2);
-#pragma unroll
-    for (int s = 0; s < H / 4; ++s) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * s], wreg[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * s], wreg[s], acc1, 0, 0, 0);
-    }
+    KH::template mma<false>(hs, lane, wreg, acc0, acc1, 0, KH::NB);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       gbuf[gate][(lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc0[r];
@@ -332,14 +362,15 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
 }
 
 template <int H, int UW>
-__global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
+__global__ __launch_bounds__(256 * UW) __attribute__((amdgpu_num_vgpr(KBJ_SEQ_BWD_NUM_VGPR))) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW;
-  constexpr int LDH = H + 4;
+  typedef SeqK<H> KH;
+  constexpr int LDH = KH::LD;
   constexpr int NUG = H / UNITS;
-  // one gate chunk of dG_{t+1} at a time: a single 33 KB buffer (plus pbuf) keeps the workgroup at 42 KB of LDS so that two
+  // one gate chunk of dG_{t+1} at a time: a single 34 KB buffer (plus pbuf) keeps the workgroup at 52 KB of LDS so that two
   // recurrences (actor + critic) AND two GEMM workgroups fit on a CU together (profiles/r01: double buffering starved the GEMMs)
   __shared__ __attribute__((aligned(16))) float ds[SEQ_ROWS * LDH];
-  __shared__ float pbuf[4][SEQ_ROWS][UNITS + 1];                     // per-wave partial sums of dh
+  __shared__ float pbuf[4][SEQ_ROWS][UNITS + 4];                     // per-wave partial sums of dh (row stride = 4 mod 8, as gbuf above)
   __shared__ int flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, uh = tid >> 8;   // wave: k quarter, uh: 16-unit half
   // XCD-aware mapping (speed only, the protocol is placement independent): workgroups b, b+8, b+16, ... share an XCD,
@@ -352,12 +383,14 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
   if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x] = wall_clock64();   // per-workgroup entry / loop start / exit
   constexpr int KW = H / 4;        // k range of one wave inside a gate chunk
   constexpr int KS = KW / 4;       // k-steps per (wave, gate chunk)
-  // B operands: for gate chunk c and k-step s: B[k][col] = Whh[c H + wave KW + 4 s + (lane>>4)][u0 + col]
+  typedef SeqK<KW> KWK;            // k order inside the wave's range (KW is a multiple of 16 for every served H)
+  static_assert(KW % 16 == 0, "the backward recurrence fetches its fragments in 16-k blocks");
+  // B operands: for gate chunk c and k-step s: B[k slot g][col] = Whh[c H + wave KW + KWK::kidx(s, g)][u0 + col]
   float wreg[4][KS];
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int s = 0; s < KS; ++s) wreg[c][s] = a.Whh[(size_t)(c * H + wave * KW + 4 * s + (lane >> 4)) * H + u0 + SEQ_UNITS * uh + (lane & 15)];
+    for (int s = 0; s < KS; ++s) wreg[c][s] = a.Whh[(size_t)(c * H + wave * KW + KWK::kidx(s, lane >> 4)) * H + u0 + SEQ_UNITS * uh + (lane & 15)];
   int erow[2], eunit[2];
   float dcm[2] = {0.0f, 0.0f};
   float bsum[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // running column sums of dG (bias gradient)
@@ -411,12 +444,16 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
                            // anything issued between a chunk's loads and its wait is waited for too); they land during the cell and the hand-off
         __syncthreads();
         SEQ_BSTAMP(2 + c);
-        const float* a0p = buf + (lane & 15) * LDH + wave * KW + (lane >> 4);
+        const float* a0p = buf + (lane & 15) * LDH + wave * KW + 4 * (lane >> 4);
         const float* a1p = a0p + 16 * LDH;
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * s], wreg[c][s], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * s], wreg[c][s], acc1, 0, 0, 0);
+        for (int j = 0; j < KW / 16; ++j) {
+          const f32x4m f0 = *reinterpret_cast<const f32x4m*>(a0p + 16 * j), f1 = *reinterpret_cast<const f32x4m*>(a1p + 16 * j);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(f0[q], wreg[c][4 * j + q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(f1[q], wreg[c][4 * j + q], acc1, 0, 0, 0);
+          }
         }
       }
 #pragma unroll
@@ -488,11 +525,12 @@ struct StepArgs {
 template <int H, int UW, int KX = H>
 __global__ __launch_bounds__(256 * UW) void lstm_step_kernel(StepArgs a) {
   constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW;
-  constexpr int LDH = H + 4, KXS = KX / 4, NUG = H / UNITS;
-  constexpr int LDX = KX % 64 == 4 ? KX : KX + 4;
+  typedef SeqK<H> KH;
+  typedef SeqK<KX> KXK;
+  constexpr int LDH = KH::LD, KXS = KXK::STEPS, LDX = KXK::LD, NUG = H / UNITS;
   __shared__ __attribute__((aligned(16))) float hs[SEQ_ROWS * LDH];
   __shared__ __attribute__((aligned(16))) float xs[SEQ_ROWS * LDX];
-  __shared__ float gbuf[4][SEQ_ROWS][UNITS + 1];
+  __shared__ float gbuf[4][SEQ_ROWS][UNITS + 4];
   const int tid = threadIdx.x, lane = tid & 63, gate = (tid >> 6) & 3, uh = tid >> 8;
   const int ug = blockIdx.x % NUG, chunk = blockIdx.x / NUG, nchunk = gridDim.x / NUG;
   const int u0 = ug * UNITS, M = a.M, nrg = (M + SEQ_ROWS - 1) / SEQ_ROWS;
@@ -500,21 +538,17 @@ __global__ __launch_bounds__(256 * UW) void lstm_step_kernel(StepArgs a) {
   const int grow = gate * H + u0 + SEQ_UNITS * uh + (lane & 15);
   float wreg[H / 4], wxreg[KXS];
   {
-    const float* wrow = a.Whh + (size_t)grow * H + (lane >> 4);
+    const float* wrow = a.Whh + (size_t)grow * H;
 #pragma unroll
-    for (int s = 0; s < H / 4; ++s) wreg[s] = wrow[4 * s];
-    const float* xrow = a.Wih + (size_t)grow * a.ldw + (lane >> 4);
+    for (int s = 0; s < H / 4; ++s) wreg[s] = wrow[KH::kidx(s, lane >> 4)];
+    const float* xrow = a.Wih + (size_t)grow * a.ldw;
 #pragma unroll
-    for (int s = 0; s < KXS; ++s) wxreg[s] = 4 * s + (lane >> 4) < kxv ? xrow[4 * s] : 0.0f;
+    for (int s = 0; s < KXS; ++s) { const int k = KXK::kidx(s, lane >> 4); wxreg[s] = k < kxv ? xrow[k] : 0.0f; }
   }
   const float bias_col = a.bias[grow];
   int erow[2], eunit[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) { int e = tid + NTH * i; erow[i] = e / UNITS; eunit[i] = e % UNITS; }
-  const float* a0p = hs + (lane & 15) * LDH + (lane >> 4);
-  const float* a1p = a0p + 16 * LDH;
-  const float* x0p = xs + (lane & 15) * LDX + (lane >> 4);
-  const float* x1p = x0p + 16 * LDX;
   SeqTile<KX, NTH> xt;
   SeqTile<H, NTH> ht;
   float cn[2] = {0.0f, 0.0f};
@@ -535,16 +569,8 @@ __global__ __launch_bounds__(256 * UW) void lstm_step_kernel(StepArgs a) {
     __syncthreads();
     if (rg + nchunk < nrg) fetch(rg + nchunk);
     f32x4m acc0 = {bias_col, bias_col, bias_col, bias_col}, acc1 = acc0;
-#pragma unroll
-    for (int s = 0; s < KXS; ++s) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(x0p[4 * s], wxreg[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(x1p[4 * s], wxreg[s], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int s = 0; s < H / 4; ++s) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0p[4 * s], wreg[s], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1p[4 * s], wreg[s], acc1, 0, 0, 0);
-    }
+    KXK::template mma<true>(xs, lane, wxreg, acc0, acc1, 0, KXK::NB);
+    KH::template mma<false>(hs, lane, wreg, acc0, acc1, 0, KH::NB);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       gbuf[gate][(lane >> 4) * 4 + r][SEQ_UNITS * uh + (lane & 15)] = acc0[r];

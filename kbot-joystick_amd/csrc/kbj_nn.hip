@@ -89,30 +89,32 @@ void build_mirror_tables(const kbj_model& m, std::vector<MirrorEntry>& ta, std::
   for (int i = 0; i < KBJ_NU; ++i) {
     int s = swp(i);
     auto rng = [&](int j) { return std::fmax(m.joint_bias[j] - m.joint_lo[j], m.joint_hi[j] - m.joint_bias[j]); };
-    tc[i] = MirrorEntry{s, -rng(s) / rng(i), (-m.joint_bias[s] - m.joint_bias[i]) / rng(i)};   // normalised joint positions
-    tc[20 + i] = MirrorEntry{20 + s, -1.0f, 0.0f};                                                // joint velocities / 10
-    tc[454 + i] = MirrorEntry{454 + s, -1.0f, 0.0f};                                              // actuator force / 4 (critic)
+    tc[KBJ_OBS_JPOS + i] = MirrorEntry{KBJ_OBS_JPOS + s, -rng(s) / rng(i), (-m.joint_bias[s] - m.joint_bias[i]) / rng(i)};   // normalised joint positions
+    tc[KBJ_OBS_JVEL + i] = MirrorEntry{KBJ_OBS_JVEL + s, -1.0f, 0.0f};                                                      // joint velocities / 10
+    tc[KBJ_OBS_ACTFRC + i] = MirrorEntry{KBJ_OBS_ACTFRC + s, -1.0f, 0.0f};                                                  // actuator force / 4 (critic)
   }
-  keep(40, -1); keep(41, 1); keep(42, 1); keep(43, -1); keep(44, 1);       // roll, pitch, unit projected gravity
-  keep(45, -1); keep(46, 1); keep(47, -1);                                   // gyro
-  keep(48, 1);                                                               // zero-command flag
+  // roll, pitch, unit projected gravity: the reference mirrors the raw vector (g0, -g1, g2) and encodes it again (train.py:1596-1603,
+  // 1338-1349): roll = atan2(g1, -g2) changes sign, pitch and the norm do not
+  keep(KBJ_OBS_PG, -1); keep(KBJ_OBS_PG + 1, 1); keep(KBJ_OBS_PG + 2, 1); keep(KBJ_OBS_PG + 3, -1); keep(KBJ_OBS_PG + 4, 1);
+  keep(KBJ_OBS_GYRO, -1); keep(KBJ_OBS_GYRO + 1, 1); keep(KBJ_OBS_GYRO + 2, -1);   // gyro
+  keep(KBJ_OBS_ZEROCMD, 1);                                                          // zero-command flag (the norm of cmd[0:3] is mirror invariant)
   const float cs[16] = {1, -1, -1, 1, -1, 1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};   // vx, vy, wz, height, roll, pitch, 10 arm targets
-  for (int k = 0; k < 16; ++k) keep(49 + k, cs[k]);
+  for (int k = 0; k < 16; ++k) keep(KBJ_OBS_CMD + k, cs[k]);
   ta.assign(tc.begin(), tc.begin() + KBJ_LD_ACTOR);
   for (int k = KBJ_NOBS_ACTOR; k < KBJ_LD_ACTOR; ++k) ta[k] = MirrorEntry{k, 0.0f, 0.0f};
-  tc[65] = MirrorEntry{66, 1, 0}; tc[66] = MirrorEntry{65, 1, 0};           // foot touch L <-> R
+  tc[KBJ_OBS_TOUCH] = MirrorEntry{KBJ_OBS_TOUCH + 1, 1, 0}; tc[KBJ_OBS_TOUCH + 1] = MirrorEntry{KBJ_OBS_TOUCH, 1, 0};           // foot touch L <-> R
   const float fs[3] = {1, -1, 1};
-  for (int k = 0; k < 3; ++k) { tc[67 + k] = MirrorEntry{70 + k, fs[k], 0}; tc[70 + k] = MirrorEntry{67 + k, fs[k], 0}; }   // feet positions
-  keep(73, 1); keep(74, 1); keep(75, 1);                                      // base position
-  keep(76, 1); keep(77, -1); keep(78, -1); keep(79, 1);                      // base quaternion
+  for (int k = 0; k < 3; ++k) { tc[KBJ_OBS_FEETPOS + k] = MirrorEntry{KBJ_OBS_FEETPOS + 3 + k, fs[k], 0}; tc[KBJ_OBS_FEETPOS + 3 + k] = MirrorEntry{KBJ_OBS_FEETPOS + k, fs[k], 0}; }   // feet positions
+  keep(KBJ_OBS_BASEPOS, 1); keep(KBJ_OBS_BASEPOS + 1, 1); keep(KBJ_OBS_BASEPOS + 2, 1);                                      // base position
+  keep(KBJ_OBS_BASEQUAT, 1); keep(KBJ_OBS_BASEQUAT + 1, -1); keep(KBJ_OBS_BASEQUAT + 2, -1); keep(KBJ_OBS_BASEQUAT + 3, 1);  // base quaternion
   const float ci[10] = {1, 1, -1, 1, 1, 1, 1, -1, 1, -1}, cv[6] = {1, -1, 1, -1, 1, -1};
   for (int b = 0; b < 23; ++b) {
-    for (int k = 0; k < 10; ++k) keep(80 + 10 * b + k, ci[k]);                // cinert
-    for (int k = 0; k < 6; ++k) keep(310 + 6 * b + k, cv[k]);                 // cvel
+    for (int k = 0; k < 10; ++k) keep(KBJ_OBS_CINERT + 10 * b + k, ci[k]);      // cinert
+    for (int k = 0; k < 6; ++k) keep(KBJ_OBS_CVEL + 6 * b + k, cv[k]);          // cvel
   }
-  keep(448, 1); keep(449, -1); keep(450, 1);                                  // base linear velocity
-  keep(451, -1); keep(452, 1); keep(453, -1);                                 // base angular velocity
-  keep(474, 1);                                                               // base height
+  keep(KBJ_OBS_LINVEL, 1); keep(KBJ_OBS_LINVEL + 1, -1); keep(KBJ_OBS_LINVEL + 2, 1);     // base linear velocity
+  keep(KBJ_OBS_ANGVEL, -1); keep(KBJ_OBS_ANGVEL + 1, 1); keep(KBJ_OBS_ANGVEL + 2, -1);    // base angular velocity
+  keep(KBJ_OBS_HEIGHT, 1);                                                                 // base height
   for (int k = KBJ_NOBS_CRITIC; k < KBJ_LD_CRITIC; ++k) tc[k] = MirrorEntry{k, 0.0f, 0.0f};
 }
 
@@ -169,8 +171,10 @@ void linear_bwd_weight2(hipStream_t s, const float* dy, int lddy, const float* x
   gemm_launch<false, false>(s, g, big ? 1 : 0);
 }
 
-// wavefronts per recurrence workgroup: 4 (16 hidden units) or 8 (32 units, KBJ_SEQ_UW=2, default) — see kbj_lstm_seq.h
-int g_seq_uw = 2;
+// recurrence workgroups are 8 wavefronts owning 32 hidden units (kbj_lstm_seq.h; the 4-wavefront / 16-unit form of round 1 is gone:
+// slower in situ at every size)
+constexpr int SEQ_UW = 2;
+constexpr int SEQ_COUNTER_WORDS = 256;   // hand-off words per recurrence launch (one per workgroup): the grid of a launch may not exceed it
 // fault injection for the tests (KBJ_DEBUG_DROP_SEQ_WG = n at kbj_create): the next n forward-recurrence launches run with one
 // workgroup missing, so its partners' bounded spins expire and the timeout / fail-stop path is exercised on real hardware
 int g_seq_drop = 0;
@@ -192,33 +196,39 @@ template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0
 }
 int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {   // a.counters: zeroed by the caller
   KbjKernelTimer timer(st, a.X ? (a.ldx == KBJ_LD_ACTOR ? KBJ_KIND_SEQ_FWD_OBS : KBJ_KIND_SEQ_FWD_FUSED) : KBJ_KIND_SEQ_FWD, 2.0 * a.T * a.B * 4.0 * H * (H + (a.X ? (a.kx ? a.kx : H) : 0)));
-  switch (H * 10 + g_seq_uw) {
-    case 641: seq_fwd_launch<64, 1>(st, a); break;
-    case 642: seq_fwd_launch<64, 2>(st, a); break;
-    case 1281: seq_fwd_launch<128, 1>(st, a); break;
-    case 1282: seq_fwd_launch<128, 2>(st, a); break;
-    case 1921: seq_fwd_launch<192, 1>(st, a); break;
-    case 1922: seq_fwd_launch<192, 2>(st, a); break;
-    case 2561: seq_fwd_launch<256, 1>(st, a); break;
-    case 2562: seq_fwd_launch<256, 2>(st, a); break;
+  switch (H) {
+    case 64: seq_fwd_launch<64, SEQ_UW>(st, a); break;
+    case 128: seq_fwd_launch<128, SEQ_UW>(st, a); break;
+    case 192: seq_fwd_launch<192, SEQ_UW>(st, a); break;
+    case 256: seq_fwd_launch<256, SEQ_UW>(st, a); break;
     default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 192, 256");
   }
   return 0;
 }
 int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {   // a.counters: zeroed by the caller
   KbjKernelTimer timer(st, KBJ_KIND_SEQ_BWD, 2.0 * a.T * a.B * 4.0 * H * H);
-  switch (H * 10 + g_seq_uw) {
-    case 641: seq_bwd_launch<64, 1>(st, a); break;
-    case 642: seq_bwd_launch<64, 2>(st, a); break;
-    case 1281: seq_bwd_launch<128, 1>(st, a); break;
-    case 1282: seq_bwd_launch<128, 2>(st, a); break;
-    case 1921: seq_bwd_launch<192, 1>(st, a); break;
-    case 1922: seq_bwd_launch<192, 2>(st, a); break;
-    case 2561: seq_bwd_launch<256, 1>(st, a); break;
-    case 2562: seq_bwd_launch<256, 2>(st, a); break;
+  switch (H) {
+    case 64: seq_bwd_launch<64, SEQ_UW>(st, a); break;
+    case 128: seq_bwd_launch<128, SEQ_UW>(st, a); break;
+    case 192: seq_bwd_launch<192, SEQ_UW>(st, a); break;
+    case 256: seq_bwd_launch<256, SEQ_UW>(st, a); break;
     default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 192, 256");
   }
   return 0;
+}
+
+// resident workgroups per CU of the recurrence kernel that fits worst, over EVERY recurrence kernel the schedule may launch for this
+// hidden size (fused forward with the hidden-layer input, fused forward from the observation rows, plain forward, backward): in the
+// gfx950 code object the fused forward is the largest (252 VGPRs / 86 KB of LDS at H = 256 against 176 / 52 KB for the backward)
+template <int H> hipError_t seq_min_blocks_per_cu(int* out) {
+  constexpr int threads = 256 * SEQ_UW;
+  int n[4] = {0, 0, 0, 0};
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], lstm_seq_fwd_kernel<H, SEQ_UW, true, H>, threads, 0);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], lstm_seq_fwd_kernel<H, SEQ_UW, true, KBJ_LD_ACTOR>, threads, 0);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[2], lstm_seq_fwd_kernel<H, SEQ_UW, false, H>, threads, 0);
+  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], lstm_seq_bwd_kernel<H, SEQ_UW>, threads, 0);
+  *out = std::min(std::min(n[0], n[1]), std::min(n[2], n[3]));
+  return e;
 }
 
 // one LSTM layer step over many rows (kbj_lstm_seq.h lstm_step_kernel): grid = unit groups x row chunks, about one workgroup per CU
@@ -269,7 +279,7 @@ int kbj_nn_check_errors(kbj_ctx* ctx) {
       hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device);
       if (wall_khz > 0) {   // per-workgroup entry / loop start / exit on the constant-rate clock
         const long long* g = st.data() + (size_t)w->T * 10;
-        int nwg = ((w->B + SEQ_ROWS - 1) / SEQ_ROWS) * (w->H / (SEQ_UNITS * g_seq_uw));
+        int nwg = ((w->B + SEQ_ROWS - 1) / SEQ_ROWS) * (w->H / (SEQ_UNITS * SEQ_UW));
         if (nwg > 256) nwg = 256;
         long long e0 = g[0], e1 = g[0], l1 = g[1], x0 = g[2], x1 = g[2];
         for (int i = 1; i < nwg; ++i) { e0 = std::min(e0, g[3 * i]); e1 = std::max(e1, g[3 * i]); l1 = std::max(l1, g[3 * i + 1]); x0 = std::min(x0, g[3 * i + 2]); x1 = std::max(x1, g[3 * i + 2]); }
@@ -350,44 +360,44 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->Weff, 4 * H * KBJ_LD_ACTOR) || dalloc(ctx, *w, &w->beff, 4 * H)) return -1;
   for (int n = 0; n < w->nnets; ++n) if (dalloc(ctx, *w, &w->Zeff[n], 4 * H * w->net[n & 1].ld_obs)) return -1;
   if (hipMemset(w->Weff, 0, 4 * H * KBJ_LD_ACTOR * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset Weff");
-  if (dalloc(ctx, *w, &w->seq_counters, 2 * MAXD * 4 * 256)) return -1;   // [phase: forward layer l = l, backward layer l = D + l][net][row group x unit group]
+  if (dalloc(ctx, *w, &w->seq_counters, 2 * MAXD * 4 * SEQ_COUNTER_WORDS)) return -1;   // [phase: forward layer l = l, backward layer l = D + l][net][row group x unit group]
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
   if (getenv("KBJ_SEQ_STAMPS")) { if (dalloc(ctx, *w, &w->seq_stamps, (size_t)T * 6)) return -1; }
   if (getenv("KBJ_SEQ_BSTAMPS")) { if (dalloc(ctx, *w, &w->seq_bstamps, (size_t)T * 10 + 768)) return -1; }
   if (hipMemset(w->seq_err, 0, 4 * sizeof(unsigned)) != hipSuccess) return kbj_fail(ctx, "hipMemset seq_err");
   g_splitk_wgs = getenv("KBJ_SPLITK_WGS") ? atoi(getenv("KBJ_SPLITK_WGS")) : 768;
   g_fold_sk = getenv("KBJ_FOLD_SK") ? std::max(1, atoi(getenv("KBJ_FOLD_SK"))) : 8;
-  g_seq_uw = getenv("KBJ_SEQ_UW") ? atoi(getenv("KBJ_SEQ_UW")) : 2;
-  if (g_seq_uw != 1 && g_seq_uw != 2) return kbj_fail(ctx, "KBJ_SEQ_UW must be 1 or 2");
   g_seq_drop = getenv("KBJ_DEBUG_DROP_SEQ_WG") ? atoi(getenv("KBJ_DEBUG_DROP_SEQ_WG")) : 0;
   g_seq_spin_limit = g_seq_drop > 0 ? (1u << 15) : SEQ_SPIN_LIMIT;   // an injected fault should not cost the full 2^24-spin bound
   // Residency of the persistent recurrences: the workgroups of one launch spin on each other, and kbj_ppo_grad keeps TWO launches
   // (actor-type and critic-type net, one per stream; the mirror branches queue behind them on the same two streams) in flight, so
   // 2 x grid workgroups must be resident at once. Every other kernel of the schedule (GEMMs, heads) terminates on its own, so it can
-  // only delay a recurrence workgroup, never starve it. Slots = what the occupancy query says for the slower-to-fit (backward) kernel.
+  // only delay a recurrence workgroup, never starve it. Slots = the occupancy query's answer for the WORST-fitting recurrence kernel
+  // of this hidden size. Independently, a launch owns SEQ_COUNTER_WORDS hand-off words (one per workgroup): a larger grid would write
+  // into the next launch's block, so it is refused whatever the occupancy says.
   {
-    const int grid = (int)((B + SEQ_ROWS - 1) / SEQ_ROWS) * (int)(H / (SEQ_UNITS * g_seq_uw));
+    const int grid = (int)((B + SEQ_ROWS - 1) / SEQ_ROWS) * (int)(H / (SEQ_UNITS * SEQ_UW));
     int per_cu = 0, cus = 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return kbj_fail(ctx, "hipGetDeviceProperties");
     cus = prop.multiProcessorCount;
     hipError_t oe = hipSuccess;
-    const int threads = 256 * g_seq_uw;
-    switch ((int)H * 10 + g_seq_uw) {
-      case 641: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<64, 1>, threads, 0); break;
-      case 642: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<64, 2>, threads, 0); break;
-      case 1281: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<128, 1>, threads, 0); break;
-      case 1282: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<128, 2>, threads, 0); break;
-      case 1921: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<192, 1>, threads, 0); break;
-      case 1922: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<192, 2>, threads, 0); break;
-      case 2561: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 1>, threads, 0); break;
-      case 2562: oe = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lstm_seq_bwd_kernel<256, 2>, threads, 0); break;
-      default: return kbj_fail(ctx, "kbj_create: hidden_size must be 64, 128 or 256 (persistent LSTM kernels)");
+    switch ((int)H) {
+      case 64: oe = seq_min_blocks_per_cu<64>(&per_cu); break;
+      case 128: oe = seq_min_blocks_per_cu<128>(&per_cu); break;
+      case 192: oe = seq_min_blocks_per_cu<192>(&per_cu); break;
+      case 256: oe = seq_min_blocks_per_cu<256>(&per_cu); break;
+      default: return kbj_fail(ctx, "kbj_create: hidden_size must be 64, 128, 192 or 256 (persistent LSTM kernels)");
     }
-    if (oe != hipSuccess || per_cu < 1) return kbj_fail(ctx, "kbj_create: occupancy query of the persistent LSTM kernel failed");
+    if (oe != hipSuccess || per_cu < 1) return kbj_fail(ctx, "kbj_create: occupancy query of the persistent LSTM kernels failed");
     const long slots = (long)per_cu * cus;
+    char msg[320];
+    if (grid > SEQ_COUNTER_WORDS) {
+      snprintf(msg, sizeof(msg), "kbj_create: a persistent LSTM launch would need %d workgroups (batch_size / 32 x hidden_size / 32), the hand-off "
+               "counters hold %d per launch: lower batch_size", grid, SEQ_COUNTER_WORDS);
+      return kbj_fail(ctx, msg);
+    }
     if (2L * grid > slots) {
-      char msg[256];
       snprintf(msg, sizeof(msg), "kbj_create: two concurrent persistent LSTM launches need 2 x %d resident workgroups, the device holds %ld "
                "(%d per CU x %d CUs): lower batch_size", grid, slots, per_cu, cus);
       return kbj_fail(ctx, msg);
@@ -541,6 +551,15 @@ int carry_h_home(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, kbj_carry*
 
 extern "C" {
 
+int kbj_mirror_table(const void* model_blob, size_t model_bytes, int critic, int32_t* src_h, float* mul_h, float* add_h) {
+  if (!model_blob || !src_h || !mul_h || !add_h || model_bytes != sizeof(kbj_model)) return kbj_fail(nullptr, "kbj_mirror_table: bad argument");
+  std::vector<MirrorEntry> ta, tc;
+  build_mirror_tables(*reinterpret_cast<const kbj_model*>(model_blob), ta, tc);
+  const std::vector<MirrorEntry>& t = critic ? tc : ta;
+  for (size_t k = 0; k < t.size(); ++k) { src_h[k] = t[k].src; mul_h[k] = t[k].mul; add_h[k] = t[k].add; }
+  return (int)t.size();
+}
+
 size_t kbj_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size, cfg->depth); return w.nparams; }
 size_t kbj_actor_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size, cfg->depth); return w.nactor; }
 
@@ -690,7 +709,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   static const bool one_stream = getenv("KBJ_ONE_STREAM") != nullptr;   // diagnostics: serialise the two nets
   hipStream_t ns[2] = {ctx->stream, one_stream ? ctx->stream : ctx->stream2};
   // hand-off counters of all eight (sixteen with the mirror branches) recurrence launches of this call: one clear, ahead of both lanes
-  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, 2 * MAXD * 4 * 256 * sizeof(unsigned), s));
+  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, 2 * MAXD * 4 * SEQ_COUNTER_WORDS * sizeof(unsigned), s));
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   static const bool fold_actor = getenv("KBJ_FOLD_ACTOR") ? atoi(getenv("KBJ_FOLD_ACTOR")) != 0 : true;
@@ -787,7 +806,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
-      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + 256 * (4 * l + n), w.seq_err, T, B, (n == stamp_net && l == stamp_layer) ? w.seq_stamps : nullptr};
+      SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + SEQ_COUNTER_WORDS * (4 * l + n), w.seq_err, T, B, (n == stamp_net && l == stamp_layer) ? w.seq_stamps : nullptr};
       if (fold_actor && (n & 1) == 0 && l == 0) {
         if (fuse_obs) { fa.X = t.obs; fa.ldx = o.ld_obs; fa.Wih = w.Weff; fa.ldw = KBJ_LD_ACTOR; fa.bias = w.beff; fa.kx = o.nin; }   // gates_0 = obs Weff^T + beff inside the recurrence
       } else if (fuse_ih) {   // K = H input projections ride inside the recurrence (kbj_lstm_seq.h FUSE)
@@ -875,7 +894,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
-      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + 256 * (4 * (D + l) + n), w.seq_err, T, B, grad_d + o.b[l]};
+      SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + SEQ_COUNTER_WORDS * (4 * (D + l) + n), w.seq_err, T, B, grad_d + o.b[l]};
       if (w.seq_bstamps && bstamp_sel == 1 + n + 2 * l) ba.stamps = w.seq_bstamps;
       if (seq_bwd(ctx, ns[n & 1], H, ba)) return -1;
     }

@@ -61,6 +61,7 @@ SIGNATURES = {
     "kbj_param_count": (_sz, [_cfgp]),
     "kbj_actor_param_count": (_sz, [_cfgp]),
     "kbj_init_params": (_i, [_vp, _u32, _vp]),
+    "kbj_mirror_table": (_i, [_vp, _sz, _i, _vp, _vp, _vp]),
     "kbj_policy_step": (_i, [_vp, _vp, _vp, _vp, C.POINTER(Carry), _u32, _u32, _i, _vp, _vp, _vp]),
     "kbj_carry_reset": (_i, [_vp, C.POINTER(Carry), _vp, _i]),
     "kbj_rollout": (_i, [_vp, _vp, C.POINTER(Carry), _u32, _u32, C.POINTER(Traj)]),
@@ -100,6 +101,17 @@ def load_library() -> C.CDLL:
             fn.restype, fn.argtypes = res, args
         _lib = lib
     return _lib
+
+
+def mirror_table(model, critic: bool):
+    """kbj_mirror_table: (src, mul, add) arrays of the packed-row mirror the kernels apply (host-only call, no device needed)."""
+    import numpy as np
+    n = L.LD_CRITIC if critic else L.LD_ACTOR
+    src, mul, add = np.zeros(n, np.int32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    rc = load_library().kbj_mirror_table(C.addressof(model), C.sizeof(model), int(critic), src.ctypes.data, mul.ctypes.data, add.ctypes.data)
+    if rc != n:
+        raise KbjError(f"kbj_mirror_table returned {rc}, expected {n}")
+    return src, mul, add
 
 
 def _ptr(t):

@@ -29,7 +29,7 @@ def export_actor(path: str, params: np.ndarray, hidden_size: int, depth: int, ct
     """Write the deployable actor: leaves + the constants its forward needs (train.py:913-941) + the I/O contract of convert.py."""
     leaves = actor_leaves(np.asarray(params), hidden_size, depth)
     meta = dict(
-        joint_names=np.array(constants.JOINT_NAMES), command_names=np.array(constants.COMMAND_NAMES),
+        joint_names=np.array(constants.JOINT_NAMES), command_names=np.array(constants.COMMAND_NAMES), step_fn_inputs=np.array(constants.STEP_FN_INPUTS),
         joint_biases=np.asarray(joint_biases, np.float32), hidden_size=hidden_size, depth=depth,
         carry_size=depth * 2 * hidden_size + L.NU, num_inputs=L.NOBS_ACTOR, num_outputs=2 * L.NU, ctrl_dt=ctrl_dt,
         cutoff_frequency=cutoff_frequency, min_std=min_std, max_std=max_std, var_scale=var_scale)

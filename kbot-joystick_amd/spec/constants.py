@@ -49,6 +49,10 @@ COMMAND_NAMES = (
     "lshoulderpitch", "lshoulderroll", "lshoulderyaw", "lelbowpitch", "lwristroll",
 )
 
+# argument order of the deployed step function and what it returns (convert.py:84-119): the first five are concatenated into the
+# 65-float actor row exactly as run_actor packs it, `carry` is the flat (depth, 2, H) LSTM carry followed by the 20 low-pass floats
+STEP_FN_INPUTS = ("joint_angles", "joint_angular_velocities", "projected_gravity", "gyroscope", "command", "carry")
+
 REWARD_NAMES = (
     "linvel", "angvel", "roll_pitch", "base_height", "arm_pos", "single_contact", "no_contact_p",
     "feet_airtime", "feet_orient", "com_distance", "base_accel", "torque",

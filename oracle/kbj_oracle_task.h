@@ -269,19 +269,19 @@ template <class R> struct Env {
       R q = qpos[7 + u], v = qvel[6 + u];
       R qn = q + phy.p.jpbias[u] + (noise ? (R)rng.uf(KBJ_RNG_OBS_NOISE, st, u, -c->jpos_noise, c->jpos_noise) : 0);
       R vn = v + (noise ? (R)rng.uf(KBJ_RNG_OBS_NOISE, st, 20 + u, -c->jvel_noise, c->jvel_noise) : 0);
-      actor[u] = (float)((qn - (R)m->joint_bias[u]) / range); actor[20 + u] = (float)(vn / 10);
-      critic[u] = (float)((q - (R)m->joint_bias[u]) / range); critic[20 + u] = (float)(v / 10);
+      actor[KBJ_OBS_JPOS + u] = (float)((qn - (R)m->joint_bias[u]) / range); actor[KBJ_OBS_JVEL + u] = (float)(vn / KBJ_OBS_JVEL_DIV);
+      critic[KBJ_OBS_JPOS + u] = (float)((q - (R)m->joint_bias[u]) / range); critic[KBJ_OBS_JVEL + u] = (float)(v / KBJ_OBS_JVEL_DIV);
     }
-    enc_pg(pgn, actor + 40); enc_pg(pg, critic + 40);
+    enc_pg(pgn, actor + KBJ_OBS_PG); enc_pg(pg, critic + KBJ_OBS_PG);
     for (int k = 0; k < 3; ++k) {
-      actor[45 + k] = (float)(d.gyro[k] + (noise ? (R)c->gyro_noise_std * rng.normal<R>(KBJ_RNG_OBS_NOISE, st, 40 + k) : 0));
-      critic[45 + k] = (float)d.gyro[k];
+      actor[KBJ_OBS_GYRO + k] = (float)(d.gyro[k] + (noise ? (R)c->gyro_noise_std * rng.normal<R>(KBJ_RNG_OBS_NOISE, st, 40 + k) : 0));
+      critic[KBJ_OBS_GYRO + k] = (float)d.gyro[k];
     }
-    actor[48] = zc; critic[48] = zc;
-    for (int k = 0; k < KBJ_NCMD; ++k) { actor[49 + k] = cmd[k]; critic[49 + k] = cmd[k]; }
+    actor[KBJ_OBS_ZEROCMD] = zc; critic[KBJ_OBS_ZEROCMD] = zc;
+    for (int k = 0; k < KBJ_NCMD; ++k) { actor[KBJ_OBS_CMD + k] = cmd[k]; critic[KBJ_OBS_CMD + k] = cmd[k]; }
     for (int k = KBJ_NOBS_ACTOR; k < KBJ_LD_ACTOR; ++k) actor[k] = 0;
     // privileged block (train.py:1417-1428)
-    critic[65] = (float)d.touch[0]; critic[66] = (float)d.touch[1];
+    critic[KBJ_OBS_TOUCH] = (float)d.touch[0]; critic[KBJ_OBS_TOUCH + 1] = (float)d.touch[1];
     {  // FeetPositionObservation (train.py:682-699)
       int bb = m->base_body;
       R e[3]; quat_to_euler(d.xquat[bb], e);
@@ -290,16 +290,16 @@ template <class R> struct Env {
       for (int f = 0; f < 2; ++f) {
         R rel[3] = {d.xpos[feet[f]][0] - d.xpos[bb][0], d.xpos[feet[f]][1] - d.xpos[bb][1], d.xpos[feet[f]][2] - d.xpos[bb][2]}, o[3];
         rotate_by_quat(rel, yq, true, o);
-        for (int k = 0; k < 3; ++k) critic[67 + 3 * f + k] = (float)o[k];
+        for (int k = 0; k < 3; ++k) critic[KBJ_OBS_FEETPOS + 3 * f + k] = (float)o[k];
       }
     }
-    for (int k = 0; k < 3; ++k) critic[73 + k] = (float)qpos[k];
-    for (int k = 0; k < 4; ++k) critic[76 + k] = (float)qpos[3 + k];
-    for (int b = 1; b < NB; ++b) for (int k = 0; k < 10; ++k) critic[80 + 10 * (b - 1) + k] = (float)d.cinert[b][k];
-    for (int b = 1; b < NB; ++b) for (int k = 0; k < 6; ++k) critic[310 + 6 * (b - 1) + k] = (float)d.cvel[b][k];
-    for (int k = 0; k < 3; ++k) { critic[448 + k] = (float)qvel[k]; critic[451 + k] = (float)qvel[3 + k]; }
-    for (int u = 0; u < NU; ++u) critic[454 + u] = (float)(d.qfrc_actuator[6 + u] / 4);
-    critic[474] = (float)d.xpos[1][2];  // BaseHeightObservation (train.py:706-707)
+    for (int k = 0; k < 3; ++k) critic[KBJ_OBS_BASEPOS + k] = (float)qpos[k];
+    for (int k = 0; k < 4; ++k) critic[KBJ_OBS_BASEQUAT + k] = (float)qpos[3 + k];
+    for (int b = 1; b < NB; ++b) for (int k = 0; k < 10; ++k) critic[KBJ_OBS_CINERT + 10 * (b - 1) + k] = (float)d.cinert[b][k];
+    for (int b = 1; b < NB; ++b) for (int k = 0; k < 6; ++k) critic[KBJ_OBS_CVEL + 6 * (b - 1) + k] = (float)d.cvel[b][k];
+    for (int k = 0; k < 3; ++k) { critic[KBJ_OBS_LINVEL + k] = (float)qvel[k]; critic[KBJ_OBS_ANGVEL + k] = (float)qvel[3 + k]; }
+    for (int u = 0; u < NU; ++u) critic[KBJ_OBS_ACTFRC + u] = (float)(d.qfrc_actuator[6 + u] / KBJ_OBS_ACTFRC_DIV);
+    critic[KBJ_OBS_HEIGHT] = (float)d.xpos[1][2];  // BaseHeightObservation (train.py:706-707)
     for (int k = KBJ_NOBS_CRITIC; k < KBJ_LD_CRITIC; ++k) critic[k] = 0;
     // the pre-step observation fields the reward stack reads
     aux[KBJ_AUX_TOUCH] = (float)d.touch[0]; aux[KBJ_AUX_TOUCH + 1] = (float)d.touch[1];

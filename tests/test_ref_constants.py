@@ -171,3 +171,131 @@ def test_wiring_views_mirror_the_reference_methods(ref, model_full):
     from kbot_joystick_amd.host.task import HumanoidWalkingTask
     for name in list(ref["wiring"]) + ["get_ppo_variables", "get_initial_model_carry", "sample_action", "run_actor", "run_critic", "launch", "load_task", "load_ckpt"]:
         assert callable(getattr(HumanoidWalkingTask, name)), name
+
+
+# ---- structure pins (observation packing order, mirror tables, convert.py's step function): derived from the reference's source text ----
+# reference observation key -> (name in layout.OBS / kbj_model.h KBJ_OBS_*, element offset inside that piece, width of the raw observation)
+NB1 = L.NBODY - 1
+PIECES = {"joint_position": ("JPOS", 0, L.NU), "noisy_biased_joint_position": ("JPOS", 0, L.NU), "joint_velocity": ("JVEL", 0, L.NU),
+          "noisy_joint_velocity": ("JVEL", 0, L.NU), "projected_gravity": ("PG", 0, 3), "noisy_imu_projected_gravity": ("PG", 0, 3),
+          "imu_gyro": ("GYRO", 0, 3), "noisy_imu_gyro": ("GYRO", 0, 3), "zero_cmd": ("ZEROCMD", 0, 1), "unified_command": ("CMD", 0, L.NCMD),
+          "left_foot_touch": ("TOUCH", 0, 1), "right_foot_touch": ("TOUCH", 1, 1), "feet_position": ("FEETPOS", 0, 6), "base_position": ("BASEPOS", 0, 3),
+          "base_orientation": ("BASEQUAT", 0, 4), "center_of_mass_inertia": ("CINERT", 0, 10 * NB1), "center_of_mass_velocity": ("CVEL", 0, 6 * NB1),
+          "base_linear_velocity": ("LINVEL", 0, 3), "base_angular_velocity": ("ANGVEL", 0, 3), "actuator_force": ("ACTFRC", 0, L.NU), "base_height": ("HEIGHT", 0, 1)}
+
+
+def packed_width(entry):
+    return 5 if entry["wrapper"] == "encode_projected_gravity" else PIECES[entry["key"]][2]     # roll, pitch, unit vector (train.py:1338-1349)
+
+
+def test_observation_packing_order_matches_the_reference(ref):
+    """train.py:1351-1433: the order, wrappers and divisors of the concatenated actor / critic vectors give this build's offsets."""
+    pk = ref["packing"]
+    assert pk["encode_projected_gravity_order"] == ["roll", "pitch", "projected_gravity_unit"]
+    assert pk["normalize_joint_vel_divisor"] == L.OBS_JVEL_DIV and pk["zero_cmd"]["threshold"] == 1e-3 and ":3" in pk["zero_cmd"]["expr"]
+    for fn, total in (("run_actor", L.NOBS_ACTOR), ("run_critic", L.NOBS_CRITIC)):
+        off = 0
+        for e in pk[fn]["entries"]:
+            name, sub, _ = PIECES[e["key"]]
+            assert L.OBS[name][0] + sub == off, (fn, e["key"], off)
+            w = packed_width(e)
+            off += w
+            assert {"JPOS": "normalize_joint_pos", "JVEL": "normalize_joint_vel", "PG": "encode_projected_gravity"}.get(name) == e["wrapper"], e
+            assert e["divisor"] == (L.OBS_ACTFRC_DIV if name == "ACTFRC" else None), e
+        assert off == total
+    # the actor row reads the NOISY keys, the critic row the clean ones (train.py:1360-1363, 1388-1391)
+    assert [e["key"] for e in pk["run_actor"]["entries"][:4]] == ["noisy_biased_joint_position", "noisy_joint_velocity", "noisy_imu_projected_gravity", "noisy_imu_gyro"]
+    assert [e["key"] for e in pk["run_critic"]["entries"][:4]] == ["joint_position", "joint_velocity", "projected_gravity", "imu_gyro"]
+    # every piece is contiguous and the table covers the critic row exactly once
+    cover = sorted(L.OBS.values())
+    assert cover[0][0] == 0 and all(a[0] + a[1] == b[0] for a, b in zip(cover, cover[1:])) and cover[-1][0] + cover[-1][1] == L.NOBS_CRITIC
+
+
+def test_header_observation_offsets_equal_layout():
+    import re
+    hdr = open(os.path.join(os.path.dirname(HERE), "include", "kbj_model.h")).read()
+    enums = {k: int(v) for k, v in re.findall(r"KBJ_OBS_([A-Z]+)\s*=\s*(\d+)", hdr)}
+    assert enums == {k: v[0] for k, v in L.OBS.items()}
+    assert float(re.search(r"KBJ_OBS_JVEL_DIV\s+([0-9.]+)f", hdr).group(1)) == L.OBS_JVEL_DIV
+    assert float(re.search(r"KBJ_OBS_ACTFRC_DIV\s+([0-9.]+)f", hdr).group(1)) == L.OBS_ACTFRC_DIV
+
+
+def reference_mirror_table(ref, m, fn):
+    """The packed-row mirror out[k] = mul * in[src] + add implied by mirror_obs / mirror_cmd / mirror_joints (train.py:1574-1756)
+    applied to the row `fn` packs (train.py:1351-1433)."""
+    mir = ref["mirror"]
+    keys = dict(mir["mirror_obs"]["keys"]); keys.update(mir["mirror_cmd"]["keys"])
+    bias = list(m.joint_bias)
+    rng = [max(b - lo, hi - b) for b, lo, hi in zip(m.joint_bias, m.joint_lo, m.joint_hi)]     # normalize_joint_pos, train.py:1329-1333
+    table = {}
+    for e in ref["packing"][fn]["entries"]:
+        name, sub, raw_w = PIECES[e["key"]]
+        base = L.OBS[name][0] + sub
+        if e["key"] == "zero_cmd":       # |cmd[0:3]| is invariant under the sign flips of mirror_cmd
+            assert all(abs(c[0]) == 1 and c[2] == i for i, c in enumerate(keys["unified_command"]["cols"][:3]))
+            table[base] = (base, 1.0, 0.0)
+            continue
+        rec = keys[e["key"]]
+        cols, per_row = rec["cols"], rec["per_row"]
+        if per_row:                       # the same pattern for every body row (train.py:1650, 1668)
+            cols = [[rec["cols"][i % per_row][0], rec["cols"][i % per_row][1], (i // per_row) * per_row + rec["cols"][i % per_row][2]] for i in range(raw_w)]
+        assert len(cols) == raw_w, (e["key"], len(cols))
+        src_of = lambda k, c: L.OBS[PIECES[k][0]][0] + PIECES[k][1] + c
+        if e["wrapper"] == "encode_projected_gravity":
+            assert [(s, c) for s, _, c in cols] == [(1, 0), (-1, 1), (1, 2)]      # g -> (g0, -g1, g2): roll = atan2(g1, -g2) flips, pitch and |g| do not
+            for i, sg in enumerate((-1.0, 1.0, 1.0, -1.0, 1.0)):
+                table[base + i] = (base + i, sg, 0.0)
+            continue
+        for i, (s, k, c) in enumerate(cols):
+            src = src_of(k, c)
+            if e["wrapper"] == "normalize_joint_pos":      # (s (x r_c + b_c) - b_i) / r_i
+                table[base + i] = (src, s * rng[c] / rng[i], (s * bias[c] - bias[i]) / rng[i])
+            else:                                            # plain pieces and pieces divided by the same constant on both sides
+                table[base + i] = (src, float(s), 0.0)
+    return table
+
+
+@pytest.mark.parametrize("critic", [False, True])
+def test_mirror_tables_match_the_reference(ref, model, model_full, critic):
+    """The table the kernels apply (kbj_mirror_table = kbj_nn.hip build_mirror_tables) against the one derived from the reference text."""
+    from kbot_joystick_amd.host import binding
+    mj = ref["mirror"]["mirror_joints"]
+    assert mj["perm"] == [5, 6, 7, 8, 9, 0, 1, 2, 3, 4] + list(range(10, 20)) and set(mj["sign"]) == {-1}
+    for m in (model, model_full):
+        src, mul, add = binding.mirror_table(m, critic)
+        want = reference_mirror_table(ref, m, "run_critic" if critic else "run_actor")
+        n = L.NOBS_CRITIC if critic else L.NOBS_ACTOR
+        assert sorted(want) == list(range(n))
+        for k in range(n):
+            assert src[k] == want[k][0], (k, src[k], want[k])
+            assert abs(mul[k] - want[k][1]) < 1e-6 and abs(add[k] - want[k][2]) < 1e-6, (k, mul[k], add[k], want[k])
+        assert not mul[n:].any() and not add[n:].any()        # row padding mirrors to zero
+
+
+def test_oracle_mirror_equals_the_table(ref, model):
+    """oracle/nn.py mirrors by unpacking / mirroring / re-packing as train.py does; it must agree with the table on random rows."""
+    import numpy as np
+    import torch
+    from kbot_joystick_amd.host import binding
+    from oracle import nn as ON
+    g = torch.Generator().manual_seed(0)
+    for critic, fn, ld in ((False, ON.mirror_actor_obs, L.LD_ACTOR), (True, ON.mirror_critic_obs, L.LD_CRITIC)):
+        x = torch.randn(7, ld, generator=g, dtype=torch.float64)
+        pg = x[:, 42:45] / x[:, 42:45].norm(dim=-1, keepdim=True)        # a consistent (roll, pitch, unit gravity) block
+        x[:, 40] = torch.atan2(pg[:, 1], -pg[:, 2]); x[:, 41] = torch.atan2(-pg[:, 0], torch.sqrt(pg[:, 1] ** 2 + pg[:, 2] ** 2)); x[:, 42:45] = pg
+        x[:, 48] = (x[:, 49:52].norm(dim=-1) < 1e-3).double()
+        src, mul, add = binding.mirror_table(model, critic)
+        n = L.NOBS_CRITIC if critic else L.NOBS_ACTOR
+        want = x[:, torch.from_numpy(src.astype(np.int64))] * torch.from_numpy(mul).double() + torch.from_numpy(add).double()
+        got = fn(x, model)
+        assert (got[:, :n] - want[:, :n]).abs().max() < 1e-6
+
+
+def test_convert_step_fn_contract(ref):
+    """convert.py:84-119: argument order of the deployed step function, its observation concatenation (= the actor row) and outputs."""
+    sf = ref["convert"]["step_fn"]
+    assert tuple(sf["args"]) == constants.STEP_FN_INPUTS
+    assert [e["wrapper"] for e in sf["entries"]] == [e["wrapper"] for e in ref["packing"]["run_actor"]["entries"]]
+    assert [e["var"] for e in sf["entries"]] == ["joint_angles", "joint_angular_velocities", "projected_gravity", "gyroscope", "cmd_zero", "command"]
+    assert sf["returns"] == ["dist.mode()", "new_carry_flat"]
+    assert ref["convert"]["carry_size_expr"].replace(" ", "") == "(depth*2*hidden_size+len(joint_names),)"

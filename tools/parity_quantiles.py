@@ -49,6 +49,7 @@ def run(N, steps, command, robot, terrain, seed=11):
     E = {k: {q: [] for q in ("qpos", "qvel", "qacc")} for k in ("hip", "o32", "pert")}
     SW = []
     obs = dict(actor=[], critic=[])
+    A17 = {k: [] for k in ("comdist_hip", "comdist_o32", "touch_hip", "touch_o32")}     # next-observation com_distance (a17) and foot touch
     for t in range(steps):
         act = H.random_actions(model, rng, N)
         ep, es = o32.ep.copy(), o32.es.copy()
@@ -60,7 +61,7 @@ def run(N, steps, command, robot, terrain, seed=11):
         pert = 1 + 6e-8 * rng.choice([-1.0, 1.0], size=(N, 54))
         o64p.es[:, 0:27] *= pert[:, 0:27].astype(np.float32); o64p.es[:, 28:54] *= pert[:, 28:54].astype(np.float32)
         a32, c32, x0, d32 = o32.step_diag(act, aux32)
-        a64, c64, _, d64 = o64.step_diag(act, aux64)
+        a64, c64, x64, d64 = o64.step_diag(act, aux64)
         _, _, _, d64p = o64p.step_diag(act, aux64p)
         cap = cfg.solver_iterations
         # an env-step sits on a discrete switch when the solver's discrete state (active contacts, rows carrying force, saturated
@@ -74,6 +75,9 @@ def run(N, steps, command, robot, terrain, seed=11):
             for q, v in H.state_errors(o64.es, got).items():
                 E[key][q].append(v[same])
         SW.append(switch[same])
+        xh, cd, tc = x2.cpu().numpy(), L.AUX["COMDIST"], slice(L.AUX["TOUCH"], L.AUX["TOUCH"] + 2)
+        A17["comdist_hip"].append(np.abs(xh[:, cd] - x64[:, cd])[same]); A17["comdist_o32"].append(np.abs(x0[:, cd] - x64[:, cd])[same])
+        A17["touch_hip"].append(np.abs(xh[:, tc] - x64[:, tc]).max(1)[same]); A17["touch_o32"].append(np.abs(x0[:, tc] - x64[:, tc]).max(1)[same])
         obs["actor"].append(np.abs(a64 - a2.cpu().numpy()).max(1)[same])
         obs["critic"].append((np.abs(c64 - c2.cpu().numpy()) / (1 + np.abs(c64))).max(1)[same])
     out = dict(config=dict(N=N, steps=steps, command=command, robot=robot, terrain=bool(terrain), seed=seed), quantity={})
@@ -92,6 +96,10 @@ def run(N, steps, command, robot, terrain, seed=11):
                                                  oracle_f32_count=int((o32e > thr).sum()), explained_by_sensitivity=int((over & sens).sum()),
                                                  unexplained=int((over & ~sens).sum()))
         out["quantity"][q] = rec
+    sw = np.concatenate(SW)
+    for k, v in A17.items():
+        v = np.concatenate(v)
+        out[k + "_vs_f64"] = dict(quantiles(v), without_switch_steps=quantiles(v[~sw]), over_1e_3=int((v > 1e-3).sum()), over_1e_3_on_switch=int(((v > 1e-3) & sw).sum()))
     out["actor_obs_vs_f64"] = quantiles(np.concatenate(obs["actor"]))
     out["critic_obs_rel_vs_f64"] = quantiles(np.concatenate(obs["critic"]))
     ctx.close()
