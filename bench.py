@@ -26,6 +26,7 @@ ENVS_PER_GPU = 8192
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
 ENV_BYTES_PER_ENVSTEP = 13.3e3  # state r/w + per-env params + trajectory rows
+PATH_BYTES_PER_ENVSTEP = 169e3  # rollout 13.3 KB + update 156 KB (trajectory re-reads + BPTT stash, 3 passes) per env-step
 
 
 def nn_flops_per_envstep(H: int, num_passes: int) -> float:
@@ -41,39 +42,60 @@ def nn_flops_per_envstep(H: int, num_passes: int) -> float:
 def cpu_baseline(repeats: int = 3):
     """The CPU oracle (C++ OpenMP env + torch actor-critic, a *port*: the JAX reference cannot run offline) on a bounded
     sample of the same workload: a full iteration of configs[1] scaled down to 256 envs x 100 steps
-    (batch 256, 3 passes, hidden 256), median of `repeats` after one warm-up, with a pinned thread count; plus the configs[0]
-    plumbing line (4 envs x 64 steps, batch 4)."""
+    (batch 256, 3 passes, hidden 256). The thread count is SWEPT (8 ... 256, capped by the cores this process may use) with one timed
+    iteration each after a warm-up, and the best setting is then timed as the median of `repeats`: the reported baseline is the best
+    the box does, and the sweep is part of the line. Plus the configs[0] plumbing line (4 envs x 64 steps, batch 4)."""
     import numpy as np
     import torch
     from kbot_joystick_amd.spec import compiler, layout as L
     from oracle import nn as ON
     from oracle.trainer import OracleTrainer
     from oracle import oracle as O
-    threads = max(1, min(16, os.cpu_count() or 1))     # small matrices: more threads only add synchronisation noise
-    torch.set_num_threads(threads)
-    O.lib().kbj_cpu_set_num_threads(threads)
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
     model = compiler.load_model("kbot-headless")
 
-    def run(n_envs, T, reps):
+    def set_threads(n):
+        torch.set_num_threads(n)
+        O.lib().kbj_cpu_set_num_threads(n)
+
+    def make(n_envs, T):
         cfg = L.default_config(num_envs=n_envs, batch_size=n_envs, rollout_len=T, hidden_size=256, num_passes=3, command_mode=1)
         cfg.fixed_command[0] = 0.5
         rng = np.random.default_rng(0)
         params = (rng.uniform(-1, 1, ON.param_count(256)) / 16).astype(np.float32)
         tr = OracleTrainer(model, cfg, seed=0, params=params)
         tr._normal = lambda step: rng.standard_normal((n_envs, 20)).astype(np.float32)   # python threefry loop is not the thing timed
-        tr.train_iteration()   # warm-up (allocator, thread pools)
-        ts = []
-        for _ in range(reps):
-            t0 = time.perf_counter()
-            tr.train_iteration()
-            ts.append(time.perf_counter() - t0)
-        return float(np.median(ts)), ts
+        return tr
 
-    t1, ts1 = run(256, 100, repeats)
-    t0, _ = run(4, 64, 3)
-    return dict(value=256 * 100 / t1, unit="env-steps/s", cores=threads, kind="port",
+    def timed(tr):
+        t0 = time.perf_counter()
+        tr.train_iteration()
+        return time.perf_counter() - t0
+
+    tr = make(256, 100)
+    sweep = {}
+    for n in (8, 16, 32, 64, 128, 256):
+        if n > usable and n != 8:
+            break
+        set_threads(n)
+        if not sweep:
+            tr.train_iteration()   # warm-up (allocator, thread pools)
+        sweep[n] = round(timed(tr), 3)
+    best = min(sweep, key=sweep.get)
+    set_threads(best)
+    ts1 = [timed(tr) for _ in range(repeats)]
+    t1 = float(np.median(ts1))
+    tr0 = make(4, 64)
+    tr0.train_iteration()
+    t0 = float(np.median([timed(tr0) for _ in range(3)]))
+    return dict(value=256 * 100 / t1, unit="env-steps/s", cores=best, kind="port",
                 sample=f"oracle full iteration (rollout + GAE + 3 passes) on 256 envs x 100 steps, batch 256, hidden 256: median of {repeats} "
-                       f"= {t1:.2f} s (runs {', '.join('%.2f' % t for t in ts1)}), {threads} threads of {os.cpu_count()} host cores",
+                       f"= {t1:.2f} s (runs {', '.join('%.2f' % t for t in ts1)}) at the best of the thread sweep ({best} threads; this process may use "
+                       f"{usable} of the host's {os.cpu_count()} cores)",
+                thread_sweep_seconds_per_iteration={str(k): v for k, v in sweep.items()},
                 config0=dict(value=4 * 64 / t0, unit="env-steps/s", sample=f"configs[0]: 4 envs x 64 steps, batch 4, 3 passes, hidden 256: median of 3 = {t0:.2f} s"))
 
 
@@ -106,7 +128,10 @@ def pmc_traffic() -> tuple[dict, dict]:
         print(f"bench.py: profiles/pmc_traffic.json was taken on other kernel sources ({meta.get('source_fingerprint')} != {fp}): "
               "roofline.traffic = null (re-run tools/pmc_traffic.py)", file=sys.stderr)
         return {}, dict(status="stale", profile_fingerprint=meta.get("source_fingerprint"), source_fingerprint=fp, git=meta.get("git"))
-    return {k: v.get("hbm_bytes_per_launch") for k, v in doc.items()}, dict(status="current", source_fingerprint=fp, git=meta.get("git"))
+    iters = max(1, int(meta.get("iterations", 3)))   # training iterations the profiled command ran (warm-up + steps + the roofline leg)
+    total = sum(v.get("hbm_bytes_per_launch", 0) * v.get("launches", 0) for v in doc.values())
+    return {k: v.get("hbm_bytes_per_launch") for k, v in doc.items()}, dict(status="current", source_fingerprint=fp, git=meta.get("git"),
+                                                                             hbm_bytes_per_iteration=total / iters, profiled_iterations=iters)
 
 
 def spawn_ranks(n: int) -> int:
@@ -198,11 +223,18 @@ def main():
     value = env_steps / elapsed
 
     # ---- roofline leg: one extra iteration with HIP-event timing inside the library (rank 0) ----
-    roofline = roofline2 = None
+    roofline = roofline2 = hbm = None
+    from kbot_joystick_amd.host import dist as dist_util
     if rank == 0:
         task.ctx.profile_begin()
+        dist_util.TIMING = []          # events around every gradient all-reduce of the instrumented iteration
     task.train_iteration()   # every rank takes part (gradient all-reduce); only rank 0 is instrumented
     torch.cuda.synchronize()
+    allreduce_ms, allreduce_calls = 0.0, 0
+    if rank == 0:
+        allreduce_calls = len(dist_util.TIMING)
+        allreduce_ms = float(sum(a.elapsed_time(b) for a, b in dist_util.TIMING))
+        dist_util.TIMING = None
     if rank == 0:
         prof = task.ctx.profile_end()
         nn_s = prof["nn_ms"] * 1e-3
@@ -234,6 +266,16 @@ def main():
         roofline = kernels[0]          # the dominant kernel by summed launch time
         roofline["traffic_profile"] = traffic_src
         roofline2 = dict(path=nn_roof, kernels=kernels[1:])
+        # whole-path HBM: counter bytes of every kernel of an iteration (committed PMC profile of the same kernel sources) against the
+        # iteration time, beside the algorithmic figure of SURVEY.md section 8d (169 KB per env-step)
+        alg = PATH_BYTES_PER_ENVSTEP * steps_gpu / iter_s / 1e9
+        hbm = dict(peak=PEAK_HBM_GBS, unit="GB/s", algorithmic=round(alg, 1), algorithmic_frac=round(alg / PEAK_HBM_GBS, 4),
+                   algorithmic_bytes_per_env_step=PATH_BYTES_PER_ENVSTEP, measured=None, measured_frac=None, measured_bytes_per_iteration=None,
+                   note="per GPU; measured = sum over all kernels of (PMC bytes per launch x launches) of one iteration / iteration time, null when the "
+                        "committed profile is of other kernel sources")
+        if traffic_src.get("hbm_bytes_per_iteration"):
+            meas = traffic_src["hbm_bytes_per_iteration"] / iter_s / 1e9
+            hbm.update(measured=round(meas, 1), measured_frac=round(meas / PEAK_HBM_GBS, 4), measured_bytes_per_iteration=round(traffic_src["hbm_bytes_per_iteration"]))
 
     if world > 1:
         dist.barrier()
@@ -255,6 +297,11 @@ def main():
                    "hidden_size": args.hidden, "baseline_config": args.config, "parallelism": f"env-sharded dp{world}, grad all-reduce {'per optimizer step' if args.allreduce == 'per_step' else 'once per pass (accumulated)'}"
                                   + (f" [{args.backend}{', ranks share GPU 0' if args.share_gpu else ''}]" if world > 1 else "")},
         "roofline": roofline, "roofline_secondary": roofline2, "cpu_baseline": cpu,
+        # data-parallel exchange: ranks in the process group (1 = no collective runs), gradient all-reduce time of one iteration (HIP events
+        # around every dist.all_reduce of the instrumented iteration, rank 0) and the whole-path HBM fraction
+        "rccl_ranks": world, "collective_backend": (args.backend if world > 1 else None),
+        "allreduce_ms_per_iteration": round(allreduce_ms, 3), "allreduce_calls_per_iteration": allreduce_calls,
+        "hbm_whole_path": hbm,
     }
     print(json.dumps(out), flush=True)
     if world > 1:

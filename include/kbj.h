@@ -141,11 +141,26 @@ int kbj_gae(kbj_ctx* ctx, const kbj_traj* traj, float* adv_d, float* target_d);
  * action_mirror_loss, value_mirror_loss */
 int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* traj, const int32_t* env_idx_d, int B, const float* adv_d,
                  const float* target_d, float* grad_d, float* metrics_d);
+/* replaces: get_ppo_variables(model, trajectory, model_carry, rng) (train.py:1510-1524) = the scan of _ppo_scan_fn (train.py:1435-1508)
+ * WITHOUT taking gradients, for the B = config.batch_size envs env_idx_d names of ANY trajectory of the context's shape (one kbj_rollout
+ * produced, or one reloaded into the same arrays): both nets run through the T steps from the trajectory's start carries with the carry
+ * reset where `done` (train.py:1502-1506), and the per-step variables of PPOVariables come back as [T][B] arrays in env_idx order
+ * (row t * B + b belongs to env env_idx_d[b]): log_probs of the stored actions (train.py:1452), values (:1455), entropy (:1486),
+ * action_std [T][B][20] (:1487). entropy_d / action_std_d / action_mean_d may be NULL. The mirror aux losses are not evaluated here. */
+typedef struct kbj_ppo_vars {
+  float* logp_d;         /* [T][B] */
+  float* value_d;        /* [T][B] */
+  float* entropy_d;      /* [T][B] or NULL */
+  float* action_std_d;   /* [T][B][20] or NULL */
+  float* action_mean_d;  /* [T][B][20] or NULL: the filtered mean (the distribution's mode, train.py:936-939) */
+} kbj_ppo_vars;
+int kbj_ppo_forward(kbj_ctx* ctx, const float* params_d, const kbj_traj* traj, const int32_t* env_idx_d, int B, kbj_ppo_vars* out);
 /* replaces: optax.adamw + global-norm clip (train.py:1059-1077). step is 1-based. grad_scale multiplies the
  * gradient first (1/world_size after an all-reduce sum). */
 int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const float* grad_d, int64_t step, float grad_scale);
 /* replaces: optax.cosine_decay_schedule feeding adamw (train.py:1067-1077): the host evaluates the schedule and sets the
- * learning rate used by the following kbj_adamw_step calls. */
+ * learning rate used by the following kbj_adamw_step calls. Any finite value; a negative one moves the parameters ALONG the Adam direction,
+ * which is what train.py:1074-1075 (scale_by_adam chained with scale_by_schedule, no sign flip) does as written. */
 int kbj_set_learning_rate(kbj_ctx* ctx, float learning_rate);
 
 /* per-launch timing of the dominant kernels, measured with HIP events on the context's stream (bench.py roofline) */

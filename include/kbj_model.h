@@ -131,7 +131,9 @@ typedef struct kbj_config {
   int32_t enable_noise;
   int32_t max_episode_steps; /* 12 s / 0.02 s = 600 */
   int32_t solver_newton;     /* 1 = Newton direction (default), 0 = Polak-Ribiere CG */
-  int32_t reserved_i[4];
+  int32_t deterministic;     /* 1 = the PPO update reduces in a fixed order (split-K slabs, per-block partials) instead of with fp32 / fp64 atomics:
+                                two updates from the same state give bit-identical parameters, as the reference's XLA program does; default 0 */
+  int32_t reserved_i[3];
   float dt;                  /* 0.004 */
   float ctrl_dt;             /* 0.02  */
   float solver_tolerance;    /* 1e-8 */

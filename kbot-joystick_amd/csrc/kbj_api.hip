@@ -90,23 +90,20 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   KBJ_TRY(hipEventCreate(&ctx->ev1));
   // stream2 carries the critic-type nets of the update. The critic's chain is the longer one (a 475-wide input projection in front of
   // layer 0 that the actor folds away; the actor's chain ends ~0.4 ms earlier), and since the two lanes stopped waiting for each other
-  // at the loss it decides the length of a minibatch: its lane gets the highest queue priority (6.66 -> 6.61 ms per minibatch;
-  // KBJ_CRITIC_PRIORITY=0: default priority).
+  // at the loss it decides the length of a minibatch: its lane gets the highest queue priority (6.66 -> 6.61 ms per minibatch).
   {
     int lo = 0, hi = 0;
     KBJ_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    const bool critic_high = !(getenv("KBJ_CRITIC_PRIORITY") && atoi(getenv("KBJ_CRITIC_PRIORITY")) == 0);
-    KBJ_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, critic_high ? hi : 0));
+    KBJ_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi));
   }
   // The side lanes carry work that hangs off the critical chain of the update (weight-gradient GEMMs, bias sums) and the critic of the
   // rollout: lowest queue priority, so that when a dX GEMM of the chain and a dW GEMM compete for CUs the chain's workgroups go first.
   // Nearly zero-sum (the dX GEMMs finish in 520 instead of 756 us, but the displaced dW GEMMs then run beside the backward recurrences,
-  // which slow from 895 to 1209 us): 6.91 -> 6.86 ms per minibatch, 444.2 -> 441.8 ms per iteration. KBJ_SIDE_PRIORITY=0: default priority.
+  // which slow from 895 to 1209 us): 6.91 -> 6.86 ms per minibatch, 444.2 -> 441.8 ms per iteration.
   int prio_least = 0, prio_greatest = 0;
   KBJ_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-  const bool side_low = !(getenv("KBJ_SIDE_PRIORITY") && atoi(getenv("KBJ_SIDE_PRIORITY")) == 0);
   for (int n = 0; n < 2; ++n) {
-    KBJ_TRY(hipStreamCreateWithPriority(&ctx->side[n], hipStreamNonBlocking, side_low ? prio_least : 0));
+    KBJ_TRY(hipStreamCreateWithPriority(&ctx->side[n], hipStreamNonBlocking, prio_least));
     KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_side[n], hipEventDisableTiming));
   }
   for (int k = 0; k < 32; ++k) KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_pool[k], hipEventDisableTiming));
@@ -168,7 +165,7 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
       "kbj::lstm_seq_fwd_kernel", "kbj::lstm_step_kernel", "kbj::lstm_step_kernel"};
   for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
     kbj_kernel_stat& st = ctx->kstats[k];
-    const int uw = getenv("KBJ_SEQ_UW") ? atoi(getenv("KBJ_SEQ_UW")) : 2;
+    const int uw = 2;   // wavefront pairs per recurrence workgroup (kbj_nn.hip SEQ_UW), as rocprofv3 prints the template argument
     if (k == KBJ_KIND_SEQ_BWD) snprintf(st.name, sizeof(st.name), "%s<%d, %d>", names[k], ctx->cfg_h.hidden_size, uw);
     else if (k == KBJ_KIND_SEQ_FWD || k == KBJ_KIND_SEQ_FWD_FUSED || k == KBJ_KIND_SEQ_FWD_OBS)   // as rocprofv3 prints the template arguments
       snprintf(st.name, sizeof(st.name), "%s<%d, %d, %s, %d>", names[k], ctx->cfg_h.hidden_size, uw, k == KBJ_KIND_SEQ_FWD ? "false" : "true",

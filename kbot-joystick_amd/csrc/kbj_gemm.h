@@ -40,6 +40,9 @@ struct GemmArgs {
   // 0 = ldb) and go to C2[m][n - n1] (ldc2, 0 = ldc) — two products that share A in one launch, so neighbouring workgroups share
   // the A panel in L2
   float* C2 = nullptr; int n1 = 0, ldb2 = 0, ldc2 = 0;
+  // deterministic split-K (kbj_config.deterministic): instead of fp32 atomics into C, k slice ks stores its partial tile into
+  // skws[ks][M][N] (N = all columns of the launch, both problems) and splitk_reduce_kernel adds the slices to C in slice order
+  float* skws = nullptr;
 };
 
 constexpr int GEMM_BK = 32;
@@ -115,7 +118,7 @@ struct GemmStage {
 };
 
 // work item -> output tile and k range (n tile fastest, then m tile, then k slice)
-struct GemmItem { int m0, n0, kbeg, kend, ks; const float* B; float* C; int ncols, ldb, ldc; };   // n0, ncols: local to the (B, C) problem
+struct GemmItem { int m0, n0, kbeg, kend, ks; const float* B; float* C; int ncols, ldb, ldc, ncol0; };   // n0, ncols: local to the (B, C) problem; ncol0: its first column in the launch
 template <int BM, int BN>
 __device__ __forceinline__ GemmItem gemm_item(const GemmArgs& g, int item, int tiles_n, int tiles_m, int per) {
   GemmItem it;
@@ -123,10 +126,10 @@ __device__ __forceinline__ GemmItem gemm_item(const GemmArgs& g, int item, int t
   int tm = r % tiles_m;
   it.ks = r / tiles_m;
   it.m0 = tm * BM; it.n0 = tn * BN;
-  it.B = g.B; it.C = g.C; it.ncols = g.N; it.ldb = g.ldb; it.ldc = g.ldc;
+  it.B = g.B; it.C = g.C; it.ncols = g.N; it.ldb = g.ldb; it.ldc = g.ldc; it.ncol0 = 0;
   if (g.n1 > 0) {
     if (it.n0 >= g.n1) {
-      it.B = g.B2; it.C = g.C2; it.n0 -= g.n1; it.ncols = g.N - g.n1;
+      it.B = g.B2; it.C = g.C2; it.n0 -= g.n1; it.ncols = g.N - g.n1; it.ncol0 = g.n1;
       if (g.ldb2 > 0) it.ldb = g.ldb2;
       if (g.ldc2 > 0) it.ldc = g.ldc2;
     }
@@ -265,14 +268,28 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
 #ifdef KBJ_GEMM_NOSTORE   // timing experiment only (tools/gemm_bench): keep the MFMAs live, drop the write-back
           if (v == 1.2345e-30f) *c = v;
 #else
-          if (sk > 1) atomicAdd(c, v);
-          else *c = g.beta ? *c + v : v;
+          if (sk > 1) {
+            if (g.skws) g.skws[((size_t)cur.ks * g.M + m) * g.N + cur.ncol0 + n] = v;
+            else atomicAdd(c, v);
+          } else *c = g.beta ? *c + v : v;
 #endif
         }
       }
     if (!have_next) break;
     cur = nxt;
   }
+}
+
+// second stage of the deterministic split-K: C (+)= sum over the k slices, in slice order, of the partial tiles (one thread per output
+// element; slices whose k range is empty wrote nothing and are skipped exactly as the GEMM skipped them)
+__global__ void splitk_reduce_kernel(GemmArgs g, int sk, int per) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)g.M * g.N) return;
+  const int m = (int)(i / g.N), n = (int)(i % g.N);
+  float s = 0.0f;
+  for (int ks = 0; ks < sk && (long)ks * per < g.K; ++ks) s += g.skws[((size_t)ks * g.M + m) * g.N + n];
+  float* c = (g.n1 > 0 && n >= g.n1) ? g.C2 + (size_t)m * (g.ldc2 > 0 ? g.ldc2 : g.ldc) + (n - g.n1) : g.C + (size_t)m * g.ldc + n;
+  *c += s;
 }
 
 template <int MT, int NT, bool A_KC, bool B_KC, int WM = 2, int WN = 2>
@@ -294,9 +311,8 @@ inline void gemm_launch(hipStream_t s, const GemmArgs& g_in, int force_big = -1)
   long big_items = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * sk;
   bool big = force_big >= 0 ? force_big != 0 : big_items >= 192;
   long items = big ? big_items : (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * sk;
-  // 256 CUs x 2 resident workgroups; keep >= ~3 rounds of workgroups for the hardware to balance, at most 4 items each
-  static const int ipw_env = getenv("KBJ_GEMM_IPW") ? atoi(getenv("KBJ_GEMM_IPW")) : 0;   // diagnostics
-  int ipw = ipw_env > 0 ? ipw_env : 1;
+  // one work item per workgroup (walking several items per workgroup was slower at every setting for this path's shapes)
+  const int ipw = 1;
   g.ipw = ipw;
   int wgs = (int)((items + ipw - 1) / ipw);
   wgs = (wgs + 7) / 8 * 8;
@@ -307,6 +323,10 @@ inline void gemm_launch(hipStream_t s, const GemmArgs& g_in, int force_big = -1)
   if (big) gemm_launch_tile<2, 1, A_KC, B_KC, 2, 4>(s, g, wgs);
 #endif
   else gemm_launch_tile<1, 1, A_KC, B_KC>(s, g, wgs);
+  if (sk > 1 && g.skws) {
+    const int per = ((g.K + sk - 1) / sk + GEMM_BK - 1) / GEMM_BK * GEMM_BK;   // as gemm_f32_kernel slices k
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((size_t)g.M * g.N + 255) / 256)), dim3(256), 0, s, g, sk, per);
+  }
 }
 
 }  // namespace kbj

@@ -77,6 +77,7 @@ struct SeqBwdArgs {
   unsigned* err;
   int T, B;
   float* db;             // optional [4H]: bias gradient accumulated with atomics (column sums of dG)
+  float* db_part = nullptr;   // deterministic mode: [row groups][4H] per-row-group column sums instead (added to db in order by reduce_rows_kernel)
   unsigned spin_limit = SEQ_SPIN_LIMIT;
   long long* stamps = nullptr;   // optional [T][10] shader-clock stamps of workgroup 0 (diagnostics)
 };
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256 * UW) __attribute__((amdgpu_num_vgpr(KBJ_SEQ_BW
     SEQ_BSTAMP(8);
   }
   // bias gradient = column sums of dG over all rows and steps: reduce this workgroup's 32 rows in LDS, one atomic per column
-  if (a.db) {
+  if (a.db || a.db_part) {
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -499,7 +500,8 @@ __global__ __launch_bounds__(256 * UW) __attribute__((amdgpu_num_vgpr(KBJ_SEQ_BW
       int k = tid / UNITS, u = tid % UNITS;
       float s = 0;
       for (int r = 0; r < SEQ_ROWS; ++r) s += pbuf[k][r][u];
-      atomicAdd(a.db + k * H + u0 + u, s);
+      if (a.db_part) a.db_part[(size_t)rg * 4 * H + k * H + u0 + u] = s;
+      else atomicAdd(a.db + k * H + u0 + u, s);
     }
   }
   if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 2] = wall_clock64();

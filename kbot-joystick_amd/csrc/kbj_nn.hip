@@ -25,8 +25,30 @@ struct TrainBufs {  // per net, minibatch-sized
   float *obs, *X0, *G[MAXD], *Hm[MAXD], *Hout[MAXD], *Cm[MAXD], *TanhC[MAXD], *Out, *dOut, *dHa, *dHb, *dGl[MAXD];
 };
 
+// Formulation switches of the schedule. Read from the environment ONCE PER CONTEXT (kbj_create), so that a test process can build contexts
+// under different settings; every non-default value below is exercised by a parity test (tests/test_gpu_switches.py) and README.md lists
+// exactly these. `deterministic` comes from kbj_config (KBJ_DETERMINISTIC=1 forces it on).
+struct Sched {
+  bool fold_actor = true;          // KBJ_FOLD_ACTOR=0: actor input projection as its own GEMM (65 -> H -> 4H) instead of folded into layer 0
+  bool fold_critic = true;         // KBJ_FOLD_CRITIC=0: critic layer-0 backward through dX0 instead of Z = dG0^T obs
+  bool fuse_ih = true;             // KBJ_SEQ_FUSE=0: input products x W_ih^T as GEMM launches in front of the forward recurrences
+  bool fuse_obs = true;            // KBJ_SEQ_FUSE_OBS=0: the folded actor layer 0 as a GEMM launch instead of inside its recurrence
+  bool fused_critic_head = true;   // KBJ_FUSED_CRITIC_HEAD=0: critic head as output GEMM + value kernel + loss kernel + K = 1 GEMM
+  bool rollout_step = true;        // KBJ_ROLLOUT_STEP=0: rollout layers as [x | h] gate GEMM + cell kernel instead of lstm_step_kernel
+  bool one_stream = false;         // KBJ_ONE_STREAM=1: the whole update on the caller's stream (no lanes)
+  bool debug_sync = false;         // KBJ_DEBUG=1: kbj_ppo_grad synchronises and reports device-side errors at the call that caused them
+  bool deterministic = false;      // fixed-order reductions instead of fp32 / fp64 atomics (bit-reproducible update)
+};
+bool env_flag(const char* name, bool dflt) { const char* v = getenv(name); return v ? atoi(v) != 0 : dflt; }
+
 struct NnWs {
+  Sched sched;
   int H = 0, N = 0, B = 0, T = 0, D = 2;
+  // deterministic mode: per-lane workspaces (lane = stream: caller's, second, side 0, side 1) for split-K slabs and reduction partials
+  float* skws[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t skws_cap[4] = {0, 0, 0, 0};
+  float* detp[4] = {nullptr, nullptr, nullptr, nullptr};   // [512][1024] floats each
+  double* detd = nullptr;                                    // [512][2] doubles (advantage statistics, gradient norm)
   NetOff net[2];
   size_t nparams = 0, nactor = 0;
   // rollout scratch
@@ -127,8 +149,15 @@ template <class T> int dalloc(kbj_ctx* ctx, NnWs& w, T** p, size_t count) {
   return 0;
 }
 
-int g_fold_sk = 8;        // k slices of the small W_ih0^T Z product of the folded input projections (KBJ_FOLD_SK)
-int g_splitk_wgs = 768;   // target number of workgroups of a split-K weight-gradient GEMM (KBJ_SPLITK_WGS)
+constexpr int g_fold_sk = 8;        // k slices of the small W_ih0^T Z product of the folded input projections
+constexpr int g_splitk_wgs = 768;   // target number of workgroups of a split-K weight-gradient GEMM (512 ... 1536 measured flat)
+constexpr int DETP_ROWS = 512, DETP_COLS = 1024;
+
+// lane index of a stream of this context (deterministic-mode workspaces are per lane: launches on different lanes overlap)
+int lane_of(kbj_ctx* ctx, hipStream_t s) { return s == ctx->stream ? 0 : (s == ctx->stream2 ? 1 : (s == ctx->side[0] ? 2 : 3)); }
+// split-K slab workspace of the lane of stream s, grown on demand (deterministic mode only; null otherwise = atomics)
+float* sk_workspace(kbj_ctx* ctx, hipStream_t s, size_t floats);
+float* det_partials(kbj_ctx* ctx, hipStream_t s);
 
 inline dim3 g1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
@@ -143,24 +172,25 @@ void linear_bwd_input(hipStream_t s, const float* dy, int lddy, const float* W, 
   gemm_launch<true, false>(s, g);
 }
 // dW[Nout][Nin] += dy^T x  (dy [R][Nout], x [R][Nin]); split-K over the R samples with atomics (dW pre-zeroed by the caller)
-void linear_bwd_weight(hipStream_t s, const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, int Nout, int Nin, int R) {
+void linear_bwd_weight(kbj_ctx* ctx, hipStream_t s, const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, int Nout, int Nin, int R) {
   // the long contraction (R = T*B samples) is split over the grid: 128x128 tiles when the output allows it, ~768 workgroups
   bool big = Nout >= 128 && Nin >= 128;
   int ts = big ? 128 : 64;
   int tiles = ((Nout + ts - 1) / ts) * ((Nin + ts - 1) / ts);
   int sk = std::max(2, std::min(256, g_splitk_wgs / std::max(1, tiles)));
   sk = std::max(2, std::min(sk, (R + 255) / 256));
-  GemmArgs g{dy, x, dW, nullptr, Nout, Nin, R, lddy, ldx, lddw, 1, sk, nullptr};  // always the atomic path: accumulates into dW
+  GemmArgs g{dy, x, dW, nullptr, Nout, Nin, R, lddy, ldx, lddw, 1, sk, nullptr};  // always the split-K path: accumulates into dW
+  g.skws = sk_workspace(ctx, s, (size_t)sk * Nout * Nin);
   gemm_launch<false, false>(s, g, big ? 1 : 0);
 }
 
 // two weight gradients that share dy in one launch: dW1 += dy^T x1, dW2 += dy^T x2 (x1, x2 [R][Nin] with the same ld)
-void linear_bwd_weight2(hipStream_t s, const float* dy, int lddy, const float* x1, const float* x2, int ldx, float* dW1, float* dW2, int lddw, int Nout, int Nin, int R) {
+void linear_bwd_weight2(kbj_ctx* ctx, hipStream_t s, const float* dy, int lddy, const float* x1, const float* x2, int ldx, float* dW1, float* dW2, int lddw, int Nout, int Nin, int R) {
   bool big = Nout >= 128 && Nin >= 128;
   int ts = big ? 128 : 64;
   if (Nin % ts != 0) {  // the column split must fall on a tile boundary
-    linear_bwd_weight(s, dy, lddy, x1, ldx, dW1, lddw, Nout, Nin, R);
-    linear_bwd_weight(s, dy, lddy, x2, ldx, dW2, lddw, Nout, Nin, R);
+    linear_bwd_weight(ctx, s, dy, lddy, x1, ldx, dW1, lddw, Nout, Nin, R);
+    linear_bwd_weight(ctx, s, dy, lddy, x2, ldx, dW2, lddw, Nout, Nin, R);
     return;
   }
   int tiles = ((Nout + ts - 1) / ts) * (2 * Nin / ts);
@@ -168,7 +198,14 @@ void linear_bwd_weight2(hipStream_t s, const float* dy, int lddy, const float* x
   sk = std::max(2, std::min(sk, (R + 255) / 256));
   GemmArgs g{dy, x1, dW1, nullptr, Nout, 2 * Nin, R, lddy, ldx, lddw, 1, sk, nullptr};
   g.B2 = x2; g.C2 = dW2; g.n1 = Nin;
+  g.skws = sk_workspace(ctx, s, (size_t)sk * Nout * 2 * Nin);
   gemm_launch<false, false>(s, g, big ? 1 : 0);
+}
+// column sums of X [M][N] (ld) added to out[N]: atomics over 512 row slices, or (deterministic) per-slice partials + ordered reduce
+void colsum_acc(kbj_ctx* ctx, hipStream_t s, const float* X, int M, int N, int ld, float* out) {
+  float* part = det_partials(ctx, s);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64, DETP_ROWS), dim3(256), 0, s, X, M, N, ld, out, part);
+  if (part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, DETP_ROWS, N, out);
 }
 
 // recurrence workgroups are 8 wavefronts owning 32 hidden units (kbj_lstm_seq.h; the 4-wavefront / 16-unit form of round 1 is gone:
@@ -252,6 +289,27 @@ int lstm_step(kbj_ctx* ctx, hipStream_t st, int H, const StepArgs& a) {
   return 0;
 }
 
+}  // namespace
+
+namespace {
+float* sk_workspace(kbj_ctx* ctx, hipStream_t s, size_t floats) {
+  NnWs& w = *ws_of(ctx);
+  if (!w.sched.deterministic) return nullptr;
+  const int l = lane_of(ctx, s);
+  if (w.skws_cap[l] < floats) {   // grows during the first calls only; nothing may still be reading the old slab
+    hipDeviceSynchronize();
+    if (w.skws[l]) hipFree(w.skws[l]);
+    w.skws[l] = nullptr; w.skws_cap[l] = 0;
+    void* q = nullptr;
+    if (hipMalloc(&q, floats * sizeof(float)) != hipSuccess) { kbj_fail(ctx, "hipMalloc (deterministic split-K workspace)"); return nullptr; }
+    w.skws[l] = reinterpret_cast<float*>(q); w.skws_cap[l] = floats;
+  }
+  return w.skws[l];
+}
+float* det_partials(kbj_ctx* ctx, hipStream_t s) {
+  NnWs& w = *ws_of(ctx);
+  return w.sched.deterministic ? w.detp[lane_of(ctx, s)] : nullptr;
+}
 }  // namespace
 
 int kbj_nn_check_errors(kbj_ctx* ctx) {
@@ -365,8 +423,18 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (getenv("KBJ_SEQ_STAMPS")) { if (dalloc(ctx, *w, &w->seq_stamps, (size_t)T * 6)) return -1; }
   if (getenv("KBJ_SEQ_BSTAMPS")) { if (dalloc(ctx, *w, &w->seq_bstamps, (size_t)T * 10 + 768)) return -1; }
   if (hipMemset(w->seq_err, 0, 4 * sizeof(unsigned)) != hipSuccess) return kbj_fail(ctx, "hipMemset seq_err");
-  g_splitk_wgs = getenv("KBJ_SPLITK_WGS") ? atoi(getenv("KBJ_SPLITK_WGS")) : 768;
-  g_fold_sk = getenv("KBJ_FOLD_SK") ? std::max(1, atoi(getenv("KBJ_FOLD_SK"))) : 8;
+  {
+    Sched& sc = w->sched;
+    sc.fold_actor = env_flag("KBJ_FOLD_ACTOR", true); sc.fold_critic = env_flag("KBJ_FOLD_CRITIC", true);
+    sc.fuse_ih = env_flag("KBJ_SEQ_FUSE", true); sc.fuse_obs = sc.fuse_ih && env_flag("KBJ_SEQ_FUSE_OBS", true);
+    sc.fused_critic_head = env_flag("KBJ_FUSED_CRITIC_HEAD", true); sc.rollout_step = env_flag("KBJ_ROLLOUT_STEP", true);
+    sc.one_stream = env_flag("KBJ_ONE_STREAM", false); sc.debug_sync = env_flag("KBJ_DEBUG", false);
+    sc.deterministic = c.deterministic != 0 || env_flag("KBJ_DETERMINISTIC", false);
+    if (sc.deterministic) {
+      for (int l = 0; l < 4; ++l) if (dalloc(ctx, *w, &w->detp[l], (size_t)DETP_ROWS * DETP_COLS)) return -1;
+      if (dalloc(ctx, *w, &w->detd, 2 * 512)) return -1;
+    }
+  }
   g_seq_drop = getenv("KBJ_DEBUG_DROP_SEQ_WG") ? atoi(getenv("KBJ_DEBUG_DROP_SEQ_WG")) : 0;
   g_seq_spin_limit = g_seq_drop > 0 ? (1u << 15) : SEQ_SPIN_LIMIT;   // an injected fault should not cost the full 2^24-spin bound
   // Residency of the persistent recurrences: the workgroups of one launch spin on each other, and kbj_ppo_grad keeps TWO launches
@@ -410,6 +478,7 @@ void kbj_nn_destroy(kbj_ctx* ctx) {
   NnWs* w = ws_of(ctx);
   if (!w) return;
   for (void* p : w->allocs) hipFree(p);
+  for (int l = 0; l < 4; ++l) if (w->skws[l]) hipFree(w->skws[l]);
   delete w;
   ctx->nn_ws = nullptr;
 }
@@ -425,22 +494,15 @@ namespace {
 // Rollout-time layer steps run in lstm_step_kernel (fused [x | h] product + cell). Its output h cannot alias its input, so every h
 // plane of the carry has a ping-pong partner in the workspace: a call with parity 0 reads the caller's planes and writes the partners,
 // parity 1 the other way round. kbj_rollout alternates per control step; the caller's arrays hold the state again when it returns.
-// KBJ_ROLLOUT_STEP=0 (diagnostics): the previous form, one GEMM over [x | h] plus a cell kernel per layer, in place.
-bool rollout_step_kernel() {
-  static const bool on = getenv("KBJ_ROLLOUT_STEP") ? atoi(getenv("KBJ_ROLLOUT_STEP")) != 0 : true;
-  return on;
-}
+// KBJ_ROLLOUT_STEP=0 (Sched::rollout_step): the previous form, one GEMM over [x | h] plus a cell kernel per layer, in place.
 // Only the actor proper (net 0) sits on the rollout's critical chain (env -> actor -> env). The critic and the mirror branches run on side
 // lanes under the env kernel, where the only free resources are those of its last, partial round of wavefronts (8192 envs = 2.67 rounds
 // of 12 per CU: 168 VGPRs per SIMD and ~58 KB of LDS per CU for the last third of the kernel): a 64x64-tile GEMM workgroup (4 waves x 84
 // VGPRs, 37 KB) fits there, a layer-step workgroup (8 waves x 220 VGPRs) does not and would run into the next actor chain instead. So the
-// side-lane nets keep the GEMM + cell form on small tiles (414 vs 418 ms per iteration). KBJ_ROLLOUT_STEP_SIDE=1: layer-step kernels there too.
-bool net_uses_step_kernel(int n) {
-  static const bool side_on = getenv("KBJ_ROLLOUT_STEP_SIDE") && atoi(getenv("KBJ_ROLLOUT_STEP_SIDE")) != 0;
-  return rollout_step_kernel() && (n == 0 || side_on);
-}
+// side-lane nets keep the GEMM + cell form on small tiles (414 vs 418 ms per iteration).
+bool net_uses_step_kernel(const NnWs& w, int n) { return w.sched.rollout_step && n == 0; }
 float* h_plane(NnWs& w, float* hc, int n, int l, int n0, bool partner) {
-  if (!net_uses_step_kernel(n)) partner = false;
+  if (!net_uses_step_kernel(w, n)) partner = false;
   return (partner ? w.rH[n][l] : hc + (size_t)(2 * l) * w.N * w.H) + (size_t)n0 * w.H;
 }
 
@@ -449,7 +511,7 @@ float* h_plane(NnWs& w, float* hc, int n, int l, int n0, bool partner) {
 const float* fold_actor_weights(kbj_ctx* ctx, hipStream_t s, const float* params_d) {
   NnWs& w = *ws_of(ctx);
   const int H = w.H;
-  if (!rollout_step_kernel() || w.net[0].ld_obs != KBJ_LD_ACTOR || (getenv("KBJ_FOLD_ACTOR") && atoi(getenv("KBJ_FOLD_ACTOR")) == 0)) return nullptr;
+  if (!w.sched.rollout_step || w.net[0].ld_obs != KBJ_LD_ACTOR || !w.sched.fold_actor) return nullptr;
   const NetOff& oa = w.net[0];
   GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, KBJ_LD_ACTOR, 0, 1, nullptr};
   gemm_launch<true, false>(s, g);
@@ -463,7 +525,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
   NnWs& w = *ws_of(ctx);
   const kbj_config& c = ctx->cfg_h;
   const int N = w.N, H = w.H;
-  const bool fused_any = rollout_step_kernel();
+  const bool fused_any = w.sched.rollout_step;
   const float* obs_base[2] = {actor_obs_d, critic_obs_d};
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
@@ -480,7 +542,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
       hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)cnt * o.ld_obs), dim3(256), 0, s, obs, obs_m, (size_t)cnt, o.ld_obs, w.mtab[k]);
       obs = obs_m;
     }
-    const bool fused = fused_any && net_uses_step_kernel(n);
+    const bool fused = fused_any && net_uses_step_kernel(w, n);
     const bool folded = fused && weff && k == 0 && o.ld_obs == KBJ_LD_ACTOR;   // actor-type net: layer-0 gates straight from the observation row
     if (!folded) linear_fwd(s, obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, X, H, cnt, H, o.nin, 0);
     const float* x = X;
@@ -499,8 +561,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
       {  // gates = [x | h] [W_ih | W_hh]^T + b as ONE launch over the concatenated contraction (no read-modify-write of G)
         GemmArgs g{x, params_d + o.w_ih[l], G, params_d + o.b[l], cnt, 4 * H, 2 * H, H, H, 4 * H, 0, 1, nullptr};
         g.A2 = h; g.B2 = params_d + o.w_hh[l]; g.k1 = H;
-        static const bool small_tiles = !(getenv("KBJ_ROLLOUT_GEMM_SMALL") && atoi(getenv("KBJ_ROLLOUT_GEMM_SMALL")) == 0);
-        gemm_launch<true, true>(s, g, (n > 0 && small_tiles && rollout_step_kernel()) ? 0 : -1);   // side-lane nets: 64x64 tiles (see net_uses_step_kernel)
+        gemm_launch<true, true>(s, g, (n > 0 && w.sched.rollout_step) ? 0 : -1);   // side-lane nets: 64x64 tiles (see net_uses_step_kernel)
       }
       CellFwdArgs2 ca;
       ca.a[0] = CellFwdArgs{G, cc, h, cc, nullptr, nullptr, nullptr, nullptr, cnt, H};
@@ -525,7 +586,7 @@ void carry_reset_nets(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, int n
   NnWs& w = *ws_of(ctx);
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   float* lpf[4] = {carry->lpf_d, nullptr, carry->lpf_mirror_d, nullptr};
-  const bool partner = parity != 0 && rollout_step_kernel();
+  const bool partner = parity != 0 && w.sched.rollout_step;
   for (int k = net_lo; k < net_hi; ++k) {
     CarryPlanes cp;
     cp.n = 2 * w.D;
@@ -542,7 +603,7 @@ int carry_h_home(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, kbj_carry*
   NnWs& w = *ws_of(ctx);
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
   for (int k = net_lo; k < net_hi; ++k)
-    for (int l = 0; l < w.D && net_uses_step_kernel(k); ++l)
+    for (int l = 0; l < w.D && net_uses_step_kernel(w, k); ++l)
       KBJ_HIP(ctx, hipMemcpyAsync(hc[k] + (size_t)(2 * l) * w.N * w.H, w.rH[k][l], (size_t)w.N * w.H * sizeof(float), hipMemcpyDeviceToDevice, s));
   return 0;
 }
@@ -592,7 +653,7 @@ int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_
     return kbj_fail(ctx, "kbj_policy_step: the mirror losses are enabled, the carry needs the mirror-branch arrays");
   if (policy_nets(ctx, ctx->stream, params_d, 0, w.nnets, 0, w.N, actor_obs_d, critic_obs_d, carry, seed, step_index, argmax, action_d, logp_d, value_d, 0,
                   fold_actor_weights(ctx, ctx->stream, params_d))) return -1;
-  if (rollout_step_kernel() && carry_h_home(ctx, ctx->stream, 0, w.nnets, carry)) return -1;   // the new h sits in the partners: bring it home
+  if (w.sched.rollout_step && carry_h_home(ctx, ctx->stream, 0, w.nnets, carry)) return -1;   // the new h sits in the partners: bring it home
   KBJ_CHECK_LAUNCH(ctx, "kbj_policy_step");
   return 0;
 }
@@ -679,7 +740,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
       KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
     }
   }
-  if (rollout_step_kernel() && (T & 1) && carry_h_home(ctx, s, 0, w.nnets, carry)) return -1;   // an odd number of steps leaves the live h planes in the partners
+  if (w.sched.rollout_step && (T & 1) && carry_h_home(ctx, s, 0, w.nnets, carry)) return -1;   // an odd number of steps leaves the live h planes in the partners
   return kbj_rewards(ctx, tr->aux_d, T, tr->reward_d, tr->reward_comps_d);
 }
 
@@ -692,35 +753,29 @@ int kbj_gae(kbj_ctx* ctx, const kbj_traj* tr, float* adv_d, float* target_d) {
   return 0;
 }
 
-int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const int32_t* env_idx_d, int B, const float* adv_d, const float* target_d,
-                 float* grad_d, float* metrics_d) {
-  if (!ctx || !params_d || !tr || !env_idx_d || !adv_d || !target_d || !grad_d || !metrics_d) return kbj_fail(ctx, "kbj_ppo_grad: null argument");
-  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+}  // extern "C"
+
+namespace {
+
+// ---- the first half of a PPO minibatch pass, shared by kbj_ppo_grad and kbj_ppo_forward -----------------------------------------------
+// gathers the minibatch (observations, actions, keep flags, start-of-trajectory carries; with `grad` also the old log-probs / values,
+// advantages and targets), prepares the folded actor weights, and runs both nets forward through time: afterwards w.tb[n].Hout[D-1]
+// holds the top layer's outputs and the BPTT stash is in place. Lanes: actor-type nets on ns[0] (the caller's stream), critic-type nets
+// on ns[1]; on return the two lanes are still forked (the caller joins them).
+int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const int32_t* idx, const float* adv_d, const float* target_d, float* grad_d,
+                     bool grad, hipStream_t ns[2]) {
   NnWs& w = *ws_of(ctx);
-  const kbj_config& c = ctx->cfg_h;
-  if (B != w.B) return kbj_fail(ctx, "kbj_ppo_grad: B must equal config.batch_size");
-  int T = tr->T, N = tr->N, H = w.H;
-  if (T != w.T || N != w.N) return kbj_fail(ctx, "kbj_ppo_grad: trajectory shape does not match the context");
+  const Sched& sc = w.sched;
+  const int T = tr->T, N = tr->N, H = w.H, B = w.B, R = T * B, D = w.D;
   hipStream_t s = ctx->stream;
-  const int R = T * B;
-  KbjTimed timed(ctx, true);
-  const int* idx = env_idx_d;
-  // ---- gather the minibatch: the large critic observation block on the critic's stream, everything else on the caller's ----
-  static const bool one_stream = getenv("KBJ_ONE_STREAM") != nullptr;   // diagnostics: serialise the two nets
-  hipStream_t ns[2] = {ctx->stream, one_stream ? ctx->stream : ctx->stream2};
+  ns[0] = ctx->stream; ns[1] = sc.one_stream ? ctx->stream : ctx->stream2;
   // hand-off counters of all eight (sixteen with the mirror branches) recurrence launches of this call: one clear, ahead of both lanes
   KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, 2 * MAXD * 4 * SEQ_COUNTER_WORDS * sizeof(unsigned), s));
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  static const bool fold_actor = getenv("KBJ_FOLD_ACTOR") ? atoi(getenv("KBJ_FOLD_ACTOR")) != 0 : true;
-  // The critic's input projection folds the same way in the BACKWARD pass only (475 > H inputs, so forward the two-step form is cheaper):
-  // Z = dG0^T obs beside dW_hh0 in one launch, then dW_in = W_ih0^T Z, dW_ih0 = Z W_in^T: 110 instead of 126 GFLOP in the tail phase and no
-  // dX0 -> dW_in -> bias-sum chain at its end. It did not pay while the lanes met at the loss (+0.1 ms); with independent, balanced lanes
-  // and the small products split over k it does: 6.55 -> 6.46 ms per minibatch. KBJ_FOLD_CRITIC=0: two-step form.
-  static const bool fold_critic = getenv("KBJ_FOLD_CRITIC") ? atoi(getenv("KBJ_FOLD_CRITIC")) != 0 : true;
   // (first on the actor's lane, ahead of the gathers: the two small launches depend on the parameters only, and behind the gathers they
   // queue for CU slots behind the 800 workgroups of the critic's input projection - 87 us on the actor's chain instead of ~25)
-  if (fold_actor) {
+  if (sc.fold_actor) {
     // The actor's input projection (65 -> H, no activation) feeds only layer 0's input GEMM, so gates_0 = obs (W_ih0 W_in)^T +
     // (W_ih0 b_in + b_0): a 65-deep contraction instead of 65 -> H -> 4H (6.8 instead of 28.5 GFLOP per minibatch forward, and
     // 6.8 instead of 55 GFLOP backward). Same function, different rounding order (inside the parity tolerances).
@@ -729,9 +784,10 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     gemm_launch<true, false>(s, g);
     hipLaunchKernelGGL(matvec_kernel, dim3((4 * H + 3) / 4), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
     // each accumulator is cleared on the lane whose side stream later accumulates into it (actor-type nets: the caller's stream,
-    // critic-type nets with KBJ_FOLD_CRITIC: the second stream), so the clear is always ordered before the split-K atomics
-    for (int n = 0; n < w.nnets; ++n)
-      if ((n & 1) == 0 || fold_critic) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), ns[n & 1]));
+    // critic-type nets with the backward fold: the second stream), so the clear is always ordered before the split-K accumulation
+    if (grad)
+      for (int n = 0; n < w.nnets; ++n)
+        if ((n & 1) == 0 || sc.fold_critic) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), ns[n & 1]));
   }
   auto gather = [&](hipStream_t st, const float* src, int wdt, int lds, float* dst, int ldd) {
     if (wdt % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && ((size_t)src & 15) == 0 && ((size_t)dst & 15) == 0)
@@ -739,17 +795,18 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
                          reinterpret_cast<float4*>(dst));
     else hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)R * wdt), dim3(256), 0, st, src, idx, T, N, B, wdt, lds, ldd, dst);
   };
+  // the large critic observation block on the critic's stream, everything else on the caller's
   gather(ns[1], tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);
   gather(s, tr->actor_obs_d, KBJ_LD_ACTOR, KBJ_LD_ACTOR, w.tb[0].obs, KBJ_LD_ACTOR);
-  GatherSmallArgs gs{tr->action_d, tr->logp_d, tr->value_d, adv_d, target_d, tr->aux_d, w.act, w.logp_old, w.val_old, w.adv, w.target, w.keep};
+  GatherSmallArgs gs{tr->action_d, grad ? tr->logp_d : nullptr, grad ? tr->value_d : nullptr, adv_d, target_d, tr->aux_d, w.act, w.logp_old, w.val_old, w.adv, w.target, w.keep};
   hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R * (KBJ_NU + 5)), dim3(256), 0, s, gs, idx, T, N, B);
   const float* carry0[4] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d, tr->carry0_actor_mirror_hc_d, tr->carry0_critic_mirror_hc_d};
   if (w.mirror && (!carry0[2] || !carry0[3] || !tr->carry0_lpf_mirror_d))
-    return kbj_fail(ctx, "kbj_ppo_grad: the mirror losses are enabled, the trajectory needs the mirror-branch carries");
+    return kbj_fail(ctx, "PPO pass: the mirror losses are enabled, the trajectory needs the mirror-branch carries");
   GatherCarryArgs gc;
   gc.nplanes = 0;
   for (int n = 0; n < w.nnets; ++n)
-    for (int l = 0; l < w.D; ++l) {  // carry at the start of the trajectory: [N][H] planes h, c of every layer
+    for (int l = 0; l < D; ++l) {  // carry at the start of the trajectory: [N][H] planes h, c of every layer
       gc.src[gc.nplanes] = carry0[n] + (size_t)(2 * l) * N * H; gc.dst[gc.nplanes++] = w.tb[n].Hm[l];
       gc.src[gc.nplanes] = carry0[n] + (size_t)(2 * l + 1) * N * H; gc.dst[gc.nplanes++] = w.tb[n].Cm[l];
     }
@@ -757,10 +814,13 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   gc.src[gc.nplanes] = tr->carry0_lpf_d; gc.dst[gc.nplanes] = w.lpf0; gc.nlpf++;
   if (w.mirror) { gc.src[gc.nplanes + 1] = tr->carry0_lpf_mirror_d; gc.dst[gc.nplanes + 1] = w.lpf0_m; gc.nlpf++; }
   hipLaunchKernelGGL(gather_carry_kernel, dim3((B * H + 255) / 256, gc.nplanes + gc.nlpf), dim3(256), 0, s, gc, idx, B, H);
-  // nothing on the forward path needs these: the advantage statistics and the cleared accumulators are ready long before the loss
-  KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), s));
-  hipLaunchKernelGGL(adv_stats_kernel, dim3(32), dim3(256), 0, s, w.adv, R, w.stats);
-  KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), s));
+  if (grad) {
+    // nothing on the forward path needs these: the advantage statistics and the cleared accumulators are ready long before the loss
+    KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), s));
+    hipLaunchKernelGGL(adv_stats_kernel, dim3(32), dim3(256), 0, s, w.adv, R, w.stats, sc.deterministic ? w.detd : (double*)nullptr);
+    if (sc.deterministic) hipLaunchKernelGGL(reduce_double_kernel, dim3(1), dim3(64), 0, s, w.detd, 32, 2, w.stats);
+    KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), s));
+  }
   // the critic's lane needs keep / carries (gathered above on the caller's stream) before its first recurrence - not before its input
   // projection, which only reads its own gather: the wait sits in front of the recurrences below
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream));
@@ -769,45 +829,33 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)R * w.net[k].ld_obs), dim3(256), 0, ns[k], w.tb[k].obs, w.tb[2 + k].obs, (size_t)R, w.net[k].ld_obs, w.mtab[k]);
   // ---- forward through time: actor on the caller's stream, critic on the context's second stream (the recurrences are
   // latency bound, so the two nets overlap) ----
-  static const int bstamp_sel = getenv("KBJ_SEQ_BSTAMPS") ? atoi(getenv("KBJ_SEQ_BSTAMPS")) : 0;
-  static const int stamp_sel = getenv("KBJ_SEQ_STAMPS") ? atoi(getenv("KBJ_SEQ_STAMPS")) : 1;   // diagnostics: 1 + net + 2 * layer picks the stamped forward launch
+  static const int stamp_sel = getenv("KBJ_SEQ_STAMPS") ? atoi(getenv("KBJ_SEQ_STAMPS")) : 1;   // diagnostics build: 1 + net + 2 * layer picks the stamped forward launch
   const int stamp_net = (stamp_sel - 1) & 1, stamp_layer = ((stamp_sel - 1) >> 1) & 1;
   // forward: the K = H input projections (x W_ih^T + b) run inside the persistent recurrence, their MFMAs placed around the flag poll and
   // the h-tile fetch where the matrix pipe idles (kbj_lstm_seq.h FUSE): a fused launch takes 1.11 instead of 0.88 ms, the 0.41-0.48 ms
-  // GEMM in front of it and its 210 MB round trip of G disappear: ppo_grad 7.72 -> 7.47 ms. KBJ_SEQ_FUSE=0: separate GEMMs.
-  static const bool fuse_ih = getenv("KBJ_SEQ_FUSE") ? atoi(getenv("KBJ_SEQ_FUSE")) != 0 : true;
-  // the folded actor layer 0 the same way (observation row x Weff inside the recurrence, 17 k-steps): KBJ_SEQ_FUSE_OBS=0 keeps the GEMM
-  static const bool fuse_obs = fuse_ih && w.net[0].ld_obs == KBJ_LD_ACTOR && (getenv("KBJ_SEQ_FUSE_OBS") ? atoi(getenv("KBJ_SEQ_FUSE_OBS")) != 0 : true);
-  // Launch order is layer-major over the nets (nets 2, 3 = mirror branches, same weights, queued behind nets 0, 1 on the same two
-  // streams). KBJ_ALIGN=1 makes the two lanes wait for each other before every recurrence phase, so that recurrences only ever
-  // run next to recurrences and GEMMs next to GEMMs (diagnostic; no measurable difference).
-  static const bool align_on = getenv("KBJ_ALIGN") ? atoi(getenv("KBJ_ALIGN")) != 0 : false;   // measured neutral (7.92 vs 7.91 ms): off
-  auto align = [&]() {
-    if (!align_on || one_stream) return;
-    hipEvent_t ea = ctx->ev_pool[ctx->ev_next++ & 31], eb = ctx->ev_pool[ctx->ev_next++ & 31];
-    hipEventRecord(ea, ns[0]); hipEventRecord(eb, ns[1]);
-    hipStreamWaitEvent(ns[0], eb, 0); hipStreamWaitEvent(ns[1], ea, 0);
-  };
+  // GEMM in front of it and its 210 MB round trip of G disappear: ppo_grad 7.72 -> 7.47 ms. Sched::fuse_ih = false: separate GEMMs.
+  const bool fuse_ih = sc.fuse_ih;
+  // the folded actor layer 0 the same way (observation row x Weff inside the recurrence, 17 k-steps): Sched::fuse_obs = false keeps the GEMM
+  const bool fuse_obs = sc.fuse_obs && w.net[0].ld_obs == KBJ_LD_ACTOR;
+  // Launch order is layer-major over the nets (nets 2, 3 = mirror branches, same weights, queued behind nets 0, 1 on the same two streams).
   for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
-    if (!(fold_actor && (n & 1) == 0))   // actor-type nets: layer-0 gates come straight from the observations
+    if (!(sc.fold_actor && (n & 1) == 0))   // actor-type nets: layer-0 gates come straight from the observations
       linear_fwd(ns[n & 1], w.tb[n].obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, w.tb[n].X0, H, R, H, o.nin, 0);
   }
-  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));   // keep / carries gathered on the caller's stream
-  const int D = w.D;
+  if (!sc.one_stream) KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));   // keep / carries gathered on the caller's stream
   for (int l = 0; l < D; ++l) {
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
-      if (fold_actor && (n & 1) == 0 && l == 0) { if (!fuse_obs) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, KBJ_LD_ACTOR, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0); }
+      if (sc.fold_actor && (n & 1) == 0 && l == 0) { if (!fuse_obs) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, KBJ_LD_ACTOR, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0); }
       else if (!fuse_ih) linear_fwd(ns[n & 1], l == 0 ? t.X0 : t.Hout[l - 1], H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
     }
-    align();
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
       SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + SEQ_COUNTER_WORDS * (4 * l + n), w.seq_err, T, B, (n == stamp_net && l == stamp_layer) ? w.seq_stamps : nullptr};
-      if (fold_actor && (n & 1) == 0 && l == 0) {
+      if (sc.fold_actor && (n & 1) == 0 && l == 0) {
         if (fuse_obs) { fa.X = t.obs; fa.ldx = o.ld_obs; fa.Wih = w.Weff; fa.ldw = KBJ_LD_ACTOR; fa.bias = w.beff; fa.kx = o.nin; }   // gates_0 = obs Weff^T + beff inside the recurrence
       } else if (fuse_ih) {   // K = H input projections ride inside the recurrence (kbj_lstm_seq.h FUSE)
         fa.X = l == 0 ? t.X0 : t.Hout[l - 1]; fa.Wih = params_d + o.w_ih[l]; fa.bias = params_d + o.b[l];
@@ -815,10 +863,65 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       if (seq_fwd(ctx, ns[n & 1], H, fa)) return -1;
     }
   }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int kbj_ppo_forward(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const int32_t* env_idx_d, int B, kbj_ppo_vars* out) {
+  if (!ctx || !params_d || !tr || !env_idx_d || !out || !out->logp_d || !out->value_d) return kbj_fail(ctx, "kbj_ppo_forward: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  NnWs& w = *ws_of(ctx);
+  const kbj_config& c = ctx->cfg_h;
+  if (B != w.B) return kbj_fail(ctx, "kbj_ppo_forward: B must equal config.batch_size");
+  if (tr->T != w.T || tr->N != w.N) return kbj_fail(ctx, "kbj_ppo_forward: trajectory shape does not match the context");
+  const int T = tr->T, H = w.H, R = T * B, D = w.D;
+  hipStream_t ns[2];
+  if (ppo_forward_nets(ctx, params_d, tr, env_idx_d, nullptr, nullptr, nullptr, false, ns)) return -1;
+  hipStream_t s = ctx->stream;
+  for (int n = 0; n < 2; ++n) {
+    const NetOff& o = w.net[n];
+    linear_fwd(ns[n], w.tb[n].Hout[D - 1], H, params_d + o.w_out, H, params_d + o.b_out, w.tb[n].Out, 40, R, o.nout, H, 0);
+  }
+  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
+  hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.tb[0].obs, w.joint_bias_d, hp, R, w.y, w.sd);
+  hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0, hp, T, B, w.y);
+  hipLaunchKernelGGL(gaussian_logp_kernel, g1(R), dim3(256), 0, s, w.y, w.sd, w.act, R, out->logp_d, out->entropy_d ? out->entropy_d : w.ent);
+  if (out->action_std_d) KBJ_HIP(ctx, hipMemcpyAsync(out->action_std_d, w.sd, (size_t)R * KBJ_NU * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (out->action_mean_d) KBJ_HIP(ctx, hipMemcpyAsync(out->action_mean_d, w.y, (size_t)R * KBJ_NU * sizeof(float), hipMemcpyDeviceToDevice, s));
+  hipLaunchKernelGGL(critic_value_kernel, g1(R), dim3(256), 0, ns[1], w.tb[1].Out, 40, R, out->value_d);
+  if (!w.sched.one_stream) {
+    KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+    KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  }
+  hipLaunchKernelGGL(poison_vars_kernel, dim3(1), dim3(1), 0, s, w.seq_err, out->logp_d, out->value_d);   // a recurrence timed out: no silent garbage
+  KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_forward");
+  if (w.sched.debug_sync) return kbj_synchronize(ctx);
+  return 0;
+}
+
+int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const int32_t* env_idx_d, int B, const float* adv_d, const float* target_d,
+                 float* grad_d, float* metrics_d) {
+  if (!ctx || !params_d || !tr || !env_idx_d || !adv_d || !target_d || !grad_d || !metrics_d) return kbj_fail(ctx, "kbj_ppo_grad: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  NnWs& w = *ws_of(ctx);
+  const kbj_config& c = ctx->cfg_h;
+  const Sched& sc = w.sched;
+  if (B != w.B) return kbj_fail(ctx, "kbj_ppo_grad: B must equal config.batch_size");
+  int T = tr->T, N = tr->N, H = w.H;
+  if (T != w.T || N != w.N) return kbj_fail(ctx, "kbj_ppo_grad: trajectory shape does not match the context");
+  hipStream_t s = ctx->stream;
+  const int R = T * B, D = w.D;
+  KbjTimed timed(ctx, true);
+  const bool one_stream = sc.one_stream, fold_actor = sc.fold_actor, fold_critic = sc.fold_critic;
+  hipStream_t ns[2];
+  if (ppo_forward_nets(ctx, params_d, tr, env_idx_d, adv_d, target_d, grad_d, true, ns)) return -1;
+  static const int bstamp_sel = getenv("KBJ_SEQ_BSTAMPS") ? atoi(getenv("KBJ_SEQ_BSTAMPS")) : 0;   // diagnostics build only
   // Without the mirror branches the critic's one-output head, the value half of the loss and the head's backward are ONE kernel on the
   // critic's lane (critic_head_kernel: ~30 us instead of two degenerate GEMMs and three small kernels, ~220 us, on the longer chain).
-  static const bool fused_critic_head_on = !(getenv("KBJ_FUSED_CRITIC_HEAD") && atoi(getenv("KBJ_FUSED_CRITIC_HEAD")) == 0);
-  const bool fused_critic_head = fused_critic_head_on && !w.mirror && w.net[1].nout == 1;
+  const bool fused_critic_head = sc.fused_critic_head && !w.mirror && w.net[1].nout == 1;
   for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
     if (n == 1 && fused_critic_head) continue;
@@ -885,18 +988,20 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     TrainBufs& t = w.tb[n];
     if (!(n == 1 && fused_critic_head)) linear_bwd_input(ns[n & 1], t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
     fork_side(n);
-    linear_bwd_weight(side_of(n), t.dOut, 40, t.Hout[D - 1], H, grad_d + o.w_out, H, o.nout, H, R);
-    hipLaunchKernelGGL(colsum_kernel, dim3((o.nout + 63) / 64, 512), dim3(256), 0, side_of(n), t.dOut, R, o.nout, 40, grad_d + o.b_out);
+    linear_bwd_weight(ctx, side_of(n), t.dOut, 40, t.Hout[D - 1], H, grad_d + o.w_out, H, o.nout, H, R);
+    colsum_acc(ctx, side_of(n), t.dOut, R, o.nout, 40, grad_d + o.b_out);
     dh_above[n] = t.dHa; dx_out[n] = t.dHb;
   }
+  const int nrg = (B + SEQ_ROWS - 1) / SEQ_ROWS;
   for (int l = D - 1; l >= 0; --l) {
-    align();
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
       SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + SEQ_COUNTER_WORDS * (4 * (D + l) + n), w.seq_err, T, B, grad_d + o.b[l]};
+      ba.db_part = det_partials(ctx, ns[n & 1]);   // deterministic mode: per-row-group bias sums, added in order below
       if (w.seq_bstamps && bstamp_sel == 1 + n + 2 * l) ba.stamps = w.seq_bstamps;
       if (seq_bwd(ctx, ns[n & 1], H, ba)) return -1;
+      if (ba.db_part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, ns[n & 1], ba.db_part, nrg, 4 * H, grad_d + o.b[l]);
     }
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
@@ -913,16 +1018,18 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
         int sk = std::max(2, std::min(g_splitk_wgs / ((4 * H / ts) * (H / ts + (o.nin + ts - 1) / ts)), (R + 255) / 256));
         GemmArgs g{dG, t.Hm[0], grad_d + o.w_hh[0], nullptr, 4 * H, H + o.nin, R, 4 * H, H, H, 1, sk, nullptr};
         g.B2 = t.obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = o.ld_obs;
+        g.skws = sk_workspace(ctx, ws, (size_t)sk * 4 * H * (H + o.nin));
         gemm_launch<false, false>(ws, g, ts == 128 ? 1 : 0);
         // (a 4H-deep contraction on a handful of output tiles: split over k so that it is a short kernel, not a 130 us tail on 32 workgroups)
         GemmArgs g1a{params_d + o.w_ih[0], Z, grad_d + o.w_in, nullptr, H, o.nin, 4 * H, H, o.ld_obs, o.nin, 1, g_fold_sk, nullptr};
+        g1a.skws = sk_workspace(ctx, ws, (size_t)g_fold_sk * H * o.nin);   // (same lane, stream-ordered behind the launch above: the slab is free again)
         gemm_launch<false, false>(ws, g1a);
         GemmArgs g2a{Z, params_d + o.w_in, grad_d + o.w_ih[0], nullptr, 4 * H, H, o.nin, o.ld_obs, o.nin, H, 1, 1, nullptr};
         gemm_launch<true, true>(ws, g2a);
         continue;
       }
       linear_bwd_input(s, dG, 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
-      linear_bwd_weight2(ws, dG, 4 * H, t.Hm[l], l == 0 ? t.X0 : t.Hout[l - 1], H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
+      linear_bwd_weight2(ctx, ws, dG, 4 * H, t.Hm[l], l == 0 ? t.X0 : t.Hout[l - 1], H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
       std::swap(dh_above[n], dx_out[n]);
     }
   }
@@ -931,8 +1038,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     TrainBufs& t = w.tb[n];
     hipStream_t s = ns[n & 1];
     if (!(fold_actor && ((n & 1) == 0 || fold_critic))) {   // input projection (dh_above now holds dX0)
-      linear_bwd_weight(s, dh_above[n], H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
-      hipLaunchKernelGGL(colsum_kernel, dim3((H + 63) / 64, 512), dim3(256), 0, s, dh_above[n], R, H, H, grad_d + o.b_in);
+      linear_bwd_weight(ctx, s, dh_above[n], H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
+      colsum_acc(ctx, s, dh_above[n], R, H, H, grad_d + o.b_in);
     }
     if (!one_stream) { hipEventRecord(ctx->ev_side[n & 1], ctx->side[n & 1]); hipStreamWaitEvent(s, ctx->ev_side[n & 1], 0); }
   }
@@ -941,19 +1048,22 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   if (fold_actor)   // the bias terms of layer 0 (db_0 is complete now): db_in = W_ih0^T db_0, dW_ih0 += db_0 b_in^T (X0 = obs W_in^T + b_in)
     for (int k = 0; k < (fold_critic ? 2 : 1); ++k) {
       const NetOff& oa = w.net[k];
-      hipLaunchKernelGGL(matvec_t_acc_kernel, dim3((H + 63) / 64, 16), dim3(256), 0, ctx->stream, params_d + oa.w_ih[0], grad_d + oa.b[0], 4 * H, H, grad_d + oa.b_in);
+      float* part = det_partials(ctx, ctx->stream);
+      hipLaunchKernelGGL(matvec_t_acc_kernel, dim3((H + 63) / 64, 16), dim3(256), 0, ctx->stream, params_d + oa.w_ih[0], grad_d + oa.b[0], 4 * H, H, grad_d + oa.b_in, part);
+      if (part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, part, 16, H, grad_d + oa.b_in);
       hipLaunchKernelGGL(outer_acc_kernel, g1((size_t)4 * H * H), dim3(256), 0, ctx->stream, grad_d + oa.w_ih[0], grad_d + oa.b[0], params_d + oa.b_in, 4 * H, H);
     }
   // a recurrence that timed out left a truncated gradient: poison it so that every data-parallel rank skips the optimizer step
   hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d);
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_grad");
-  static const bool debug_sync = getenv("KBJ_DEBUG") && atoi(getenv("KBJ_DEBUG")) != 0;
-  if (debug_sync) return kbj_synchronize(ctx);   // KBJ_DEBUG=1: surface a hand-off timeout at the call that caused it
+  if (sc.debug_sync) return kbj_synchronize(ctx);   // KBJ_DEBUG=1: surface a hand-off timeout at the call that caused it
   return 0;
 }
 
 int kbj_set_learning_rate(kbj_ctx* ctx, float learning_rate) {
-  if (!ctx || !(learning_rate >= 0.0f)) return kbj_fail(ctx, "kbj_set_learning_rate: bad argument");
+  // a negative rate is legal: the reference's scale_by_adam + scale_by_schedule chain (train.py:1074-1075) has no sign flip and is served
+  // as written by passing minus the schedule's value (host/task.py update())
+  if (!ctx || !std::isfinite(learning_rate)) return kbj_fail(ctx, "kbj_set_learning_rate: bad argument");
   ctx->cfg_h.learning_rate = learning_rate;
   return 0;
 }
@@ -966,7 +1076,9 @@ int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const 
   hipStream_t s = ctx->stream;
   double* sumsq = w.stats + 10;
   KBJ_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double), s));
-  hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, s, grad_d, w.nparams, grad_scale, sumsq);
+  double* part = w.sched.deterministic ? w.detd : nullptr;
+  hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, s, grad_d, w.nparams, grad_scale, sumsq, part);
+  if (part) hipLaunchKernelGGL(reduce_double_kernel, dim3(1), dim3(64), 0, s, part, 512, 1, sumsq);
   AdamParams ap{c.learning_rate, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay, c.max_grad_norm,
                 (float)(1.0 - std::pow((double)c.adam_b1, (double)step)), (float)(1.0 - std::pow((double)c.adam_b2, (double)step)), grad_scale};
   hipLaunchKernelGGL(adamw_kernel, g1(w.nparams), dim3(256), 0, s, params_d, m_d, v_d, grad_d, w.nparams, sumsq, ap, w.seq_err);

@@ -146,10 +146,10 @@ __global__ void gather_small_kernel(GatherSmallArgs a, const int* __restrict__ i
   int c = (int)(i - r * W), b = (int)(r % B);
   size_t src = (r / B) * N + idx[b];
   if (c < KBJ_NU) a.action_o[r * KBJ_NU + c] = a.action[src * KBJ_NU + c];
-  else if (c == KBJ_NU) a.logp_o[r] = a.logp[src];
-  else if (c == KBJ_NU + 1) a.value_o[r] = a.value[src];
-  else if (c == KBJ_NU + 2) a.adv_o[r] = a.adv[src];
-  else if (c == KBJ_NU + 3) a.target_o[r] = a.target[src];
+  else if (c == KBJ_NU) { if (a.logp) a.logp_o[r] = a.logp[src]; }          // the forward-only pass (kbj_ppo_forward) gathers actions and keep flags only
+  else if (c == KBJ_NU + 1) { if (a.value) a.value_o[r] = a.value[src]; }
+  else if (c == KBJ_NU + 2) { if (a.adv) a.adv_o[r] = a.adv[src]; }
+  else if (c == KBJ_NU + 3) { if (a.target) a.target_o[r] = a.target[src]; }
   else a.keep_o[r] = a.aux[src * KBJ_AUX_SIZE + KBJ_AUX_DONE] != 0 ? 0.0f : 1.0f;
 }
 // the carries at the start of the trajectory: up to 16 [N][H] planes and 2 [N][20] low-pass states, one launch (blockIdx.y = plane)
@@ -216,14 +216,26 @@ __global__ void gaussian_logp_kernel(const float* __restrict__ y, const float* _
 
 // ---- PPO loss (restated ksim defaults): statistics pass then per-sample gradient coefficients ------------
 // stats[0..1] += sum(adv), sum(adv^2) over the minibatch (double accumulation, one atomic pair per block)
-__global__ void adv_stats_kernel(const float* __restrict__ adv, int R, double* __restrict__ stats) {
+// part != null (deterministic mode): the block's pair goes to part[2 * blockIdx.x ..] and reduce_double_kernel adds the blocks in order
+__global__ void adv_stats_kernel(const float* __restrict__ adv, int R, double* __restrict__ stats, double* __restrict__ part) {
   __shared__ double s1[256], s2[256];
   double a = 0, b = 0;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < R; i += 256 * gridDim.x) { double v = adv[i]; a += v; b += v * v; }
   s1[threadIdx.x] = a; s2[threadIdx.x] = b;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) { s1[threadIdx.x] += s1[threadIdx.x + o]; s2[threadIdx.x] += s2[threadIdx.x + o]; } __syncthreads(); }
-  if (threadIdx.x == 0) { atomicAdd(&stats[0], s1[0]); atomicAdd(&stats[1], s2[0]); }   // stats zeroed by the caller
+  if (threadIdx.x == 0) {
+    if (part) { part[2 * blockIdx.x] = s1[0]; part[2 * blockIdx.x + 1] = s2[0]; }
+    else { atomicAdd(&stats[0], s1[0]); atomicAdd(&stats[1], s2[0]); }   // stats zeroed by the caller
+  }
+}
+// out[j] += sum over blocks b (in order) of part[b * w + j], j < w (w <= 64): the fixed-order second stage of the double-precision sums
+__global__ void reduce_double_kernel(const double* __restrict__ part, int nblocks, int w, double* __restrict__ out) {
+  const int j = threadIdx.x;
+  if (j >= w) return;
+  double s = 0;
+  for (int b = 0; b < nblocks; ++b) s += part[(size_t)b * w + j];
+  out[j] += s;
 }
 struct PpoParams { float clip, vclip, vcoef, ecoef, lrclip, adv_eps; };
 // per sample: coefficients dL/dlogp, dL/dvalue, dL/dentropy(const) and metric partial sums (atomics into metrics_acc[8] doubles)
@@ -415,14 +427,18 @@ __global__ void matvec_kernel(const float* __restrict__ W, const float* __restri
 }
 // y[n] += sum_k W[k][n] x[k]   (W [K][N] row-major): block = 64 columns x 4 row phases, grid.y slices of k, one atomic per column and
 // block (a single thread per column walking all K rows serially took 270 us on the critical path of every minibatch)
-__global__ void matvec_t_acc_kernel(const float* __restrict__ W, const float* __restrict__ x, int K, int N, float* __restrict__ y) {
+// part != null (deterministic mode): block row blockIdx.y stores its sums to part[blockIdx.y][N] and reduce_rows_kernel adds the rows in order
+__global__ void matvec_t_acc_kernel(const float* __restrict__ W, const float* __restrict__ x, int K, int N, float* __restrict__ y, float* __restrict__ part) {
   __shared__ float red[4][64];
   int n = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   float s = 0;
   if (n < N) for (int k = ph + 4 * blockIdx.y; k < K; k += 4 * gridDim.y) s += W[(size_t)k * N + n] * x[k];
   red[ph][threadIdx.x & 63] = s;
   __syncthreads();
-  if (ph == 0 && n < N) atomicAdd(&y[n], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (ph == 0 && n < N) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (part) part[(size_t)blockIdx.y * N + n] = v; else atomicAdd(&y[n], v);
+  }
 }
 
 // C[m][n] += u[m] v[n]   (rank-1 update, C [M][N] row-major)
@@ -433,14 +449,25 @@ __global__ void outer_acc_kernel(float* __restrict__ C, const float* __restrict_
 }
 
 // column sums: out[n] (+)= sum_m X[m][n]  (bias gradients); one block per 64 columns, 256 threads = 4 row phases
-__global__ void colsum_kernel(const float* __restrict__ X, int M, int N, int ld, float* __restrict__ out) {
+// out[c] += sum over rows p (in order) of part[p][c]: the fixed-order second stage of the fp32 column sums (deterministic mode)
+__global__ void reduce_rows_kernel(const float* __restrict__ part, int nparts, int n, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  float s = 0.0f;
+  for (int p = 0; p < nparts; ++p) s += part[(size_t)p * n + c];
+  out[c] += s;
+}
+__global__ void colsum_kernel(const float* __restrict__ X, int M, int N, int ld, float* __restrict__ out, float* __restrict__ part) {
   __shared__ float red[4][64];
   int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   float s = 0;
   if (c < N) for (int m = ph + 4 * blockIdx.y; m < M; m += 4 * gridDim.y) s += X[(size_t)m * ld + c];
   red[ph][threadIdx.x & 63] = s;
   __syncthreads();
-  if (ph == 0 && c < N) atomicAdd(&out[c], red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (ph == 0 && c < N) {
+    const float v = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+    if (part) part[(size_t)blockIdx.y * N + c] = v; else atomicAdd(&out[c], v);
+  }
 }
 
 // ---- GAE (gamma, lambda train.py:1769-1770): one thread per env, reverse scan ------------------------------------------
@@ -460,14 +487,14 @@ __global__ void gae_kernel(const float* __restrict__ value, const float* __restr
 }
 
 // ---- AdamW with global-norm clipping (optax.adamw, train.py:1059-1077) -------------------------------------------------
-__global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float scale, double* __restrict__ out) {
+__global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float scale, double* __restrict__ out, double* __restrict__ part) {
   __shared__ double red[256];
   double s = 0;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { double v = (double)g[i] * scale; s += v * v; }
   red[threadIdx.x] = s;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
-  if (threadIdx.x == 0) atomicAdd(out, red[0]);
+  if (threadIdx.x == 0) { if (part) part[blockIdx.x] = red[0]; else atomicAdd(out, red[0]); }
 }
 struct AdamParams { float lr, b1, b2, eps, wd, max_norm, bc1, bc2, gscale; };
 // Fail-stop: a gradient whose global norm is not finite leaves parameters and moments untouched and raises err[1]; err[0] is the
@@ -476,6 +503,9 @@ struct AdamParams { float lr, b1, b2, eps, wd, max_norm, bc1, bc2, gscale; };
 // kbj_synchronize.
 __global__ void poison_grad_kernel(const unsigned* __restrict__ err, float* __restrict__ g) {
   if (err[0]) g[0] = __int_as_float(0x7FC00000);
+}
+__global__ void poison_vars_kernel(const unsigned* __restrict__ err, float* __restrict__ logp, float* __restrict__ value) {
+  if (err[0]) { logp[0] = __int_as_float(0x7FC00000); value[0] = __int_as_float(0x7FC00000); }
 }
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g, size_t n,
                              const double* __restrict__ sumsq, AdamParams ap, unsigned* __restrict__ err) {

@@ -34,6 +34,10 @@ class Traj(C.Structure):
                 ("carry0_lpf_mirror_d", C.c_void_p), ("reward_comps_d", C.c_void_p)]
 
 
+class PpoVars(C.Structure):
+    _fields_ = [("logp_d", C.c_void_p), ("value_d", C.c_void_p), ("entropy_d", C.c_void_p), ("action_std_d", C.c_void_p), ("action_mean_d", C.c_void_p)]
+
+
 class KernelStat(C.Structure):
     _fields_ = [("name", C.c_char * 96), ("launches", C.c_int32), ("total_ms", C.c_float), ("flops", C.c_double)]
 
@@ -67,6 +71,7 @@ SIGNATURES = {
     "kbj_rollout": (_i, [_vp, _vp, C.POINTER(Carry), _u32, _u32, C.POINTER(Traj)]),
     "kbj_gae": (_i, [_vp, C.POINTER(Traj), _vp, _vp]),
     "kbj_ppo_grad": (_i, [_vp, _vp, C.POINTER(Traj), _vp, _i, _vp, _vp, _vp, _vp]),
+    "kbj_ppo_forward": (_i, [_vp, _vp, C.POINTER(Traj), _vp, _i, C.POINTER(PpoVars)]),
     "kbj_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _f]),
     "kbj_set_learning_rate": (_i, [_vp, _f]),
     "kbj_profile_begin": (_i, [_vp]),
@@ -222,6 +227,11 @@ class Context:
     def ppo_grad(self, params, traj: Traj, env_idx, B, adv, target, grad, metrics):
         self.call("kbj_ppo_grad", _ptr(params), C.byref(traj), _ptr(env_idx), B, _ptr(adv), _ptr(target), _ptr(grad),
                   _ptr(metrics))
+
+    def ppo_forward(self, params, traj: Traj, env_idx, B, logp, value, entropy=None, action_std=None, action_mean=None):
+        """kbj_ppo_forward: the on-policy pass (no gradients) for the B envs `env_idx` names; outputs are [T][B](x20) in env_idx order."""
+        out = PpoVars(_ptr(logp), _ptr(value), _ptr(entropy), _ptr(action_std), _ptr(action_mean))
+        self.call("kbj_ppo_forward", _ptr(params), C.byref(traj), _ptr(env_idx), B, C.byref(out))
 
     def adamw_step(self, params, m, v, grad, step, grad_scale=1.0):
         self.call("kbj_adamw_step", _ptr(params), _ptr(m), _ptr(v), _ptr(grad), step, grad_scale)

@@ -86,13 +86,19 @@ def save_ckpt(path: str, params: np.ndarray, opt_m: np.ndarray, opt_v: np.ndarra
     model = [a for _, a in split_leaves(np.asarray(params), hidden_size, depth)]
     mu = [a for _, a in split_leaves(np.asarray(opt_m), hidden_size, depth)]
     nu = [a for _, a in split_leaves(np.asarray(opt_v), hidden_size, depth)]
-    with tarfile.open(path, "w:gz") as tar:
+    import os
+    tmp = path + ".tmp"        # never leave a truncated ckpt.bin behind: write beside it, flush to disk, then rename over it
+    with open(tmp, "wb") as fh, tarfile.open(fileobj=fh, mode="w:gz") as tar:
         _add(tar, "model_0", _npy_blobs(model))
         _add(tar, "opt_state_0", _npy_blobs([np.asarray(opt_count, np.int32)] + mu + nu))
         _add(tar, "state", json.dumps(state).encode())
         _add(tar, "config", _yaml(config).encode())
         for k, v in (extras or {}).items():
             _add(tar, "kbj_" + k, _npy_blobs([v]))
+        tar.close()
+        fh.flush()
+        os.fsync(fh.fileno())
+    os.replace(tmp, path)
 
 
 def load_ckpt(path: str, part: str = "all", hidden_size: Optional[int] = None, depth: int = 2):
@@ -121,20 +127,32 @@ def load_ckpt(path: str, part: str = "all", hidden_size: Optional[int] = None, d
         return join_leaves(_read_blobs(members["model_0"]), hidden_size, depth)
 
     def opt_state():
+        """optax state leaves: adam / adamw = ScaleByAdamState(count, mu, nu) [+ ...]; with a schedule (train.py:1067-1077) optax adds a
+        second integer `count` leaf (ScaleByScheduleState). Integer scalars are counters wherever they sit; the float leaves are mu then
+        nu in parameter order. Returns None when the member is absent or does not have that shape (model-only use still works)."""
+        if "opt_state_0" not in members:
+            return None
         blobs = _read_blobs(members["opt_state_0"])
-        if len(blobs) != 1 + 2 * nleaf:
-            raise ValueError(f"opt_state_0 holds {len(blobs)} leaves, expected count + 2 x {nleaf}")
-        return dict(count=int(np.asarray(blobs[0]).reshape(-1)[0]), mu=join_leaves(blobs[1:1 + nleaf], hidden_size, depth), nu=join_leaves(blobs[1 + nleaf:], hidden_size, depth))
+        is_count = lambda b: np.asarray(b).size == 1 and np.issubdtype(np.asarray(b).dtype, np.integer)   # optax counts are 0-d int32 (saved here as shape (1,))
+        counts = [int(np.asarray(b).reshape(-1)[0]) for b in blobs if is_count(b)]
+        arrays = [b for b in blobs if not is_count(b)]
+        if len(arrays) != 2 * nleaf:
+            return None
+        try:
+            return dict(count=counts[0] if counts else 0, counts=counts, mu=join_leaves(arrays[:nleaf], hidden_size, depth), nu=join_leaves(arrays[nleaf:], hidden_size, depth))
+        except ValueError:
+            return None
 
     if part == "model":
         return model()
     if part == "opt_state":
         return opt_state()
+    state = json.loads(members["state"].decode()) if "state" in members else {}
     if part == "state":
-        return json.loads(members["state"].decode())
+        return state
     if part == "config":
         return config
     if part != "all":
         raise ValueError(f"unknown part {part!r}")
     extras = {k[4:]: _read_blobs(v, 1)[0] for k, v in members.items() if k.startswith("kbj_")}
-    return dict(model=model(), opt_state=opt_state(), state=json.loads(members["state"].decode()), config=config, extras=extras)
+    return dict(model=model(), opt_state=opt_state(), state=state, config=config, extras=extras)

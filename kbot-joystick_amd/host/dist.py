@@ -14,9 +14,20 @@ def env_shard(num_envs_total: int, rank: int, world_size: int) -> tuple[int, int
     return n, rank * n
 
 
+FORCE_COLLECTIVE = False      # run the collective even at world_size 1 (tests: the RCCL leg on a one-GPU box)
+TIMING = None                 # set to a list to collect (start, end) CUDA event pairs around every gradient all-reduce (bench.py)
+
+
 def allreduce_grad_(grad: torch.Tensor, world_size: int) -> float:
-    """In-place SUM all-reduce; returns the scale (1/world) the optimizer step must apply."""
-    if world_size > 1:
+    """In-place SUM all-reduce on the current stream; returns the scale (1/world) the optimizer step must apply."""
+    if world_size > 1 or FORCE_COLLECTIVE:
         import torch.distributed as dist
-        dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+        if TIMING is not None and grad.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
+            e1.record()
+            TIMING.append((e0, e1))
+        else:
+            dist.all_reduce(grad, op=dist.ReduceOp.SUM)
     return 1.0 / world_size

@@ -15,6 +15,7 @@ import time
 from dataclasses import dataclass
 from typing import Optional
 
+import numpy as np
 import torch
 
 from ..spec import compiler, constants, layout as L
@@ -79,13 +80,17 @@ class HumanoidWalkingTaskConfig:
     # a pass locally, ONE all-reduce and ONE optimizer step per pass (fewer, larger steps - a different algorithm). KBJ_ALLREDUCE
     # in the environment overrides the default.
     allreduce: str = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_ALLREDUCE", "per_step"))
+    # bit-reproducible update: fixed-order reductions instead of fp32 / fp64 atomics in the gradient (kbj_config.deterministic); the
+    # reference's XLA program is deterministic by default, here it costs a few percent and is off unless asked for
+    deterministic: bool = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_DETERMINISTIC", "0") not in ("0", ""))
 
     def to_kbj(self, num_envs_local: int, env_id_offset: int = 0) -> L.Config:
         if self.batch_size <= 0 or num_envs_local % self.batch_size != 0:
             raise ValueError(f"batch_size {self.batch_size} must divide the per-GPU num_envs {num_envs_local}")
-        if self.use_lr_decay and self.adam_weight_decay == 0.0:
-            # train.py:1074-1075 chains scale_by_adam with scale_by_schedule and no sign flip (gradient ascent as written)
-            raise NotImplementedError("use_lr_decay with adam_weight_decay == 0 is not supported")
+        # use_lr_decay with adam_weight_decay == 0 is train.py:1074-1075: optax.chain(scale_by_adam(), scale_by_schedule(cosine_schedule)).
+        # AS WRITTEN that chain has no sign flip (optax.adam ends in scale_by_learning_rate = scale(-lr); scale_by_schedule does not), so
+        # the parameters move ALONG the Adam direction: p += lr_t * m / (sqrt(v) + eps). It is served as written - kbj_adamw_step with
+        # weight_decay 0 and the learning rate -cosine_decay_lr (update()) - and update() warns once, because it is gradient ascent.
         T = int(round(self.rollout_length_seconds / self.ctrl_dt))
         kw = dict(num_envs=num_envs_local, env_id_offset=env_id_offset, rollout_len=T, substeps=int(round(self.ctrl_dt / self.dt)),
                   solver_iterations=self.iterations, ls_iterations=self.ls_iterations, hidden_size=self.hidden_size, depth=self.depth,
@@ -94,7 +99,7 @@ class HumanoidWalkingTaskConfig:
                   drop_action_prob=self.drop_action_prob, var_scale=self.var_scale, entropy_coef=self.entropy_coef, gamma=self.gamma,
                   lam=self.lam, learning_rate=self.learning_rate, weight_decay=self.adam_weight_decay, switch_prob=self.ctrl_dt / 5,
                   actor_mirror_loss_scale=self.actor_mirror_loss_scale, critic_mirror_loss_scale=self.critic_mirror_loss_scale,
-                  lpf_alpha=self.ctrl_dt / (self.ctrl_dt + 1.0 / (2.0 * math.pi * self.cutoff_frequency)))
+                  lpf_alpha=self.ctrl_dt / (self.ctrl_dt + 1.0 / (2.0 * math.pi * self.cutoff_frequency)), deterministic=int(bool(self.deterministic)))
         if self.allreduce not in ("per_step", "per_pass"):
             raise ValueError(f"unknown allreduce mode {self.allreduce!r} (per_step | per_pass)")
         if self.terrain not in ("flat", "sine"):
@@ -222,7 +227,15 @@ class HumanoidWalkingTask:
                 if per_pass:
                     scale /= nmb                                     # mean over the pass's minibatches (and ranks)
                 if self.config.use_lr_decay:
-                    self.ctx.set_learning_rate(cosine_decay_lr(self.config, self.opt_step))
+                    lr = cosine_decay_lr(self.config, self.opt_step)
+                    if self.config.adam_weight_decay == 0.0:      # train.py:1074-1075 as written: no sign flip behind scale_by_adam
+                        if not getattr(self, "_warned_ascent", False):
+                            import warnings
+                            warnings.warn("use_lr_decay with adam_weight_decay == 0 reproduces train.py:1074-1075 as written: "
+                                          "optax.chain(scale_by_adam, scale_by_schedule) has no sign flip, the update ASCENDS the loss")
+                            self._warned_ascent = True
+                        lr = -lr
+                    self.ctx.set_learning_rate(lr)
                 self.opt_step += 1
                 self.ctx.adamw_step(self.params, self.opt_m, self.opt_v, g, self.opt_step, scale)
 
@@ -272,10 +285,28 @@ class HumanoidWalkingTask:
     def get_curriculum(self) -> wiring.CurriculumSpec:
         return wiring.CurriculumSpec()
 
-    def get_ppo_variables(self) -> dict:
-        """train.py:1510-1524 for the LAST rollout: ksim recomputes log-probs / values with the pre-update model in a separate
-        on-policy pass; here they are produced by the rollout's own policy steps (same parameters, same observations)."""
-        return dict(log_probs=self.traj.logp, values=self.traj.value, action=self.traj.action)
+    def get_ppo_variables(self, trajectory: Optional[TrajBuffers] = None, params: Optional[torch.Tensor] = None) -> dict:
+        """train.py:1510-1524. Without arguments: the variables of the LAST rollout as its own policy steps produced them (ksim recomputes
+        them with the pre-update model in a separate on-policy pass: same parameters, same observations). With `trajectory` (any
+        TrajBuffers of this task's shape - e.g. a reloaded one, or the last rollout after the parameters changed) and optionally
+        `params`: that separate pass itself (kbj_ppo_forward: both nets through the T steps from the trajectory's start carries, carry
+        reset where done, no gradients), minibatch by minibatch. Returns PPOVariables' per-step fields as [T][N](x20) tensors."""
+        if trajectory is None:
+            return dict(log_probs=self.traj.logp, values=self.traj.value, action=self.traj.action)
+        p = self.params if params is None else params
+        T, N, B, dev = self.T, self.N, self.B, self.device
+        out = dict(log_probs=torch.empty(T, N, device=dev), values=torch.empty(T, N, device=dev), entropy=torch.empty(T, N, device=dev),
+                   action_std=torch.empty(T, N, L.NU, device=dev), action_mean=torch.empty(T, N, L.NU, device=dev))
+        lp, v, en = (torch.empty(T, B, device=dev) for _ in range(3))
+        sd, mu = torch.empty(T, B, L.NU, device=dev), torch.empty(T, B, L.NU, device=dev)
+        for mb in range(N // B):
+            idx = torch.arange(mb * B, (mb + 1) * B, device=dev, dtype=torch.int32)
+            self.ctx.ppo_forward(p, trajectory.c, idx, B, lp, v, en, sd, mu)
+            sl = slice(mb * B, (mb + 1) * B)
+            out["log_probs"][:, sl], out["values"][:, sl], out["entropy"][:, sl] = lp, v, en
+            out["action_std"][:, sl], out["action_mean"][:, sl] = sd, mu
+        out["action"] = trajectory.action
+        return out
 
     def run_actor(self, actor_obs: torch.Tensor, critic_obs: torch.Tensor, step_index: int = 0):
         """train.py:1351-1379 + Actor.forward (:913-941) for all envs: returns the distribution's mode (filtered mean incl. biases).
@@ -300,6 +331,13 @@ class HumanoidWalkingTask:
         if self.mirror:
             extras.update(actor_mirror_hc=self.carry.actor_mirror_hc.cpu().numpy(), critic_mirror_hc=self.carry.critic_mirror_hc.cpu().numpy(),
                           lpf_mirror=self.carry.lpf_mirror.cpu().numpy())
+        # carries of Python StatefulReward terms (extra_rewards): tensors (or tuples / lists of tensors) per term name
+        import numpy as np
+        for name, carry in self._extra_carries.items():
+            leaves = list(carry) if isinstance(carry, (tuple, list)) else [carry]
+            for i, leaf in enumerate(leaves):
+                extras[f"extra_{name}_{i}"] = leaf.detach().cpu().numpy() if hasattr(leaf, "detach") else np.asarray(leaf)
+            extras[f"extra_{name}_n"] = np.asarray(len(leaves) if isinstance(carry, (tuple, list)) else 0, np.int32)   # 0: a bare tensor
         cfg = dataclasses.asdict(self.config)
         cfg["action_latency_range"] = list(cfg["action_latency_range"])
         if cfg.get("fixed_command") is not None:
@@ -314,8 +352,12 @@ class HumanoidWalkingTask:
         z = ckpt_io.load_ckpt(path, "all", hidden_size=self.H, depth=self.kcfg.depth)
         dev = self.device
         self.params.copy_(torch.from_numpy(z["model"]))
-        self.opt_m.copy_(torch.from_numpy(z["opt_state"]["mu"])); self.opt_v.copy_(torch.from_numpy(z["opt_state"]["nu"]))
-        self.opt_step, self.iteration = int(z["state"]["opt_step"]), int(z["state"]["num_steps"])
+        opt, st = z["opt_state"], z["state"]
+        if opt is not None:       # None: no optimizer member, or one this build cannot map onto (mu, nu): keep the fresh moments
+            self.opt_m.copy_(torch.from_numpy(opt["mu"])); self.opt_v.copy_(torch.from_numpy(opt["nu"]))
+        # `opt_step` is this build's key; an upstream checkpoint only has the optax `count` leaf (and xax's num_steps)
+        self.opt_step = int(st.get("opt_step", opt["count"] if opt is not None else 0))
+        self.iteration = int(st.get("num_steps", 0))
         x = z["extras"]
         if "es" not in x:
             return            # a model-only checkpoint (e.g. written by the reference): parameters and optimizer only
@@ -332,6 +374,12 @@ class HumanoidWalkingTask:
             self.carry.actor_mirror_hc.copy_(torch.from_numpy(x["actor_mirror_hc"]))
             self.carry.critic_mirror_hc.copy_(torch.from_numpy(x["critic_mirror_hc"]))
             self.carry.lpf_mirror.copy_(torch.from_numpy(x["lpf_mirror"]))
+        self._extra_carries = {}
+        for name in self.extra_rewards:      # Python StatefulReward carries; a term the checkpoint does not know starts from initial_carry
+            if f"extra_{name}_n" in x:
+                n = int(x[f"extra_{name}_n"])
+                leaves = [torch.from_numpy(np.array(x[f"extra_{name}_{i}"])).to(dev) for i in range(max(n, 1))]
+                self._extra_carries[name] = tuple(leaves) if n > 0 else leaves[0]
 
     @classmethod
     def load_task(cls, ckpt_path: str, device: Optional[torch.device] = None) -> "HumanoidWalkingTask":

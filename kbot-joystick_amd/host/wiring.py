@@ -140,7 +140,14 @@ def apply_reward_overrides(kcfg: L.Config, scales: Optional[dict], params: Optio
         for k, v in kv.items():
             if k not in REWARD_PARAM_FIELDS[name]:
                 raise KeyError(f"reward {name!r} has no parameter {k!r}; it has {sorted(REWARD_PARAM_FIELDS[name])}")
-            setattr(kcfg, REWARD_PARAM_FIELDS[name][k], float(v))
+            v = float(v)
+            # error scales sit in exp(-x / scale): zero, negative or non-finite values make the reward inf / NaN, GAE passes that into the
+            # gradient and the optimizer's non-finite guard then skips every step - refuse here, with the name
+            if ("error_scale" in k or k.endswith("_scale")) and not (v > 0.0 and v < float("inf")):
+                raise ValueError(f"reward {name!r}: {k} must be a positive finite number, got {v!r}")
+            if v != v or v in (float("inf"), float("-inf")):
+                raise ValueError(f"reward {name!r}: {k} must be finite, got {v!r}")
+            setattr(kcfg, REWARD_PARAM_FIELDS[name][k], v)
 
 
 def rewards(kcfg: L.Config) -> Dict[str, RewardSpec]:
@@ -155,6 +162,8 @@ def rewards(kcfg: L.Config) -> Dict[str, RewardSpec]:
 
 def optimizer(cfg, kcfg: L.Config) -> OptimizerSpec:
     kind = "adam" if cfg.adam_weight_decay == 0.0 else "adamw"
+    if cfg.use_lr_decay and cfg.adam_weight_decay == 0.0:
+        kind = "scale_by_adam+scale_by_schedule"      # train.py:1074-1075 as written: no sign flip (host/task.py update())
     if cfg.use_lr_decay:
         return OptimizerSpec(kind, cfg.learning_rate, cfg.adam_weight_decay, kcfg.adam_b1, kcfg.adam_b2, kcfg.adam_eps, kcfg.max_grad_norm,
                              "cosine_decay", cfg.lr_decay_steps, cfg.lr_final_multiplier)

@@ -87,6 +87,6 @@ def test_cosine_decay_schedule():
     assert abs(cosine_decay_lr(c, 0) - 5e-4) < 1e-12
     assert abs(cosine_decay_lr(c, 500) - 5e-4 * (0.99 * 0.5 + 0.01)) < 1e-12
     assert abs(cosine_decay_lr(c, 1000) - 5e-6) < 1e-12 and abs(cosine_decay_lr(c, 5000) - 5e-6) < 1e-12
-    c.to_kbj(4096)                                               # adamw + schedule is supported
-    with pytest.raises(NotImplementedError):
-        launch_config(use_lr_decay=True, adam_weight_decay=0.0).to_kbj(4096)
+    c.to_kbj(4096)                                               # adamw + schedule (train.py:1076-1077)
+    z = launch_config(use_lr_decay=True, adam_weight_decay=0.0).to_kbj(4096)   # scale_by_adam + scale_by_schedule (train.py:1074-1075): served too
+    assert z.weight_decay == 0.0

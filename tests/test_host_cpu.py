@@ -88,3 +88,73 @@ def test_oracle_rewards_follow_the_config(model):
     mod2 = L.default_config(num_envs=N, batch_size=N, rew_angvel_err=0.4)
     _, c2 = O.Oracle(model, mod2, 0).rewards(aux)
     assert np.allclose(c2[:, :, i], np.sqrt(c0[:, :, i]), atol=1e-6)                 # exp(-e/0.4) = sqrt(exp(-e/0.2))
+
+
+def test_upstream_style_checkpoint_without_kbj_members(tmp_path):
+    """A checkpoint as the reference's own run would leave it: no kbj_* members, no `opt_step` key in `state`, and an optimizer with a
+    schedule (train.py:1067-1077: optax adds a second integer `count` leaf). Model and optimizer load; the counters fall back to the
+    optax count; an optimizer member this build cannot map onto (mu, nu) degrades to model-only instead of failing."""
+    import io
+    import json
+    import tarfile
+    from kbot_joystick_amd.host import ckpt
+    H, depth = 64, 2
+    pa, pc = L.param_count(H, depth)
+    rng = np.random.default_rng(1)
+    p, m, v = (rng.standard_normal(pa + pc).astype(np.float32) for _ in range(3))
+    leaves = lambda flat: [a for _, a in ckpt.split_leaves(flat, H, depth)]
+
+    def write(path, opt_blobs):
+        with tarfile.open(path, "w:gz") as tar:
+            for name, data in (("model_0", ckpt._npy_blobs(leaves(p))), ("opt_state_0", opt_blobs), ("state", json.dumps(dict(num_steps=7, num_samples=123)).encode()),
+                               ("config", ckpt._yaml(dict(hidden_size=H, depth=depth)).encode())):
+                if data is None:
+                    continue
+                info = tarfile.TarInfo(name); info.size = len(data)
+                tar.addfile(info, io.BytesIO(data))
+
+    path = str(tmp_path / "upstream.bin")
+    write(path, ckpt._npy_blobs([np.asarray(41, np.int32)] + leaves(m) + leaves(v) + [np.asarray(41, np.int32)]))   # adamw under a schedule
+    z = ckpt.load_ckpt(path)
+    assert np.array_equal(z["model"], p) and z["extras"] == {} and "opt_step" not in z["state"]
+    assert z["opt_state"]["count"] == 41 and z["opt_state"]["counts"] == [41, 41]
+    assert np.array_equal(z["opt_state"]["mu"], m) and np.array_equal(z["opt_state"]["nu"], v)
+    write(path, ckpt._npy_blobs([np.asarray(3, np.int32)] + leaves(m)))          # a state this build cannot map: model-only
+    z = ckpt.load_ckpt(path)
+    assert z["opt_state"] is None and np.array_equal(z["model"], p)
+    write(path, None)                                                             # no optimizer member at all
+    assert ckpt.load_ckpt(path)["opt_state"] is None and np.array_equal(ckpt.load_ckpt(path, "model"), p)
+
+
+def test_checkpoint_write_is_atomic(tmp_path, monkeypatch):
+    """save_ckpt writes ckpt.bin.tmp, fsyncs and renames: a crash in the middle of a save leaves the previous checkpoint intact."""
+    from kbot_joystick_amd.host import ckpt
+    H, depth = 64, 1
+    pa, pc = L.param_count(H, depth)
+    p = np.arange(pa + pc, dtype=np.float32)
+    path = str(tmp_path / "ckpt.bin")
+    ckpt.save_ckpt(path, p, p, p, 1, H, depth, dict(num_steps=1, opt_step=1), dict(hidden_size=H, depth=depth))
+    assert os.listdir(tmp_path) == ["ckpt.bin"]
+    calls = []
+    real = ckpt._add
+
+    def failing(tar, name, data):
+        calls.append(name)
+        if name == "state":
+            raise OSError("disk full")
+        real(tar, name, data)
+    monkeypatch.setattr(ckpt, "_add", failing)
+    with pytest.raises(OSError):
+        ckpt.save_ckpt(path, 2 * p, p, p, 2, H, depth, dict(num_steps=2, opt_step=2), dict(hidden_size=H, depth=depth))
+    monkeypatch.setattr(ckpt, "_add", real)
+    assert np.array_equal(ckpt.load_ckpt(path, "model"), p) and ckpt.load_ckpt(path, "state")["num_steps"] == 1
+
+
+def test_reward_error_scales_are_validated():
+    from kbot_joystick_amd.host.task import launch_config
+    for bad in (0.0, -0.1, float("nan"), float("inf")):
+        with pytest.raises(ValueError, match="error_scale"):
+            launch_config(reward_params={"linvel": {"error_scale": bad}}).to_kbj(4096)
+    with pytest.raises(ValueError, match="finite"):
+        launch_config(reward_params={"base_height": {"standard_height": float("nan")}}).to_kbj(4096)
+    launch_config(reward_params={"roll_pitch": {"error_scale_zero_cmd": 0.02}, "feet_airtime": {"touchdown_penalty": 0.0}}).to_kbj(4096)

@@ -53,7 +53,10 @@ def main():
         git = subprocess.run(["git", "-C", root, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip() or None
     except Exception:
         git = None
-    out["_meta"] = dict(source_fingerprint=source_fingerprint(), git=git, command=os.environ.get("KBJ_PROFILE_CMD"))
+    cmd = os.environ.get("KBJ_PROFILE_CMD") or ""
+    m_steps, m_warm = re.search(r"--steps\s+(\d+)", cmd), re.search(r"--warmup\s+(\d+)", cmd)
+    iters = (int(m_steps.group(1)) if m_steps else 3) + (int(m_warm.group(1)) if m_warm else 1) + 1      # + bench.py's instrumented roofline iteration
+    out["_meta"] = dict(source_fingerprint=source_fingerprint(), git=git, command=cmd or None, iterations=iters)
     json.dump(out, sys.stdout, indent=1)
     print()
 

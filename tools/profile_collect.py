@@ -19,6 +19,9 @@ def main():
     tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
     src = os.path.join(ROOT, "gpurun_out", tag)
     out = os.path.join(ROOT, "profiles")
+    for name in ("bench_n1.json", "kernel_stats.md", "pmc_traffic.json", "pmc_bench_summary.json", "pmc_env_summary.json"):
+        if "Traceback" in open(os.path.join(src, name)).read():
+            raise SystemExit(f"profile_collect.py: {name} holds a traceback - refusing")
     line = [l for l in open(os.path.join(src, "bench_n1.json")) if l.startswith("{")][-1]
     bench = json.loads(line)
     json.dump(bench, open(os.path.join(out, f"{tag}_bench_n1.json"), "w"), indent=1)
@@ -74,6 +77,8 @@ def main():
         p = os.path.join(src, name)
         if os.path.exists(p):
             txt = "".join(l for l in open(p) if "amdgpu.ids" not in l)
+            if "Traceback" in txt or not txt.strip():      # a failed tool run is not a profile (round 2 committed one)
+                raise SystemExit(f"profile_collect.py: {p} holds a traceback or nothing - refusing to commit it as evidence")
             open(os.path.join(out, f"{tag}_{name}"), "w").write(txt)
     print(json.dumps({k: bench[k] for k in ("value", "ms_per_step")}))
 
