@@ -53,6 +53,13 @@ int kbj_env_reset_all(kbj_ctx* ctx, uint32_t seed, float* actor0_d, float* criti
  * (train.py:1091-1105, 1134-1144, 1155-1222, 1258-1269, 1775-1781).
  * action_d [N][20]; aux_t_d [N][72] row of this step (completed); *_next_d rows of step t+1. */
 int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d, float* aux_next_d);
+/* replaces: ksim's reset of the envs a Termination finished, for terminations decided OUTSIDE the step kernel - user-written terms in
+ * the reference's protocol (`Termination.__call__(physics_data, curriculum_level) -> {-1, 0, 1}`, train.py:817) evaluated by the host on
+ * the post-step record. mask_d [N] float: envs with a non-zero entry are re-initialised exactly as kbj_env_step re-initialises an env its
+ * own terminations finish (same reset / randomiser / command streams, episode counter + 1) and their rows of the NEXT observation arrays
+ * are rewritten; the others are untouched. The caller then writes the term's value into the step's KBJ_AUX_DONE column before
+ * kbj_carry_reset / kbj_rewards / kbj_gae read it. */
+int kbj_env_reset_where(kbj_ctx* ctx, const float* mask_d, float* actor_next_d, float* critic_next_d, float* aux_next_d);
 /* state save/restore (checkpointing, tests): ep [N][KBJ_EP_SIZE], es [N][KBJ_ES_SIZE]; synchronous */
 int kbj_env_get_state(kbj_ctx* ctx, float* ep_h, float* es_h);
 int kbj_env_set_state(kbj_ctx* ctx, const float* ep_h, const float* es_h);

@@ -16,6 +16,8 @@ struct kbj_ctx {
   hipStream_t stream2 = nullptr;   // second lane for the critic network inside kbj_ppo_grad
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t side[2] = {nullptr, nullptr};   // per-net side lanes for weight-gradient GEMMs
+  hipStream_t dxs[2] = {nullptr, nullptr};    // per-net lanes of the input-gradient GEMM chunks that run under the backward recurrence (chunk-gated schedule)
+  hipEvent_t ev_dx[2] = {nullptr, nullptr};
   hipEvent_t ev_side[2] = {nullptr, nullptr};
   hipEvent_t ev_pool[32] = {};                // lane-alignment events of kbj_ppo_grad
   int ev_next = 0;

@@ -26,6 +26,28 @@ __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restri
   PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
 }
 
+// re-initialise the envs whose mask entry is non-zero, exactly as env_step_kernel does for an env its own terminations finish (same
+// task_reset / task_write_obs on the env's state row: the episode counter advances, the randomisers, reset distributions and the first
+// command are drawn from the env's streams) and rewrite their next observation rows; other envs are untouched. For terminations decided
+// OUTSIDE the kernel (user-written Termination terms on the host, train.py:817 protocol).
+__global__ __launch_bounds__(64) void env_reset_where_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, uint32_t seed,
+                                                             float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ mask, float* actor_next,
+                                                             float* critic_next, float* aux_next) {
+  __shared__ KbjShared S;
+  const int env = blockIdx.x;
+  if (mask[env] == 0.0f) return;     // uniform over the workgroup
+  PFOR(k, (int)(sizeof(KbjModelLds) / sizeof(float))) reinterpret_cast<float*>(&S.mc)[k] = mc[k];
+  PFOR(k, KBJ_EP_SIZE) S.ep[k] = ep[(size_t)env * KBJ_EP_SIZE + k];
+  PFOR(k, KBJ_ES_SIZE) S.es[k] = es[(size_t)env * KBJ_ES_SIZE + k];
+  KBJ_SYNC();
+  Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
+  PhysConst pc = phys_const(*c, *m);
+  task_reset(S, *m, *c, pc, rng);
+  task_write_obs(S, *m, *c, rng, actor_next + (size_t)env * KBJ_LD_ACTOR, critic_next + (size_t)env * KBJ_LD_CRITIC, aux_next + (size_t)env * KBJ_AUX_SIZE);
+  PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
+  PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
+}
+
 // register budget of the step kernel: 13.4 KB of LDS lets 12 single-wavefront workgroups share a CU (3 waves/SIMD), which
 // needs <= 168 VGPRs. `amdgpu_num_vgpr(N)` makes hipcc allocate 2 N registers for this wave64 kernel (floor 129): N = 84 gives
 // exactly 168 with 61 spilled values. Measured (8192 envs, ms/step): no cap (2 waves/SIMD, no spills) 3.26 -> N = 62 (129 VGPRs,
@@ -205,6 +227,15 @@ int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* act
   if (!action_d || !aux_t_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_step: null pointer");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   return kbj_env_step_range(ctx, ctx->stream, 0, ctx->cfg_h.num_envs, action_d, aux_t_d, actor_next_d, critic_next_d, aux_next_d);
+}
+
+int kbj_env_reset_where(kbj_ctx* ctx, const float* mask_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {
+  if (!ctx || !mask_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_reset_where: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  hipLaunchKernelGGL(env_reset_where_kernel, dim3(ctx->cfg_h.num_envs), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->mc_d, ctx->seed, ctx->ep_d, ctx->es_d,
+                     mask_d, actor_next_d, critic_next_d, aux_next_d);
+  KBJ_CHECK_LAUNCH(ctx, "env_reset_where_kernel");
+  return 0;
 }
 
 int kbj_env_get_state(kbj_ctx* ctx, float* ep_h, float* es_h) {

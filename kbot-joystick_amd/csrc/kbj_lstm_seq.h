@@ -77,6 +77,11 @@ struct SeqBwdArgs {
   unsigned* err;
   int T, B;
   float* db;             // optional [4H]: bias gradient accumulated with atomics (column sums of dG)
+  // chunk-gated schedule: after its hand-off of step t = c * chunk_steps (the last step of time chunk c, the recurrence runs downwards)
+  // every workgroup adds 1 to progress[c]; once the count reaches the grid size the chunk's dG rows [c * chunk_steps, ...) are complete
+  // and drained, and the GEMMs that consume them (seq_gate_kernel in front of them on their own lanes) start while the recurrence goes on
+  unsigned* progress = nullptr;
+  int chunk_steps = 0;
   float* db_part = nullptr;   // deterministic mode: [row groups][4H] per-row-group column sums instead (added to db in order by reduce_rows_kernel)
   unsigned spin_limit = SEQ_SPIN_LIMIT;
   long long* stamps = nullptr;   // optional [T][10] shader-clock stamps of workgroup 0 (diagnostics)
@@ -485,6 +490,7 @@ __global__ __launch_bounds__(256 * UW) __attribute__((amdgpu_num_vgpr(KBJ_SEQ_BW
     }
     SEQ_BSTAMP(7);
     seq_publish(a.counters + rg * NUG + ug, (unsigned)(T - t));
+    if (a.progress && tid == 0 && t % a.chunk_steps == 0) __hip_atomic_fetch_add(a.progress + t / a.chunk_steps, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SEQ_BSTAMP(8);
   }
   // bias gradient = column sums of dG over all rows and steps: reduce this workgroup's 32 rows in LDS, one atomic per column
@@ -505,6 +511,19 @@ __global__ __launch_bounds__(256 * UW) __attribute__((amdgpu_num_vgpr(KBJ_SEQ_BW
     }
   }
   if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 2] = wall_clock64();
+}
+
+// Gate in front of a consumer of a time chunk (one wavefront, one lane polling): returns once *ctr >= target, i.e. once every workgroup
+// of the recurrence has handed off the chunk's last step. It only ever waits for a kernel that was enqueued BEFORE it (deadlock-free
+// whatever streams share a hardware queue), the spin is bounded, and it gives up at once when a recurrence has already timed out.
+__global__ void seq_gate_kernel(const unsigned* ctr, unsigned target, unsigned* err, unsigned spin_limit) {
+  if (threadIdx.x != 0) return;
+  unsigned spins = 0;
+  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    __builtin_amdgcn_s_sleep(32);
+    if (++spins > spin_limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+  }
 }
 
 // ---- one LSTM layer step for MANY independent rows (rollout: 8192 envs, no recurrence inside the launch) ------------------------------

@@ -38,7 +38,11 @@ struct Sched {
   bool one_stream = false;         // KBJ_ONE_STREAM=1: the whole update on the caller's stream (no lanes)
   bool debug_sync = false;         // KBJ_DEBUG=1: kbj_ppo_grad synchronises and reports device-side errors at the call that caused them
   bool deterministic = false;      // fixed-order reductions instead of fp32 / fp64 atomics (bit-reproducible update)
+  int bwd_chunks = 1;              // KBJ_BWD_CHUNKS=n (2..10): weight-gradient GEMMs per time chunk UNDER the backward recurrence (chunk-gated schedule);
+                                   // measured flat against 1 = behind the whole recurrence (6.37-6.45 vs 6.43 ms per minibatch)
+  bool chunk_dx = false;           // KBJ_BWD_CHUNK_DX=1 (with bwd_chunks > 1): the input-gradient GEMM per chunk as well (slower: 6.64 / 6.83 ms at 2 / 4 chunks)
 };
+constexpr int MAX_BWD_CHUNKS = 10;
 bool env_flag(const char* name, bool dflt) { const char* v = getenv(name); return v ? atoi(v) != 0 : dflt; }
 
 struct NnWs {
@@ -71,6 +75,7 @@ struct NnWs {
   double* stats = nullptr;  // [0..1] adv stats, [2..9] metric accumulators, [10] grad sumsq
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
+  unsigned* bwd_progress = nullptr;  // [layer][net][MAX_BWD_CHUNKS] chunk completion counts of the backward recurrences (cleared with the hand-off counters)
   long long* seq_stamps = nullptr;   // diagnostics (KBJ_SEQ_STAMPS=1): per-step clock stamps of one workgroup
   long long* seq_bstamps = nullptr;  // same for a backward recurrence (KBJ_SEQ_BSTAMPS = 1 + net + 2 * layer)
   std::vector<void*> allocs;
@@ -418,7 +423,8 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->Weff, 4 * H * KBJ_LD_ACTOR) || dalloc(ctx, *w, &w->beff, 4 * H)) return -1;
   for (int n = 0; n < w->nnets; ++n) if (dalloc(ctx, *w, &w->Zeff[n], 4 * H * w->net[n & 1].ld_obs)) return -1;
   if (hipMemset(w->Weff, 0, 4 * H * KBJ_LD_ACTOR * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset Weff");
-  if (dalloc(ctx, *w, &w->seq_counters, 2 * MAXD * 4 * SEQ_COUNTER_WORDS)) return -1;   // [phase: forward layer l = l, backward layer l = D + l][net][row group x unit group]
+  if (dalloc(ctx, *w, &w->seq_counters, 2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS)) return -1;
+  w->bwd_progress = w->seq_counters + 2 * MAXD * 4 * SEQ_COUNTER_WORDS;   // same allocation: one clear covers both   // [phase: forward layer l = l, backward layer l = D + l][net][row group x unit group]
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
   if (getenv("KBJ_SEQ_STAMPS")) { if (dalloc(ctx, *w, &w->seq_stamps, (size_t)T * 6)) return -1; }
   if (getenv("KBJ_SEQ_BSTAMPS")) { if (dalloc(ctx, *w, &w->seq_bstamps, (size_t)T * 10 + 768)) return -1; }
@@ -430,6 +436,10 @@ int kbj_nn_create(kbj_ctx* ctx) {
     sc.fused_critic_head = env_flag("KBJ_FUSED_CRITIC_HEAD", true); sc.rollout_step = env_flag("KBJ_ROLLOUT_STEP", true);
     sc.one_stream = env_flag("KBJ_ONE_STREAM", false); sc.debug_sync = env_flag("KBJ_DEBUG", false);
     sc.deterministic = c.deterministic != 0 || env_flag("KBJ_DETERMINISTIC", false);
+    sc.bwd_chunks = getenv("KBJ_BWD_CHUNKS") ? atoi(getenv("KBJ_BWD_CHUNKS")) : 1;
+    sc.chunk_dx = env_flag("KBJ_BWD_CHUNK_DX", false);
+    if (sc.bwd_chunks < 1 || sc.bwd_chunks > MAX_BWD_CHUNKS) return kbj_fail(ctx, "KBJ_BWD_CHUNKS must be in 1..10");
+    if (sc.one_stream) sc.bwd_chunks = 1;   // no lanes, nothing to run under the recurrence
     if (sc.deterministic) {
       for (int l = 0; l < 4; ++l) if (dalloc(ctx, *w, &w->detp[l], (size_t)DETP_ROWS * DETP_COLS)) return -1;
       if (dalloc(ctx, *w, &w->detd, 2 * 512)) return -1;
@@ -770,9 +780,11 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
   hipStream_t s = ctx->stream;
   ns[0] = ctx->stream; ns[1] = sc.one_stream ? ctx->stream : ctx->stream2;
   // hand-off counters of all eight (sixteen with the mirror branches) recurrence launches of this call: one clear, ahead of both lanes
-  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, 2 * MAXD * 4 * SEQ_COUNTER_WORDS * sizeof(unsigned), s));
+  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, (2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS) * sizeof(unsigned), s));
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
+  // the gates of the dx lanes poll the chunk counters: never before this call's clear (the side lanes follow their net's lane later on)
+  for (int k = 0; k < 2; ++k) if (ctx->dxs[k]) KBJ_HIP(ctx, hipStreamWaitEvent(ctx->dxs[k], ctx->ev_fork, 0));
   // (first on the actor's lane, ahead of the gathers: the two small launches depend on the parameters only, and behind the gathers they
   // queue for CU slots behind the 800 workgroups of the critic's input projection - 87 us on the actor's chain instead of ~25)
   if (sc.fold_actor) {
@@ -993,12 +1005,28 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     dh_above[n] = t.dHa; dx_out[n] = t.dHb;
   }
   const int nrg = (B + SEQ_ROWS - 1) / SEQ_ROWS;
+  // Chunk-gated schedule (Sched::bwd_chunks > 1, off by default). The backward recurrence of a layer stays ONE persistent launch, but it
+  // counts the completion of every time chunk (SeqBwdArgs::progress), and the GEMMs that consume the chunk's dG rows - the layer's weight
+  // gradients on the net's side lane, with Sched::chunk_dx also its input gradient - are launched per chunk behind a seq_gate_kernel:
+  // they run UNDER the rest of the recurrence instead of after it. Meant to fill the layer-1 backward phase (the only one with idle matrix
+  // cores and nothing else to run) and to shorten the GEMM-only tail behind layer 0 to the last chunk; measured flat, because a GEMM
+  // workgroup that shares a CU with a recurrence workgroup stretches the recurrence by what it gains. Chunk c = time
+  // steps [c * TC, (c + 1) * TC); the recurrence runs downwards, so chunks complete from the last one to chunk 0. A gate only waits for a
+  // kernel enqueued before it. (Own lanes for the input-gradient chunks - KBJ_DX_LANE=1 - cost 0.7 ms per minibatch by merely existing:
+  // two more streams change how HIP maps this context's lanes onto hardware queues.)
+  const int nch_req = (sc.bwd_chunks > 1 && T >= 2 * sc.bwd_chunks) ? sc.bwd_chunks : 1;
+  const int TC = (T + nch_req - 1) / nch_req;
+  const int nch = (T + TC - 1) / TC;      // chunks that hold at least one step (T = 9 in 4 chunks of 3 steps: 3 chunks)
+  const unsigned seq_grid = (unsigned)(nrg * (H / (SEQ_UNITS * SEQ_UW)));
+  auto gate = [&](hipStream_t st, const unsigned* ctr) { hipLaunchKernelGGL(seq_gate_kernel, dim3(1), dim3(64), 0, st, ctr, seq_grid, w.seq_err, g_seq_spin_limit); };
+  auto dx_of = [&](int n) { return ctx->dxs[n & 1] ? ctx->dxs[n & 1] : side_of(n); };   // without dx lanes: on the side lane, ahead of the chunk's weight gradients
   for (int l = D - 1; l >= 0; --l) {
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
       SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + SEQ_COUNTER_WORDS * (4 * (D + l) + n), w.seq_err, T, B, grad_d + o.b[l]};
       ba.db_part = det_partials(ctx, ns[n & 1]);   // deterministic mode: per-row-group bias sums, added in order below
+      if (nch > 1) { ba.progress = w.bwd_progress + (size_t)(4 * l + n) * MAX_BWD_CHUNKS; ba.chunk_steps = TC; }
       if (w.seq_bstamps && bstamp_sel == 1 + n + 2 * l) ba.stamps = w.seq_bstamps;
       if (seq_bwd(ctx, ns[n & 1], H, ba)) return -1;
       if (ba.db_part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, ns[n & 1], ba.db_part, nrg, 4 * H, grad_d + o.b[l]);
@@ -1007,29 +1035,51 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
       hipStream_t s = ns[n & 1], ws = side_of(n);
-      float* dG = t.dGl[l];
-      fork_side(n);
-      if (fold_actor && l == 0 && ((n & 1) == 0 || fold_critic)) {
-        // layer 0 backwards through the (activation-free) input projection without dX0: dW_hh0 += dG0^T Hm and Z = dG0^T obs in
-        // one launch, then two small products carry Z back to the stored parameters: dW_in += W_ih0^T Z, dW_ih0 += Z W_in^T
-        // (the bias terms follow from db_0 at the end).
-        float* Z = w.Zeff[n];
-        const int ts = H % 128 == 0 ? 128 : 64;   // the column split (n1 = H) must fall on a tile boundary
-        int sk = std::max(2, std::min(g_splitk_wgs / ((4 * H / ts) * (H / ts + (o.nin + ts - 1) / ts)), (R + 255) / 256));
-        GemmArgs g{dG, t.Hm[0], grad_d + o.w_hh[0], nullptr, 4 * H, H + o.nin, R, 4 * H, H, H, 1, sk, nullptr};
-        g.B2 = t.obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = o.ld_obs;
-        g.skws = sk_workspace(ctx, ws, (size_t)sk * 4 * H * (H + o.nin));
-        gemm_launch<false, false>(ws, g, ts == 128 ? 1 : 0);
+      const unsigned* prog = w.bwd_progress + (size_t)(4 * l + n) * MAX_BWD_CHUNKS;
+      const bool folded = fold_actor && l == 0 && ((n & 1) == 0 || fold_critic);
+      if (nch == 1) fork_side(n);     // the side lane starts behind the whole recurrence
+      // (the dx and side lanes need no event from the net's lane here: a gate passes only once this layer's recurrence runs, and that
+      // recurrence started behind everything the lane did before - the previous readers of the dX buffer included)
+      for (int c = nch - 1; c >= 0; --c) {
+        const int t0 = c * TC, t1 = std::min(T, t0 + TC);
+        const size_t r0 = (size_t)t0 * B;
+        const int Rc = (t1 - t0) * B;
+        const float* dG = t.dGl[l] + r0 * 4 * H;
+        if (nch > 1) gate(ws, prog + c);
+        if (folded) {
+          // layer 0 backwards through the (activation-free) input projection without dX0: dW_hh0 += dG0^T Hm and Z = dG0^T obs in
+          // one launch (per chunk); two small products then carry Z back to the stored parameters (below, behind the last chunk)
+          float* Z = w.Zeff[n];
+          const int ts = H % 128 == 0 ? 128 : 64;   // the column split (n1 = H) must fall on a tile boundary
+          int sk = std::max(2, std::min(g_splitk_wgs / ((4 * H / ts) * (H / ts + (o.nin + ts - 1) / ts)), (Rc + 255) / 256));
+          GemmArgs g{dG, t.Hm[0] + r0 * H, grad_d + o.w_hh[0], nullptr, 4 * H, H + o.nin, Rc, 4 * H, H, H, 1, sk, nullptr};
+          g.B2 = t.obs + r0 * o.ld_obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = o.ld_obs;
+          g.skws = sk_workspace(ctx, ws, (size_t)sk * 4 * H * (H + o.nin));
+          gemm_launch<false, false>(ws, g, ts == 128 ? 1 : 0);
+          continue;
+        }
+        if (nch > 1 && sc.chunk_dx) {
+          if (dx_of(n) != ws) gate(dx_of(n), prog + c);
+          linear_bwd_input(dx_of(n), dG, 4 * H, params_d + o.w_ih[l], H, dx_out[n] + r0 * H, H, Rc, H, 4 * H, 0);
+        } else if (c == nch - 1) {   // the input gradient as ONE product on the net's own lane, behind the recurrence (it is the next layer's input)
+          linear_bwd_input(s, t.dGl[l], 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
+        }
+        linear_bwd_weight2(ctx, ws, dG, 4 * H, t.Hm[l] + r0 * H, (l == 0 ? t.X0 : t.Hout[l - 1]) + r0 * H, H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, Rc);
+      }
+      if (folded) {
+        // dW_in += W_ih0^T Z, dW_ih0 += Z W_in^T (the bias terms follow from db_0 at the end)
         // (a 4H-deep contraction on a handful of output tiles: split over k so that it is a short kernel, not a 130 us tail on 32 workgroups)
+        float* Z = w.Zeff[n];
         GemmArgs g1a{params_d + o.w_ih[0], Z, grad_d + o.w_in, nullptr, H, o.nin, 4 * H, H, o.ld_obs, o.nin, 1, g_fold_sk, nullptr};
-        g1a.skws = sk_workspace(ctx, ws, (size_t)g_fold_sk * H * o.nin);   // (same lane, stream-ordered behind the launch above: the slab is free again)
+        g1a.skws = sk_workspace(ctx, ws, (size_t)g_fold_sk * H * o.nin);   // (same lane, stream-ordered behind the launches above: the slab is free again)
         gemm_launch<false, false>(ws, g1a);
         GemmArgs g2a{Z, params_d + o.w_in, grad_d + o.w_ih[0], nullptr, 4 * H, H, o.nin, o.ld_obs, o.nin, H, 1, 1, nullptr};
         gemm_launch<true, true>(ws, g2a);
         continue;
       }
-      linear_bwd_input(s, dG, 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
-      linear_bwd_weight2(ctx, ws, dG, 4 * H, t.Hm[l], l == 0 ? t.X0 : t.Hout[l - 1], H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
+      if (nch > 1 && sc.chunk_dx) {   // the next layer's recurrence (and the input-projection gradient) read the whole dX: the net's lane waits for its dx lane
+        hipEventRecord(ctx->ev_dx[n & 1], dx_of(n)); hipStreamWaitEvent(s, ctx->ev_dx[n & 1], 0);
+      }
       std::swap(dh_above[n], dx_out[n]);
     }
   }

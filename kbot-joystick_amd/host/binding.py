@@ -57,6 +57,7 @@ SIGNATURES = {
     "kbj_synchronize": (_i, [_vp]),
     "kbj_env_reset_all": (_i, [_vp, _u32, _vp, _vp, _vp]),
     "kbj_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "kbj_env_reset_where": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "kbj_env_get_state": (_i, [_vp, _vp, _vp]),
     "kbj_env_set_state": (_i, [_vp, _vp, _vp]),
     "kbj_env_get_reward_carry": (_i, [_vp, _vp]),
@@ -171,6 +172,9 @@ class Context:
 
     def env_step(self, action, aux_t, actor_next, critic_next, aux_next):
         self.call("kbj_env_step", _ptr(action), _ptr(aux_t), _ptr(actor_next), _ptr(critic_next), _ptr(aux_next))
+
+    def env_reset_where(self, mask, actor_next, critic_next, aux_next):
+        self.call("kbj_env_reset_where", _ptr(mask), _ptr(actor_next), _ptr(critic_next), _ptr(aux_next))
 
     def env_get_state(self):
         import numpy as np

@@ -67,6 +67,9 @@ class HumanoidWalkingTaskConfig:
     reward_scales: Optional[dict] = None          # e.g. {"feet_airtime": 2.0, "torque": 0.0}
     reward_params: Optional[dict] = None          # e.g. {"base_height": {"standard_height": 0.85}}
     command_ranges: Optional[dict] = None         # e.g. {"vx_range": (-0.5, 1.5)}; keys as UnifiedCommand's (train.py:1211-1217)
+    # the editable part of get_terminations() (train.py:1258-1269): {"bad_z": {"unhealthy_z": 0.4}, "not_upright": {"max_radians": 0.785},
+    # "episode_length": {"max_length_sec": 12}}; a threshold of -inf / +inf switches the built-in term off (a Python term may replace it)
+    termination_params: Optional[dict] = None
     # build-specific
     robot: str = "kbot"                # train.py:1080 loads robot/kbot; BASELINE configs use kbot-headless
     seed: int = 0
@@ -113,6 +116,17 @@ class HumanoidWalkingTaskConfig:
             if k not in ("vx_range", "vy_range", "wz_range", "bh_range", "rx_range", "ry_range"):
                 raise KeyError(f"unknown command range {k!r}")
             kw[k[:2] + "_lo"], kw[k[:2] + "_hi"] = float(lo), float(hi)
+        for name, kv in (self.termination_params or {}).items():
+            for k, v in kv.items():
+                v = float(v)
+                if (name, k) == ("bad_z", "unhealthy_z"):
+                    kw["unhealthy_z"] = max(v, -3.0e38)
+                elif (name, k) == ("not_upright", "max_radians"):
+                    kw["max_tilt_rad"] = min(v, math.pi)
+                elif (name, k) == ("episode_length", "max_length_sec"):
+                    kw["max_episode_steps"] = int(min(v / self.ctrl_dt, 2 ** 30))
+                else:
+                    raise KeyError(f"unknown termination parameter {name}.{k} (bad_z.unhealthy_z | not_upright.max_radians | episode_length.max_length_sec)")
         kcfg = L.default_config(**kw)
         wiring.apply_reward_overrides(kcfg, self.reward_scales, self.reward_params)
         return kcfg
@@ -143,10 +157,20 @@ class HumanoidWalkingTask:
     """
 
     def __init__(self, config: HumanoidWalkingTaskConfig, device: Optional[torch.device] = None, rank: int = 0, world_size: int = 1,
-                 extra_rewards: Optional[dict] = None):
+                 extra_rewards: Optional[dict] = None, extra_terminations: Optional[dict] = None, extra_observations: Optional[dict] = None):
         """extra_rewards: {name: term} of Python reward terms in ksim's Reward protocol (`scale`, `get_reward(trajectory)` or the stateful
-        pair), evaluated on `TrajectoryView` after every rollout and added to the built-in stack's reward (host/traj_view.py)."""
+        pair), evaluated on `TrajectoryView` after every rollout and added to the built-in stack's reward (host/traj_view.py).
+        extra_terminations: {name: term}, `term(state, curriculum_level) -> [N] in {-1, 0, 1}` (train.py:817) on a `StepView` after every
+        control step, OR-ed into the kernel's own terminations: the env is reset (kbj_env_reset_where), the model carries with it, GAE is
+        cut there. extra_observations: {name: term}, `term.observe(state, curriculum_level, rng)` or a plain callable -> [N, d]
+        (train.py:635, 682, 706), evaluated per control step and kept as [T + 1, N, d] tensors for the Python reward / termination terms
+        (`TrajectoryView.extra_observations[name]`); the networks' input rows stay the reference's 65 / 475 floats.
+        With either of the two the rollout runs step by step from the host (policy step, env step, user terms, carry reset: the same calls
+        kbj_rollout fuses, bit-identical when no user term fires) instead of as one kbj_rollout call."""
         self.extra_rewards = dict(extra_rewards or {})
+        self.extra_terminations = dict(extra_terminations or {})
+        self.extra_observations = dict(extra_observations or {})
+        self.extra_obs_buffers: dict = {}
         self._extra_carries: dict = {}
         self.extra_reward_means: dict = {}
         if not torch.cuda.is_available():
@@ -200,10 +224,53 @@ class HumanoidWalkingTask:
     # ---- the hot path ----
     def rollout(self):
         """T control steps of all envs, trajectory + rewards on the device."""
-        self.ctx.rollout(self.params, self.carry.c, self.config.seed, self.iteration * self.T, self.traj.c)
+        if self.extra_terminations or self.extra_observations:
+            self._rollout_stepwise()
+        else:
+            self.ctx.rollout(self.params, self.carry.c, self.config.seed, self.iteration * self.T, self.traj.c)
         if self.extra_rewards:
             from .traj_view import TrajectoryView, apply_extra_rewards
-            self.extra_reward_means = apply_extra_rewards(self.extra_rewards, self._extra_carries, TrajectoryView(self.traj, self.T), self.traj.reward)
+            view = TrajectoryView(self.traj, self.T)
+            view.extra_observations = {k: v[:self.T] for k, v in self.extra_obs_buffers.items()}
+            self.extra_reward_means = apply_extra_rewards(self.extra_rewards, self._extra_carries, view, self.traj.reward)
+
+    def _rollout_stepwise(self):
+        """kbj_rollout's steps as separate ABI calls with the user's Termination / Observation terms between the env step and the carry
+        reset (train.py:817, 635 protocols on host/traj_view.StepView)."""
+        from .traj_view import StepView, combine_terminations
+        T, tr, c = self.T, self.traj, self.ctx
+        done_col = 4 * L.AUX["DONE"]
+        tr.actor_obs[0].copy_(tr.actor_obs[T]); tr.critic_obs[0].copy_(tr.critic_obs[T]); tr.aux[0].copy_(tr.aux[T])   # row T of the last rollout is row 0 of this one
+        tr.carry0_actor_hc.copy_(self.carry.actor_hc); tr.carry0_critic_hc.copy_(self.carry.critic_hc); tr.carry0_lpf.copy_(self.carry.lpf)
+        if self.mirror:
+            tr.carry0_actor_mirror_hc.copy_(self.carry.actor_mirror_hc); tr.carry0_critic_mirror_hc.copy_(self.carry.critic_mirror_hc)
+            tr.carry0_lpf_mirror.copy_(self.carry.lpf_mirror)
+        first = self.iteration * T
+
+        def observe(row: int, view):
+            for name, term in self.extra_observations.items():
+                v = term.observe(view, 1.0, None) if hasattr(term, "observe") else term(view)
+                v = v.reshape(self.N, -1).to(torch.float32)
+                if name not in self.extra_obs_buffers:
+                    self.extra_obs_buffers[name] = torch.zeros(T + 1, self.N, v.shape[1], device=self.device)
+                self.extra_obs_buffers[name][row].copy_(v)
+
+        for name, buf in self.extra_obs_buffers.items():
+            buf[0].copy_(buf[T])
+        for t in range(T):
+            c.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], self.carry.c, self.config.seed, first + t, False, tr.action[t], tr.logp[t], tr.value[t])
+            c.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
+            view = StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob)
+            if self.extra_terminations:
+                user = combine_terminations(self.extra_terminations, view)
+                fire = (user != 0) & (tr.aux[t][:, L.AUX["DONE"]] == 0)          # the kernel's own terminations already reset their envs
+                c.env_reset_where(fire.to(torch.float32), tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
+                tr.aux[t][:, L.AUX["DONE"]] = torch.where(fire, user, tr.aux[t][:, L.AUX["DONE"]])
+                view = StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob)
+            if self.extra_observations:
+                observe(t + 1, view)
+            c.carry_reset(self.carry.c, tr.aux[t].data_ptr() + done_col, L.AUX["SIZE"])
+        c.rewards(tr.aux, T, tr.reward, tr.comps)
 
     def update(self):
         """GAE, then num_passes x (N / B) minibatch steps: BPTT gradient, all-reduce, AdamW."""

@@ -58,3 +58,58 @@ def apply_extra_rewards(terms: Dict[str, object], carries: Dict[str, object], vi
         reward.add_(r.to(reward.dtype), alpha=scale)
         means[name] = float(r.mean())
     return means
+
+
+class StepView:
+    """What a user-written Termination / Observation term sees after one control step of all envs (the reference hands such terms the
+    engine's `physics_data`, train.py:635, 682, 706, 817): the post-step record of the step (`KBJ_AUX_*`, the state BEFORE any reset) and
+    the next observation rows (the state the policy will see: post-reset for the envs the kernel's own terminations finished). [N, ...]
+    torch views on the device, no copies."""
+
+    def __init__(self, aux_t: torch.Tensor, actor_next: torch.Tensor, critic_next: torch.Tensor, aux_next: torch.Tensor, model):
+        A, O = L.AUX, L.OBS
+        self.N = aux_t.shape[0]
+        # ---- post-step, pre-reset (what the kernel's own terminations and the reward stack read) ----
+        self.base_qvel = aux_t[:, A["QVEL"]:A["QVEL"] + 6]
+        self.base_quat = aux_t[:, A["BQUAT"]:A["BQUAT"] + 4]
+        self.base_z = aux_t[:, A["BASEZ"]]                      # xpos[base].z
+        self.left_foot_z = aux_t[:, A["LFZ"]]                   # xpos[left foot].z
+        self.right_foot_z = aux_t[:, A["RFZ"]]
+        self.left_foot_quat = aux_t[:, A["LFQUAT"]:A["LFQUAT"] + 4]
+        self.right_foot_quat = aux_t[:, A["RFQUAT"]:A["RFQUAT"] + 4]
+        self.arm_qpos = aux_t[:, A["ARMQ"]:A["ARMQ"] + 10]
+        self.ctrl = aux_t[:, A["CTRL"]:A["CTRL"] + L.NU]
+        self.command = aux_t[:, A["CMD"]:A["CMD"] + L.NCMD]
+        self.done = aux_t[:, A["DONE"]]                         # the kernel's own terminations: -1 failure, +1 episode length
+        # ---- the next observation (clean critic pieces, train.py:1381-1433 order; KBJ_OBS_* offsets) ----
+        piece = lambda name: critic_next[:, O[name][0]:O[name][0] + O[name][1]]
+        bias = torch.tensor(list(model.joint_bias), device=aux_t.device)
+        rng = torch.tensor([max(b - lo, hi - b) for b, lo, hi in zip(model.joint_bias, model.joint_lo, model.joint_hi)], device=aux_t.device)
+        self.joint_position = piece("JPOS") * rng + bias         # qpos[7:]
+        self.joint_velocity = piece("JVEL") * L.OBS_JVEL_DIV     # qvel[6:]
+        self.projected_gravity = critic_next[:, O["PG"][0] + 2:O["PG"][0] + 5]
+        self.imu_gyro = piece("GYRO")
+        self.foot_touch = piece("TOUCH")
+        self.feet_position = piece("FEETPOS")
+        self.base_position = piece("BASEPOS")                    # qpos[0:3]
+        self.base_orientation = piece("BASEQUAT")                # qpos[3:7]
+        self.center_of_mass_inertia = piece("CINERT").reshape(self.N, -1, 10)
+        self.center_of_mass_velocity = piece("CVEL").reshape(self.N, -1, 6)
+        self.base_linear_velocity = piece("LINVEL")
+        self.base_angular_velocity = piece("ANGVEL")
+        self.actuator_force = piece("ACTFRC") * L.OBS_ACTFRC_DIV
+        self.base_height = piece("HEIGHT")[:, 0]
+        self.com_distance = aux_next[:, A["COMDIST"]]
+        self.actor_obs, self.critic_obs = actor_next[:, :L.NOBS_ACTOR], critic_next[:, :L.NOBS_CRITIC]
+
+
+def combine_terminations(terms: Dict[str, object], view: StepView, curriculum_level: float = 1.0) -> torch.Tensor:
+    """[N] float in {-1, 0, 1}: the first non-zero answer of the user terms, in dictionary order (train.py:1258-1269 lists them likewise)."""
+    out = torch.zeros(view.N, device=view.done.device)
+    for name, term in terms.items():
+        v = term(view, curriculum_level) if callable(term) else term.__call__(view, curriculum_level)
+        v = v.to(out.dtype)
+        if v.shape != out.shape:
+            raise ValueError(f"termination {name!r} returned shape {tuple(v.shape)}, expected {tuple(out.shape)}")
+        out = torch.where(out != 0, out, torch.sign(v))
+    return out

@@ -68,6 +68,7 @@ def test_teacher_forced_steps_match_oracle(model, N, steps, command):
     rng = np.random.default_rng(0)
     errs, errs_o32, errs64, switch = {k: [] for k in H.TOL}, {k: [] for k in H.TOL}, {k: [] for k in H.TOL}, []
     obs_a, obs_c, ndone = [], [], 0
+    cd_err, touch_err = [], []
     for t in range(steps):
         act = H.random_actions(model, rng, N)
         ep0, es0 = o.ep.copy(), o.es.copy()
@@ -106,9 +107,19 @@ def test_teacher_forced_steps_match_oracle(model, N, steps, command):
         obs_c.append((np.abs(c0 - c2.cpu().numpy()) / (1 + np.abs(c0))).max(1)[run])
         # com_distance (a17) and touch beyond the reset, compared directly (pre-divergence: same state in, one step)
         nx = x2.cpu().numpy()
-        assert np.quantile(np.abs(nx[run, L.AUX["COMDIST"]] - x0[run, L.AUX["COMDIST"]]), 0.99) < 1e-4
-        assert np.quantile(np.abs(nx[run, L.AUX["TOUCH"]:L.AUX["TOUCH"] + 2] - x0[run, L.AUX["TOUCH"]:L.AUX["TOUCH"] + 2]).max(1), 0.99) < 5e-2
+        cd_err.append(np.abs(nx[run, L.AUX["COMDIST"]] - x0[run, L.AUX["COMDIST"]]))
+        touch_err.append(np.abs(nx[run, L.AUX["TOUCH"]:L.AUX["TOUCH"] + 2] - x0[run, L.AUX["TOUCH"]:L.AUX["TOUCH"] + 2]).max(1))
     assert ndone > 0 or steps < 30                                   # the reset path is exercised in the long case
+    # a17 com_distance and the foot touch sensors of the next observation. Measured at 8192 envs x 12 steps against the fp64 oracle
+    # (tools/parity_quantiles.py -> profiles/parity_r03.json): com_distance p99 1.0e-7, p99.9 1.4e-7, max 1.1e-3 (the one env-step on a
+    # solver switch; the fp32 oracle's own max 1.7e-4); touch (newtons) p99 3.7e-3, p99.9 5.8e-3, max 195 = a contact that closes in one
+    # evaluation and not in the other (the fp32 oracle's own: 3.7e-3 / 5.5e-3 / 176). Bounds = ~10x the quantiles, a capped count of
+    # outliers for the discrete events, and a hard cap on the extreme value.
+    cd, tc = np.concatenate(cd_err), np.concatenate(touch_err)
+    assert np.quantile(cd, 0.99) < 2e-6 and np.quantile(cd, 0.999) < 1e-5 and cd.max() < 0.02, (np.quantile(cd, 0.99), np.quantile(cd, 0.999), cd.max())
+    assert (cd > 1e-4).sum() <= 2 + cd.size // 20000
+    assert np.quantile(tc, 0.99) < 5e-2 and np.quantile(tc, 0.999) < 0.2, (np.quantile(tc, 0.99), np.quantile(tc, 0.999))
+    assert (tc > 1.0).sum() <= 3 + tc.size // 5000 and tc.max() < 400.0, ((tc > 1.0).sum(), tc.max())      # 400 N = the robot's weight
     oa, oc = np.concatenate(obs_a), np.concatenate(obs_c)
     # observation rows (measured vs fp64: actor median 1.2e-6, p99 6.7e-6; critic (relative) median 4.5e-6, p99 2.6e-5)
     assert np.median(oa) < 5e-6 and np.quantile(oa, 0.99) < 3e-5 and np.median(oc) < 2e-5 and np.quantile(oc, 0.99) < 1e-4

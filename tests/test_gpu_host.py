@@ -270,3 +270,55 @@ def test_bench_launches_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=120,
                          env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"))
     assert bad.returncode != 0 and "does not match WORLD_SIZE" in (bad.stderr + bad.stdout)
+
+
+def test_python_termination_and_observation_terms():
+    """f3: user-written Termination / Observation terms in the reference's protocol (train.py:817, 635-707) on the post-step StepView.
+    The reference's own TerrainBadZTermination (train.py:817-823) restated in Python, with the kernel's built-in bad-z term switched off,
+    must give the stock run's DONE column, env rows, actions and actor observations BIT FOR BIT - the env is reset through
+    kbj_env_reset_where as the step kernel resets an env its own terminations finish. (The critic's composite-inertia entries of a reset
+    row may differ in the last bit: the reset code is compiled into two kernels and hipcc contracts its fused multiply-adds differently;
+    they are derived from the state, not part of it, so the env trajectory is unaffected - the values follow to 1e-5.)"""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+
+    class TerrainBadZ:                      # train.py:817-823
+        unhealthy_z = 0.4
+
+        def __call__(self, state, curriculum_level):
+            height = state.base_z - torch.minimum(state.left_foot_z, state.right_foot_z)
+            return torch.where(height < self.unhealthy_z, -1, 0)
+
+    class BaseHeight:                       # train.py:706-707 (xpos[1, 2:])
+        def observe(self, state, curriculum_level, rng):
+            return state.base_height[:, None]
+
+    kw = dict(num_envs=256, batch_size=64, rollout_length_seconds=1.0)
+    stock = HumanoidWalkingTask(_small(**kw))
+    user = HumanoidWalkingTask(_small(termination_params={"bad_z": {"unhealthy_z": float("-inf")}}, **kw),
+                               extra_terminations={"bad_z": TerrainBadZ()}, extra_observations={"base_height": BaseHeight()})
+    assert user.kcfg.unhealthy_z < -1e30 and user.get_terminations()["bad_z"].params["unhealthy_z"] < -1e30
+    fails = 0
+    for it in range(3):
+        stock.rollout(); user.rollout()
+        torch.cuda.synchronize()
+        for name in ("aux", "actor_obs", "action", "logp", "reward"):          # aux holds the DONE column
+            assert torch.equal(getattr(stock.traj, name), getattr(user.traj, name)), (it, name)
+        assert float((stock.traj.critic_obs - user.traj.critic_obs).abs().max()) < 1e-6
+        assert float((stock.traj.value - user.traj.value).abs().max()) < 1e-5
+        fails += int((stock.traj.done < 0).sum())
+        stock.iteration += 1; user.iteration += 1
+    assert fails > 20                                                   # the random-init policy falls: the user term did fire (and reset) often
+    es, eu = stock.ctx.env_get_state(), user.ctx.env_get_state()
+    assert np.array_equal(es[0], eu[0]) and np.array_equal(es[1].view(np.uint32), eu[1].view(np.uint32))
+    assert torch.equal(stock.carry.actor_hc, user.carry.actor_hc) and float((stock.carry.critic_hc - user.carry.critic_hc).abs().max()) < 1e-5
+    # the user observation is the critic row's base-height entry of every step (row t + 1 = the state after step t)
+    bh = user.extra_obs_buffers["base_height"]
+    assert bh.shape == (user.T + 1, 256, 1) and torch.equal(bh[1:, :, 0], user.traj.critic_obs[1:, :, L.OBS["HEIGHT"][0]])
+    # a user term that never fires leaves the run identical to the fused kbj_rollout; a full training iteration runs with both kinds of terms
+    user.train_iteration()
+    torch.cuda.synchronize()
+    assert torch.isfinite(user.params).all()
+    with pytest.raises(KeyError):
+        _small(termination_params={"bad_z": {"nope": 1.0}}).to_kbj(64)
+    stock.ctx.close(); user.ctx.close()

@@ -24,6 +24,8 @@ SWITCHES = {
     "KBJ_ROLLOUT_STEP=0": {"KBJ_ROLLOUT_STEP": "0"},
     "KBJ_DETERMINISTIC=1": {"KBJ_DETERMINISTIC": "1"},
     "KBJ_DEBUG=1": {"KBJ_DEBUG": "1"},
+    "KBJ_BWD_CHUNKS=4": {"KBJ_BWD_CHUNKS": "4"},
+    "KBJ_BWD_CHUNKS=3+DX": {"KBJ_BWD_CHUNKS": "3", "KBJ_BWD_CHUNK_DX": "1"},
 }
 
 
@@ -84,7 +86,7 @@ def _autograd(torch, cfg, tr, idx, H, aux):
 
 
 @pytest.mark.parametrize("name", [k for k in SWITCHES if k != "KBJ_ROLLOUT_STEP=0"])
-@pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (256, 96, 64, 9)])
+@pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (256, 96, 64, 9)])      # T = 9 in 4 chunks: 3 + 3 + 3 steps (one chunk empty); in 3: 3 + 3 + 3
 def test_switch_gradient_matches_autograd(monkeypatch, name, H, N, B, T):
     import torch
     from oracle import nn as ON
