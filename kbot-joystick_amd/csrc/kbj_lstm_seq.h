@@ -88,8 +88,10 @@ struct SeqBwdArgs {
 };
 
 // gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each; shared with the rollout cell kernel)
-__device__ __forceinline__ float seq_sigmoid(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float seq_tanh(float x) { float xc = fminf(fmaxf(x, -15.0f), 15.0f); return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * xc)); }
+// (__builtin_amdgcn_rcpf = one v_rcp_f32; __frcp_rn compiles to the 10-instruction correctly rounded division, and on this chip fp32 MFMA and
+// the vector ALU share the SIMD's issue: every vector instruction in a recurrence step is matrix time lost - DESIGN.md section 10)
+__device__ __forceinline__ float seq_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float seq_tanh(float x) { float xc = fminf(fmaxf(x, -15.0f), 15.0f); return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * xc)); }
 
 // wait until *ctr >= target: one lane polls the one word (relaxed, agent scope); returns false on timeout
 // flags: one word per producer workgroup of the row group (nflags consecutive words = one cache line), each holding the
@@ -186,6 +188,15 @@ template <int H, int NTH> struct SeqTile {
     }
   }
   __device__ __forceinline__ void to_lds(float* lds, int r0, int B) const {
+    if (r0 + SEQ_ROWS <= B) {   // a full row group (every one but a ragged last): no per-element selects - vector instructions are matrix time lost
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4);
+        if (!EXACT && q >= NQ) continue;
+        *reinterpret_cast<f32x4m*>(lds + row * SeqK<H>::LD + 4 * c4) = v[i];
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int q = threadIdx.x + NTH * i, row = q / (H / 4), c4 = q % (H / 4);

@@ -11,8 +11,8 @@ namespace kbj {
 constexpr float kLog2Pi = 1.8378770664093453f;
 
 // gate non-linearities on the hardware exp/rcp units (same definitions as kbj_lstm_seq.h so rollout and update agree)
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { float xc = fminf(fmaxf(x, -15.0f), 15.0f); return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * xc)); }
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }      // same forms as kbj_lstm_seq.h seq_sigmoid / seq_tanh
+__device__ __forceinline__ float tanhf_(float x) { float xc = fminf(fmaxf(x, -15.0f), 15.0f); return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * xc)); }
 __device__ __forceinline__ float softplusf_(float x) { return x > 20.0f ? x : log1pf(expf(x)); }
 
 // ---- LSTM cell, forward ----------------------------------------------------------------------------------------
