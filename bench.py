@@ -75,17 +75,25 @@ def cpu_baseline(repeats: int = 3):
         tr.train_iteration()
         return time.perf_counter() - t0
 
-    tr = make(256, 100)
+    # thread sweep on a quarter-size probe (128 envs x 50 steps), smallest first; it stops at the first setting that is clearly slower
+    # than the best so far (oversubscribed OpenMP / intra-op pools on these small matrices get slower, and an unbounded sweep could sit
+    # silent for minutes); every point is printed as it is measured
+    probe = make(128, 50)
     sweep = {}
     for n in (8, 16, 32, 64, 128, 256):
-        if n > usable and n != 8:
+        if n > usable and sweep:
             break
         set_threads(n)
         if not sweep:
-            tr.train_iteration()   # warm-up (allocator, thread pools)
-        sweep[n] = round(timed(tr), 3)
+            probe.train_iteration()   # warm-up (allocator, thread pools)
+        sweep[n] = round(timed(probe), 3)
+        print(f"bench.py: cpu_baseline thread sweep: {n} threads -> {sweep[n]:.3f} s per probe iteration", file=sys.stderr, flush=True)
+        if sweep[n] > 1.3 * min(sweep.values()):
+            break
     best = min(sweep, key=sweep.get)
     set_threads(best)
+    tr = make(256, 100)
+    tr.train_iteration()              # warm-up at the chosen setting
     ts1 = [timed(tr) for _ in range(repeats)]
     t1 = float(np.median(ts1))
     tr0 = make(4, 64)
@@ -95,6 +103,7 @@ def cpu_baseline(repeats: int = 3):
                 sample=f"oracle full iteration (rollout + GAE + 3 passes) on 256 envs x 100 steps, batch 256, hidden 256: median of {repeats} "
                        f"= {t1:.2f} s (runs {', '.join('%.2f' % t for t in ts1)}) at the best of the thread sweep ({best} threads; this process may use "
                        f"{usable} of the host's {os.cpu_count()} cores)",
+                thread_sweep_probe="128 envs x 50 steps, seconds per iteration by thread count (stops at the first setting > 1.3x the best)",
                 thread_sweep_seconds_per_iteration={str(k): v for k, v in sweep.items()},
                 config0=dict(value=4 * 64 / t0, unit="env-steps/s", sample=f"configs[0]: 4 envs x 64 steps, batch 4, 3 passes, hidden 256: median of 3 = {t0:.2f} s"))
 

@@ -162,6 +162,11 @@ typedef struct kbj_ppo_vars {
   float* action_mean_d;  /* [T][B][20] or NULL: the filtered mean (the distribution's mode, train.py:936-939) */
 } kbj_ppo_vars;
 int kbj_ppo_forward(kbj_ctx* ctx, const float* params_d, const kbj_traj* traj, const int32_t* env_idx_d, int B, kbj_ppo_vars* out);
+/* Data-parallel overlap (no reference counterpart: the reference has no collective call site). After kbj_ppo_grad, work enqueued on
+ * `hip_stream` behind this call starts once the ACTOR's slice of the gradient, grad_d[0, kbj_actor_param_count()), is final - about half
+ * a millisecond before the call's own stream sees the whole gradient - so a host may all-reduce that slice on a second stream under the
+ * critic's tail and the rest on the call's stream (host/task.py `overlap_allreduce`). */
+int kbj_stream_wait_actor_grad(kbj_ctx* ctx, void* hip_stream);
 /* replaces: optax.adamw + global-norm clip (train.py:1059-1077). step is 1-based. grad_scale multiplies the
  * gradient first (1/world_size after an all-reduce sum). */
 int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const float* grad_d, int64_t step, float grad_scale);

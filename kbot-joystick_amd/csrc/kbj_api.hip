@@ -112,6 +112,7 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   if (getenv("KBJ_DX_LANE") && atoi(getenv("KBJ_DX_LANE")) != 0)
     for (int n = 0; n < 2; ++n) KBJ_TRY(hipStreamCreateWithPriority(&ctx->dxs[n], hipStreamNonBlocking, n == 1 ? prio_greatest : 0));
   for (int k = 0; k < 32; ++k) KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_pool[k], hipEventDisableTiming));
+  KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_actor_grad, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
 #undef KBJ_TRY
@@ -133,6 +134,7 @@ int kbj_destroy(kbj_ctx* ctx) {
   if (ctx->ev0) hipEventDestroy(ctx->ev0);
   if (ctx->ev1) hipEventDestroy(ctx->ev1);
   for (int k = 0; k < 32; ++k) if (ctx->ev_pool[k]) hipEventDestroy(ctx->ev_pool[k]);
+  if (ctx->ev_actor_grad) hipEventDestroy(ctx->ev_actor_grad);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
   if (ctx->stream2) hipStreamDestroy(ctx->stream2);

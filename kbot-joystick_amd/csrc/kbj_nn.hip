@@ -1093,20 +1093,35 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     }
     if (!one_stream) { hipEventRecord(ctx->ev_side[n & 1], ctx->side[n & 1]); hipStreamWaitEvent(s, ctx->ev_side[n & 1], 0); }
   }
+  // the bias terms of layer 0 (db_0 is complete once the net's side lane has joined): db_in = W_ih0^T db_0, dW_ih0 += db_0 b_in^T
+  // (X0 = obs W_in^T + b_in)
+  auto fold_bias_terms = [&](int k, hipStream_t st) {
+    const NetOff& oa = w.net[k];
+    float* part = det_partials(ctx, st);
+    hipLaunchKernelGGL(matvec_t_acc_kernel, dim3((H + 63) / 64, 16), dim3(256), 0, st, params_d + oa.w_ih[0], grad_d + oa.b[0], 4 * H, H, grad_d + oa.b_in, part);
+    if (part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((H + 255) / 256), dim3(256), 0, st, part, 16, H, grad_d + oa.b_in);
+    hipLaunchKernelGGL(outer_acc_kernel, g1((size_t)4 * H * H), dim3(256), 0, st, grad_d + oa.w_ih[0], grad_d + oa.b[0], params_d + oa.b_in, 4 * H, H);
+  };
+  // The actor's slice grad[0, nactor) is final here, ~0.5 ms before the critic's (shorter chain: folded layer 0, no 475-wide projection).
+  // A data-parallel host may start its all-reduce now, under the critic's tail (kbj_stream_wait_actor_grad). A hand-off timeout seen so far
+  // poisons the actor slice; the check behind the join below covers everything later through the critic's slice.
+  if (fold_actor) fold_bias_terms(0, ctx->stream);
+  hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d);
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_actor_grad, ctx->stream));
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-  if (fold_actor)   // the bias terms of layer 0 (db_0 is complete now): db_in = W_ih0^T db_0, dW_ih0 += db_0 b_in^T (X0 = obs W_in^T + b_in)
-    for (int k = 0; k < (fold_critic ? 2 : 1); ++k) {
-      const NetOff& oa = w.net[k];
-      float* part = det_partials(ctx, ctx->stream);
-      hipLaunchKernelGGL(matvec_t_acc_kernel, dim3((H + 63) / 64, 16), dim3(256), 0, ctx->stream, params_d + oa.w_ih[0], grad_d + oa.b[0], 4 * H, H, grad_d + oa.b_in, part);
-      if (part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((H + 255) / 256), dim3(256), 0, ctx->stream, part, 16, H, grad_d + oa.b_in);
-      hipLaunchKernelGGL(outer_acc_kernel, g1((size_t)4 * H * H), dim3(256), 0, ctx->stream, grad_d + oa.w_ih[0], grad_d + oa.b[0], params_d + oa.b_in, 4 * H, H);
-    }
+  if (fold_actor && fold_critic) fold_bias_terms(1, ctx->stream);
   // a recurrence that timed out left a truncated gradient: poison it so that every data-parallel rank skips the optimizer step
-  hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d);
+  hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d + w.nactor);
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_grad");
   if (sc.debug_sync) return kbj_synchronize(ctx);   // KBJ_DEBUG=1: surface a hand-off timeout at the call that caused it
+  return 0;
+}
+
+int kbj_stream_wait_actor_grad(kbj_ctx* ctx, void* hip_stream) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_stream_wait_actor_grad: null ctx");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  KBJ_HIP(ctx, hipStreamWaitEvent((hipStream_t)hip_stream, ctx->ev_actor_grad, 0));
   return 0;
 }
 

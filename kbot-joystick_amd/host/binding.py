@@ -73,6 +73,7 @@ SIGNATURES = {
     "kbj_gae": (_i, [_vp, C.POINTER(Traj), _vp, _vp]),
     "kbj_ppo_grad": (_i, [_vp, _vp, C.POINTER(Traj), _vp, _i, _vp, _vp, _vp, _vp]),
     "kbj_ppo_forward": (_i, [_vp, _vp, C.POINTER(Traj), _vp, _i, C.POINTER(PpoVars)]),
+    "kbj_stream_wait_actor_grad": (_i, [_vp, _vp]),
     "kbj_adamw_step": (_i, [_vp, _vp, _vp, _vp, _vp, C.c_int64, _f]),
     "kbj_set_learning_rate": (_i, [_vp, _f]),
     "kbj_profile_begin": (_i, [_vp]),
@@ -236,6 +237,9 @@ class Context:
         """kbj_ppo_forward: the on-policy pass (no gradients) for the B envs `env_idx` names; outputs are [T][B](x20) in env_idx order."""
         out = PpoVars(_ptr(logp), _ptr(value), _ptr(entropy), _ptr(action_std), _ptr(action_mean))
         self.call("kbj_ppo_forward", _ptr(params), C.byref(traj), _ptr(env_idx), B, C.byref(out))
+
+    def stream_wait_actor_grad(self, hip_stream: int):
+        self.call("kbj_stream_wait_actor_grad", hip_stream)
 
     def adamw_step(self, params, m, v, grad, step, grad_scale=1.0):
         self.call("kbj_adamw_step", _ptr(params), _ptr(m), _ptr(v), _ptr(grad), step, grad_scale)

@@ -18,6 +18,20 @@ FORCE_COLLECTIVE = False      # run the collective even at world_size 1 (tests: 
 TIMING = None                 # set to a list to collect (start, end) CUDA event pairs around every gradient all-reduce (bench.py)
 
 
+def allreduce_grad_overlapped_(ctx, grad: torch.Tensor, n_actor: int, world_size: int, comm_stream) -> float:
+    """The same exchange in two pieces: the actor's slice grad[:n_actor] on `comm_stream` as soon as kbj_ppo_grad has finished it
+    (kbj_stream_wait_actor_grad: ~0.5 ms before the critic's), the critic's slice on the current stream behind the whole call; the
+    current stream then waits for `comm_stream`. Same sums, same result as allreduce_grad_."""
+    if world_size > 1 or FORCE_COLLECTIVE:
+        import torch.distributed as dist
+        ctx.stream_wait_actor_grad(comm_stream.cuda_stream)
+        with torch.cuda.stream(comm_stream):
+            dist.all_reduce(grad[:n_actor], op=dist.ReduceOp.SUM)
+        dist.all_reduce(grad[n_actor:], op=dist.ReduceOp.SUM)
+        torch.cuda.current_stream().wait_stream(comm_stream)
+    return 1.0 / world_size
+
+
 def allreduce_grad_(grad: torch.Tensor, world_size: int) -> float:
     """In-place SUM all-reduce on the current stream; returns the scale (1/world) the optimizer step must apply."""
     if world_size > 1 or FORCE_COLLECTIVE:

@@ -83,6 +83,9 @@ class HumanoidWalkingTaskConfig:
     # a pass locally, ONE all-reduce and ONE optimizer step per pass (fewer, larger steps - a different algorithm). KBJ_ALLREDUCE
     # in the environment overrides the default.
     allreduce: str = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_ALLREDUCE", "per_step"))
+    # per_step exchange only: all-reduce the actor's gradient slice on a second stream under the critic's tail of kbj_ppo_grad
+    # (kbj_stream_wait_actor_grad), the critic's slice behind the call. Same result; pays only where the exchange is visible (N > 1)
+    overlap_allreduce: bool = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_OVERLAP_ALLREDUCE", "0") not in ("0", ""))
     # bit-reproducible update: fixed-order reductions instead of fp32 / fp64 atomics in the gradient (kbj_config.deterministic); the
     # reference's XLA program is deterministic by default, here it costs a few percent and is off unless asked for
     deterministic: bool = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_DETERMINISTIC", "0") not in ("0", ""))
@@ -290,7 +293,12 @@ class HumanoidWalkingTask:
                     if mb + 1 < nmb:
                         continue
                 g = self.grad_acc if per_pass else self.grad
-                scale = dist_util.allreduce_grad_(g, self.world_size)   # RCCL over xGMI: the one exchange step
+                if self.config.overlap_allreduce and not per_pass:
+                    if getattr(self, "_comm_stream", None) is None:
+                        self._comm_stream = torch.cuda.Stream(device=self.device)
+                    scale = dist_util.allreduce_grad_overlapped_(self.ctx, g, self.ctx.actor_param_count(), self.world_size, self._comm_stream)
+                else:
+                    scale = dist_util.allreduce_grad_(g, self.world_size)   # RCCL over xGMI: the one exchange step
                 if per_pass:
                     scale /= nmb                                     # mean over the pass's minibatches (and ranks)
                 if self.config.use_lr_decay:

@@ -11,13 +11,14 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, overlap=False):
     import torch.distributed as dist
     from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    cfg = launch_config(num_envs=128, batch_size=32, hidden_size=64, rollout_length_seconds=0.2, robot="kbot-headless", seed=6, num_passes=1)
+    cfg = launch_config(num_envs=128, batch_size=32, hidden_size=64, rollout_length_seconds=0.2, robot="kbot-headless", seed=6, num_passes=1,
+                        overlap_allreduce=overlap, deterministic=True)
     task = HumanoidWalkingTask(cfg, device=torch.device("cuda", 0), rank=rank, world_size=world)
     assert task.N == 64 and task.kcfg.env_id_offset == 64 * rank
     task.train_iteration()
@@ -45,3 +46,15 @@ def test_two_ranks_share_one_gpu():
     both = np.concatenate([r0["reward"], r1["reward"]], axis=1)
     assert np.allclose(single.traj.reward.cpu().numpy(), both, atol=1e-5)
     single.ctx.close()
+
+
+def test_overlapped_actor_slice_exchange_gives_identical_parameters():
+    """overlap_allreduce: the actor's gradient slice is all-reduced on a second stream as soon as kbj_ppo_grad has finished it
+    (kbj_stream_wait_actor_grad), the critic's slice behind the call. Two ranks on one GPU, deterministic reductions: the parameters
+    equal those of the plain exchange bit for bit."""
+    mgr = mp.Manager()
+    plain, over = mgr.dict(), mgr.dict()
+    mp.spawn(_worker, args=(2, 29537, plain, False), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, 29539, over, True), nprocs=2, join=True)
+    assert np.array_equal(over[0]["params"], over[1]["params"])
+    assert np.array_equal(plain[0]["params"], over[0]["params"]) and plain[0]["steps"] == over[0]["steps"] == 2

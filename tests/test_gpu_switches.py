@@ -289,6 +289,6 @@ t = torch.ones(4, device="cuda"); orig(t); assert float(t.sum()) == 4.0
 dist.barrier(); dist.destroy_process_group()
 print("RCCL_OK", len(calls))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
