@@ -18,6 +18,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <type_traits>
 #include "kbj_ctx.h"
 
 namespace kbj {
@@ -140,7 +141,11 @@ __device__ __forceinline__ GemmItem gemm_item(const GemmArgs& g, int item, int t
   return it;
 }
 
-// WM x WN wavefronts per workgroup, each owning MT x NT 32x32 accumulator tiles
+// WM x WN wavefronts per workgroup, each owning MT x NT 32x32 accumulator tiles. One work item (output tile x k slice) per workgroup.
+// On this chip fp32 MFMA and vector instructions share a SIMD's issue, so the k loop is written to need almost no
+// vector instructions besides the MFMAs: interior tiles are fetched with buffer loads whose per-thread byte offsets are computed once
+// and whose k advance is a scalar offset; the loop is unrolled over the two LDS stages so that every LDS address is a per-thread base
+// plus an immediate.
 template <int MT, int NT, bool A_KC, bool B_KC, int WM = 2, int WN = 2>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
   constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NTH = 64 * WM * WN;
@@ -156,128 +161,137 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
   const int per = sk > 1 ? ((g.K + sk - 1) / sk + GEMM_BK - 1) / GEMM_BK * GEMM_BK : g.K;
   const int items = tiles_n * tiles_m * sk;
   // XCD-contiguous hand-out: workgroup b runs on XCD b % 8 and takes logical slot (b % 8) * (G / 8) + b / 8
-  const int logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-  int item = logical * g.ipw;
-  const int item_end = min(items, item + g.ipw);
-  if (item >= item_end) return;
+  const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (item >= items) return;
+  const GemmItem cur = gemm_item<BM, BN>(g, item, tiles_n, tiles_m, per);
+  if (cur.kbeg >= cur.kend) return;   // empty k slice (K not a multiple of the slice length): nothing to add
 
   const bool a_vec = (g.lda & 3) == 0 && (((size_t)g.A & 15) == 0) && (((size_t)g.A2 & 15) == 0);
   const bool b_vec = (g.ldb & 3) == 0 && (g.ldb2 & 3) == 0 && (((size_t)g.B & 15) == 0) && (((size_t)g.B2 & 15) == 0);   // B2 null or aligned
+  // interior tiles (all rows in range, vector-aligned) take the buffer-load path, decided per operand
+  const bool rows_a = a_vec && cur.m0 + BM <= g.M, rows_b = b_vec && cur.n0 + BN <= cur.ncols;
   GemmStage<BM, A_KC, NTH> sa;
   GemmStage<BN, B_KC, NTH> sb;
-  GemmItem cur = gemm_item<BM, BN>(g, item, tiles_n, tiles_m, per);
-  while (cur.kbeg >= cur.kend) {   // empty k slice (K not a multiple of the slice length): nothing to add
-    if (++item >= item_end) return;
-    cur = gemm_item<BM, BN>(g, item, tiles_n, tiles_m, per);
+  // per-thread byte offsets of the staged pieces at k = 0 (buffer-load path): k-contiguous operand: (row * ld + 4 kq) * 4, k advances by
+  // 4 bytes per k; row-contiguous operand: (k row * ld + r0 + 4 rq) * 4, k advances by ld * 4 bytes per k
+  unsigned voa[GemmStage<BM, A_KC, NTH>::NV], vob[GemmStage<BN, B_KC, NTH>::NV];
+  {
+    if (A_KC) { const int kq = tid & 7, rr = tid >> 3;
+#pragma unroll
+      for (int i = 0; i < sa.NV; ++i) voa[i] = (unsigned)(((size_t)(cur.m0 + rr + sa.RPP * i) * g.lda + 4 * kq) * 4); }
+    else { constexpr int QPR = BM / 4, KROWS = NTH / QPR; const int rq = tid % QPR, kr0 = tid / QPR;
+#pragma unroll
+      for (int i = 0; i < sa.NV; ++i) voa[i] = (unsigned)(((size_t)(kr0 + KROWS * i) * g.lda + cur.m0 + 4 * rq) * 4); }
+    if (B_KC) { const int kq = tid & 7, rr = tid >> 3;
+#pragma unroll
+      for (int i = 0; i < sb.NV; ++i) vob[i] = (unsigned)(((size_t)(cur.n0 + rr + sb.RPP * i) * cur.ldb + 4 * kq) * 4); }
+    else { constexpr int QPR = BN / 4, KROWS = NTH / QPR; const int rq = tid % QPR, kr0 = tid / QPR;
+#pragma unroll
+      for (int i = 0; i < sb.NV; ++i) vob[i] = (unsigned)(((size_t)(kr0 + KROWS * i) * cur.ldb + cur.n0 + 4 * rq) * 4); }
   }
-  int stage = 0;
-  // one k tile of both operands into the staging registers; rows_a / rows_b: all tile rows in range and vector-aligned
-  auto load_tile = [&](const GemmItem& it, int k, bool rows_a, bool rows_b) {
-    const float *pa = g.A, *pb = it.B;
-    int kk = k, ke = it.kend;
+  typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
+  // one k tile of both operands into the staging registers
+  auto load_tile = [&](int k) {
+    const float *pa = g.A, *pb = cur.B;
+    int kk = k, ke = cur.kend;
     if (g.k1 > 0) {
       if (k >= g.k1) { pa = g.A2; pb = g.B2; kk = k - g.k1; ke = g.K - g.k1; }
       else ke = g.k1;
     }
     const bool kfull = kk + GEMM_BK <= ke;
-    if (rows_a && kfull) sa.load_fast(pa, g.lda, it.m0, kk);
-    else sa.load(pa, g.lda, g.M, it.m0, kk, ke, a_vec);
-    if (rows_b && kfull) sb.load_fast(pb, it.ldb, it.n0, kk);
-    else sb.load(pb, it.ldb, it.ncols, it.n0, kk, ke, b_vec);
+    if (rows_a && kfull) {
+      __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa), 0, 0x7FFFFFFF, 0x00020000);
+      const unsigned so = (unsigned)(A_KC ? (size_t)kk * 4 : (size_t)kk * g.lda * 4);      // scalar: the k advance costs no vector instruction
+#pragma unroll
+      for (int i = 0; i < sa.NV; ++i) sa.v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa[i], so, 0));
+    } else sa.load(pa, g.lda, g.M, cur.m0, kk, ke, a_vec);
+    if (rows_b && kfull) {
+      __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pb), 0, 0x7FFFFFFF, 0x00020000);
+      const unsigned so = (unsigned)(B_KC ? (size_t)kk * 4 : (size_t)kk * cur.ldb * 4);
+#pragma unroll
+      for (int i = 0; i < sb.NV; ++i) sb.v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, vob[i], so, 0));
+    } else sb.load(pb, cur.ldb, cur.ncols, cur.n0, kk, ke, b_vec);
   };
-  load_tile(cur, cur.kbeg, false, false);
+  load_tile(cur.kbeg);
   sa.store(lds); sb.store(lds + A_ELEMS);
   __syncthreads();
 
-  while (true) {
-    // the item after this one (skipping empty k slices)
-    GemmItem nxt = cur;
-    bool have_next = false;
-    for (int j = item + 1; j < item_end; ++j) {
-      nxt = gemm_item<BM, BN>(g, j, tiles_n, tiles_m, per);
-      if (nxt.kbeg < nxt.kend) { have_next = true; item = j; break; }
-    }
-    f32x16 acc[MT][NT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
+    for (int j = 0; j < NT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // interior tiles take straight-line vector loads, decided per operand and per k tile (a ragged last k tile or an
-    // unaligned operand, e.g. the 475-wide critic input projection, only slows the loads it touches)
-    const bool rows_a_cur = a_vec && cur.m0 + BM <= g.M, rows_b_cur = b_vec && cur.n0 + BN <= cur.ncols;
-    const bool rows_a_nxt = have_next && a_vec && nxt.m0 + BM <= g.M, rows_b_nxt = have_next && b_vec && nxt.n0 + BN <= nxt.ncols;
-    for (int k0 = cur.kbeg; k0 < cur.kend; k0 += GEMM_BK) {
-      const bool more = k0 + GEMM_BK < cur.kend;
-      const bool pre = more || have_next;
-      if (more) load_tile(cur, k0 + GEMM_BK, rows_a_cur, rows_b_cur);        // next k tile of this item in flight during this tile's MFMAs
-      else if (have_next) load_tile(nxt, nxt.kbeg, rows_a_nxt, rows_b_nxt);  // first k tile of the next item
-      const float* As = lds + stage * STAGE;
-      const float* Bs = As + A_ELEMS;
-      // MFMA over the 32-wide k tile: 4 groups of 8 k; lane half lh owns k = 8 kk + 4 lh + e. The prefetched tile goes to the
-      // other LDS stage half way through (its loads have landed behind the first 32 MFMAs; that stage was last read one k tile
-      // ago, before the barrier every wavefront has passed since).
+  // one k tile out of LDS stage S (a compile-time constant: every LDS address below is a per-thread base plus an immediate). The next
+  // tile's global loads are issued first and written to the other stage half way through the MFMAs (they have landed behind the first
+  // 16 x MT x NT of them; that stage was last read one k tile ago, before the barrier every wavefront has passed since).
+  auto k_tile = [&](auto stage_tag, int k0) {
+    constexpr int S = decltype(stage_tag)::value;
+    const bool more = k0 + GEMM_BK < cur.kend;
+    if (more) load_tile(k0 + GEMM_BK);
+    const float* As = lds + S * STAGE;
+    const float* Bs = As + A_ELEMS;
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
+    for (int half = 0; half < 2; ++half) {
 #pragma unroll
-        for (int kk = 2 * half; kk < 2 * half + 2; ++kk) {
-          f32x4 a[MT], b[NT];
+      for (int kk = 2 * half; kk < 2 * half + 2; ++kk) {
+        f32x4 a[MT], b[NT];
 #pragma unroll
-          for (int i = 0; i < MT; ++i) {
-            int row = wr * 32 * MT + 32 * i + lr;
-            if (A_KC) a[i] = *reinterpret_cast<const f32x4*>(As + row * GEMM_LDK + 8 * kk + 4 * lh);
-            else { for (int e = 0; e < 4; ++e) a[i][e] = As[(8 * kk + 4 * lh + e) * (BM + 4) + row]; }
-          }
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            int row = wc * 32 * NT + 32 * j + lr;
-            if (B_KC) b[j] = *reinterpret_cast<const f32x4*>(Bs + row * GEMM_LDK + 8 * kk + 4 * lh);
-            else { for (int e = 0; e < 4; ++e) b[j][e] = Bs[(8 * kk + 4 * lh + e) * (BN + 4) + row]; }
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-              for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < MT; ++i) {
+          int row = wr * 32 * MT + 32 * i + lr;
+          if (A_KC) a[i] = *reinterpret_cast<const f32x4*>(As + row * GEMM_LDK + 8 * kk + 4 * lh);
+          else { for (int e = 0; e < 4; ++e) a[i][e] = As[(8 * kk + 4 * lh + e) * (BM + 4) + row]; }
         }
-        if (half == 0 && pre) {
-          float* dst = lds + (stage ^ 1) * STAGE;
-          sa.store(dst); sb.store(dst + A_ELEMS);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          int row = wc * 32 * NT + 32 * j + lr;
+          if (B_KC) b[j] = *reinterpret_cast<const f32x4*>(Bs + row * GEMM_LDK + 8 * kk + 4 * lh);
+          else { for (int e = 0; e < 4; ++e) b[j][e] = Bs[(8 * kk + 4 * lh + e) * (BN + 4) + row]; }
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][e], b[j][e], acc[i][j], 0, 0, 0);
       }
-      __syncthreads();
-      stage ^= 1;
+      if (half == 0 && more) {
+        float* dst = lds + (S ^ 1) * STAGE;
+        sa.store(dst); sb.store(dst + A_ELEMS);
+      }
     }
-    // ---- epilogue: accumulator (col = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)) -> C ----
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        int n = cur.n0 + wc * 32 * NT + 32 * j + lr;
-        if (n >= cur.ncols) continue;
-        float bv = (g.bias && cur.ks == 0) ? g.bias[n] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          int m = cur.m0 + wr * 32 * MT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (m >= g.M) continue;
-          float* c = cur.C + (size_t)m * cur.ldc + n;
-          float v = acc[i][j][r] + bv;
-#ifdef KBJ_GEMM_NOSTORE   // timing experiment only (tools/gemm_bench): keep the MFMAs live, drop the write-back
-          if (v == 1.2345e-30f) *c = v;
-#else
-          if (sk > 1) {
-            if (g.skws) g.skws[((size_t)cur.ks * g.M + m) * g.N + cur.ncol0 + n] = v;
-            else atomicAdd(c, v);
-          } else *c = g.beta ? *c + v : v;
-#endif
-        }
-      }
-    if (!have_next) break;
-    cur = nxt;
+    __syncthreads();
+  };
+  for (int k0 = cur.kbeg; k0 < cur.kend; k0 += 2 * GEMM_BK) {
+    k_tile(std::integral_constant<int, 0>{}, k0);
+    if (k0 + GEMM_BK < cur.kend) k_tile(std::integral_constant<int, 1>{}, k0 + GEMM_BK);
   }
+  // ---- epilogue: accumulator (col = lane&31, row = (r&3) + 8 (r>>2) + 4 (lane>>5)) -> C ----
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      int n = cur.n0 + wc * 32 * NT + 32 * j + lr;
+      if (n >= cur.ncols) continue;
+      float bv = (g.bias && cur.ks == 0) ? g.bias[n] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = cur.m0 + wr * 32 * MT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.M) continue;
+        float* c = cur.C + (size_t)m * cur.ldc + n;
+        float v = acc[i][j][r] + bv;
+#ifdef KBJ_GEMM_NOSTORE   // timing experiment only (tools/gemm_bench): keep the MFMAs live, drop the write-back
+        if (v == 1.2345e-30f) *c = v;
+#else
+        if (sk > 1) {
+          if (g.skws) g.skws[((size_t)cur.ks * g.M + m) * g.N + cur.ncol0 + n] = v;
+          else atomicAdd(c, v);
+        } else *c = g.beta ? *c + v : v;
+#endif
+      }
+    }
 }
 
 // second stage of the deterministic split-K: C (+)= sum over the k slices, in slice order, of the partial tiles (one thread per output
@@ -312,9 +326,7 @@ inline void gemm_launch(hipStream_t s, const GemmArgs& g_in, int force_big = -1)
   bool big = force_big >= 0 ? force_big != 0 : big_items >= 192;
   long items = big ? big_items : (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * sk;
   // one work item per workgroup (walking several items per workgroup was slower at every setting for this path's shapes)
-  const int ipw = 1;
-  g.ipw = ipw;
-  int wgs = (int)((items + ipw - 1) / ipw);
+  int wgs = (int)items;
   wgs = (wgs + 7) / 8 * 8;
   KbjKernelTimer timer(s, KBJ_KIND_GEMM + (big ? 0 : 4) + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);
 #ifdef KBJ_GEMM_W4   // 128x128 tile on 4 wavefronts (2 x 2, each 64x64, 207 registers): 2-4 % faster only at K >= 4096
