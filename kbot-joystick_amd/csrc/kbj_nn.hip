@@ -72,6 +72,7 @@ struct NnWs {
   // actor layer 0 with the input projection folded in (the projection has no activation and 65 < H inputs):
   // W_eff = W_ih0 W_in [4H][68 (65 used)], b_eff = W_ih0 b_in + b_0; Zeff[n] = dG0^T obs of actor-type net n (n = 0, 2)
   float *Weff = nullptr, *beff = nullptr, *Zeff[4] = {nullptr, nullptr, nullptr, nullptr};
+  float* WinP[2] = {nullptr, nullptr};   // input-projection weights re-pitched to the observation rows' 16-byte aligned stride (per call: the parameters change)
   double* stats = nullptr;  // [0..1] adv stats, [2..9] metric accumulators, [10] grad sumsq
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
@@ -422,6 +423,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->stats, 16)) return -1;
   if (dalloc(ctx, *w, &w->Weff, 4 * H * KBJ_LD_ACTOR) || dalloc(ctx, *w, &w->beff, 4 * H)) return -1;
   for (int n = 0; n < w->nnets; ++n) if (dalloc(ctx, *w, &w->Zeff[n], 4 * H * w->net[n & 1].ld_obs)) return -1;
+  for (int k = 0; k < 2; ++k) if (dalloc(ctx, *w, &w->WinP[k], H * w->net[k].ld_obs)) return -1;
   if (hipMemset(w->Weff, 0, 4 * H * KBJ_LD_ACTOR * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset Weff");
   if (dalloc(ctx, *w, &w->seq_counters, 2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS)) return -1;
   w->bwd_progress = w->seq_counters + 2 * MAXD * 4 * SEQ_COUNTER_WORDS;   // same allocation: one clear covers both   // [phase: forward layer l = l, backward layer l = D + l][net][row group x unit group]
@@ -852,8 +854,13 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
   // Launch order is layer-major over the nets (nets 2, 3 = mirror branches, same weights, queued behind nets 0, 1 on the same two streams).
   for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
-    if (!(sc.fold_actor && (n & 1) == 0))   // actor-type nets: layer-0 gates come straight from the observations
-      linear_fwd(ns[n & 1], w.tb[n].obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, w.tb[n].X0, H, R, H, o.nin, 0);
+    if (sc.fold_actor && (n & 1) == 0) continue;   // actor-type nets: layer-0 gates come straight from the observations
+    // X0 = obs W_in^T + b_in. The stored rows of W_in are nin (65 / 475) floats long - no 16-byte alignment, which would put the GEMM on
+    // its element-wise load path for this operand (55 instead of ~90 TF for the critic's 12 GFLOP, at the head of the longer chain): a
+    // re-pitched copy with the observation rows' stride (zeros behind column nin, as in the observation rows) is made first; the
+    // contraction then runs over the padded width
+    if (n < 2) hipLaunchKernelGGL(repitch_rows_kernel, g1((size_t)H * o.ld_obs), dim3(256), 0, ns[n & 1], params_d + o.w_in, H, o.nin, o.ld_obs, w.WinP[n & 1]);
+    linear_fwd(ns[n & 1], w.tb[n].obs, o.ld_obs, w.WinP[n & 1], o.ld_obs, params_d + o.b_in, w.tb[n].X0, H, R, H, o.ld_obs, 0);
   }
   if (!sc.one_stream) KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));   // keep / carries gathered on the caller's stream
   for (int l = 0; l < D; ++l) {

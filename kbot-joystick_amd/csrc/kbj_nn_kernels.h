@@ -441,6 +441,15 @@ __global__ void matvec_t_acc_kernel(const float* __restrict__ W, const float* __
   }
 }
 
+// dst[r][0:ld_dst] = src[r][0:cols] followed by zeros: a weight matrix whose row length is not a multiple of 4 (the critic's 475-wide
+// input projection) re-pitched to 16-byte aligned rows, so that the GEMM takes its vector-free buffer-load path for it
+__global__ void repitch_rows_kernel(const float* __restrict__ src, int rows, int cols, int ld_dst, float* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * ld_dst) return;
+  const int r = i / ld_dst, c = i - r * ld_dst;
+  dst[i] = c < cols ? src[(size_t)r * cols + c] : 0.0f;
+}
+
 // C[m][n] += u[m] v[n]   (rank-1 update, C [M][N] row-major)
 __global__ void outer_acc_kernel(float* __restrict__ C, const float* __restrict__ u, const float* __restrict__ v, int M, int N) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
