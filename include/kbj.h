@@ -34,7 +34,9 @@ typedef struct kbj_ctx kbj_ctx;
 /* ---- lifetime ---------------------------------------------------------------------------- */
 /* replaces: HumanoidWalkingTask.launch(config) set-up — get_mujoco_model / metadata / mjx.put_model
  * (train.py:1079-1089, 1760-1792). model_blob is a kbj_model produced by the spec compiler.
- * Model fields served (train.py:78-85): cfg->hidden_size in {64, 128, 192, 256}, cfg->depth in 1..KBJ_MAX_DEPTH; anything else fails here. */
+ * Model fields served (train.py:78-85): cfg->hidden_size in 1..256 (multiples of 64 run natively; any other size runs zero padded to the
+ * next one INSIDE the library - parameters, gradients, carries and trajectory start carries keep the caller's hidden_size layout and are
+ * converted at every entry point, exact for this network), cfg->depth in 1..KBJ_MAX_DEPTH; anything else fails here. */
 int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const kbj_config* cfg, int device, void* hip_stream);
 int kbj_destroy(kbj_ctx* ctx);
 const char* kbj_last_error(const kbj_ctx* ctx); /* ctx may be NULL: error of a failed kbj_create */
@@ -60,6 +62,12 @@ int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* act
  * are rewritten; the others are untouched. The caller then writes the term's value into the step's KBJ_AUX_DONE column before
  * kbj_carry_reset / kbj_rewards / kbj_gae read it. */
 int kbj_env_reset_where(kbj_ctx* ctx, const float* mask_d, float* actor_next_d, float* critic_next_d, float* aux_next_d);
+/* replaces: the command update of a user-written Command term in the reference's protocol (`Command.initial_command(physics_data,
+ * curriculum_level, rng)` / `Command.__call__(prev_command, physics_data, curriculum_level, rng)`, train.py:724, 768) evaluated by the host
+ * between two control steps. cmd_d [N][16]; mask_d [N] float or NULL (= every env): the envs with a non-zero entry get cmd_d's row as
+ * their joystick command - in the env state (the next kbj_env_step starts from it; run with command_mode = 1 so the kernel's own
+ * switch draw does not replace it) and in the command columns + zero-command flag of the NEXT observation rows and aux record. */
+int kbj_env_set_command(kbj_ctx* ctx, const float* mask_d, const float* cmd_d, float* actor_next_d, float* critic_next_d, float* aux_next_d);
 /* state save/restore (checkpointing, tests): ep [N][KBJ_EP_SIZE], es [N][KBJ_ES_SIZE]; synchronous */
 int kbj_env_get_state(kbj_ctx* ctx, float* ep_h, float* es_h);
 int kbj_env_set_state(kbj_ctx* ctx, const float* ep_h, const float* es_h);

@@ -56,9 +56,9 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   if (!topology_ok(ctx->model_h, why)) { delete ctx; return kbj_fail(nullptr, "kbj_create: " + why); }
   if (cfg->num_envs <= 0 || cfg->substeps <= 0 || cfg->rollout_len <= 0) { delete ctx; return kbj_fail(nullptr, "kbj_create: bad config sizes"); }
   if (cfg->solver_newton != 1) { delete ctx; return kbj_fail(nullptr, "kbj_create: only the Newton solver is implemented on the GPU (solver_newton = 1)"); }
-  if ((cfg->hidden_size != 64 && cfg->hidden_size != 128 && cfg->hidden_size != 192 && cfg->hidden_size != 256) || cfg->depth < 1 || cfg->depth > KBJ_MAX_DEPTH) {
+  if (cfg->hidden_size < 1 || cfg->hidden_size > 256 || cfg->depth < 1 || cfg->depth > KBJ_MAX_DEPTH) {
     delete ctx;
-    return kbj_fail(nullptr, "kbj_create: the kernels are built for hidden_size 64, 128, 192 or 256 and depth 1..4 (train.py:78-85 defaults 128 / 2, launch 256 / 2)");
+    return kbj_fail(nullptr, "kbj_create: hidden_size must be in 1..256 (multiples of 64 run unpadded) and depth in 1..4 (train.py:78-85 defaults 128 / 2, launch 256 / 2)");
   }
   ctx->device = device;
   ctx->stream = (hipStream_t)hip_stream;
@@ -175,12 +175,13 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
   for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
     kbj_kernel_stat& st = ctx->kstats[k];
     const int uw = 2;   // wavefront pairs per recurrence workgroup (kbj_nn.hip SEQ_UW), as rocprofv3 prints the template argument
-    if (k == KBJ_KIND_SEQ_BWD) snprintf(st.name, sizeof(st.name), "%s<%d, %d>", names[k], ctx->cfg_h.hidden_size, uw);
+    const int hk = (ctx->cfg_h.hidden_size + 63) / 64 * 64;   // the kernels' hidden size (kbj_nn.hip NnWs::H)
+    if (k == KBJ_KIND_SEQ_BWD) snprintf(st.name, sizeof(st.name), "%s<%d, %d>", names[k], hk, uw);
     else if (k == KBJ_KIND_SEQ_FWD || k == KBJ_KIND_SEQ_FWD_FUSED || k == KBJ_KIND_SEQ_FWD_OBS)   // as rocprofv3 prints the template arguments
-      snprintf(st.name, sizeof(st.name), "%s<%d, %d, %s, %d>", names[k], ctx->cfg_h.hidden_size, uw, k == KBJ_KIND_SEQ_FWD ? "false" : "true",
-               k == KBJ_KIND_SEQ_FWD_OBS ? KBJ_LD_ACTOR : ctx->cfg_h.hidden_size);
+      snprintf(st.name, sizeof(st.name), "%s<%d, %d, %s, %d>", names[k], hk, uw, k == KBJ_KIND_SEQ_FWD ? "false" : "true",
+               k == KBJ_KIND_SEQ_FWD_OBS ? KBJ_LD_ACTOR : hk);
     else if (k == KBJ_KIND_LSTM_STEP || k == KBJ_KIND_LSTM_STEP_OBS)
-      snprintf(st.name, sizeof(st.name), "%s<%d, 2, %d>", names[k], ctx->cfg_h.hidden_size, k == KBJ_KIND_LSTM_STEP_OBS ? KBJ_LD_ACTOR : ctx->cfg_h.hidden_size);
+      snprintf(st.name, sizeof(st.name), "%s<%d, 2, %d>", names[k], hk, k == KBJ_KIND_LSTM_STEP_OBS ? KBJ_LD_ACTOR : hk);
     else snprintf(st.name, sizeof(st.name), "%s", names[k]);
     st.launches = 0; st.total_ms = 0; st.flops = 0;
   }

@@ -48,6 +48,26 @@ __global__ __launch_bounds__(64) void env_reset_where_kernel(const kbj_model* __
   PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
 }
 
+// overwrite the joystick command of the envs whose mask entry is non-zero (mask == nullptr: all envs): the env's state row (the next step's
+// rewards and its command-switch draw start from it) and the command columns of the NEXT observation rows + aux record, zero-command flag
+// included — what task_write_obs wrote there from the kernel's own command. One thread per (env, command slot).
+__global__ __launch_bounds__(256) void env_set_command_kernel(int N, float* __restrict__ es, const float* __restrict__ mask, const float* __restrict__ cmd, float* actor_next,
+                                                              float* critic_next, float* aux_next) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, env = i / KBJ_NCMD, k = i % KBJ_NCMD;
+  if (env >= N || (mask && mask[env] == 0.0f)) return;
+  const float* c = cmd + (size_t)env * KBJ_NCMD;
+  const float v = c[k];
+  es[(size_t)env * KBJ_ES_SIZE + KBJ_ES_CMD + k] = v;
+  actor_next[(size_t)env * KBJ_LD_ACTOR + KBJ_OBS_CMD + k] = v;
+  critic_next[(size_t)env * KBJ_LD_CRITIC + KBJ_OBS_CMD + k] = v;
+  aux_next[(size_t)env * KBJ_AUX_SIZE + KBJ_AUX_CMD + k] = v;
+  if (k == 0) {
+    const float zc = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) < 1e-3f ? 1.0f : 0.0f;
+    actor_next[(size_t)env * KBJ_LD_ACTOR + KBJ_OBS_ZEROCMD] = zc;
+    critic_next[(size_t)env * KBJ_LD_CRITIC + KBJ_OBS_ZEROCMD] = zc;
+  }
+}
+
 // register budget of the step kernel: 13.4 KB of LDS lets 12 single-wavefront workgroups share a CU (3 waves/SIMD), which
 // needs <= 168 VGPRs. `amdgpu_num_vgpr(N)` makes hipcc allocate 2 N registers for this wave64 kernel (floor 129): N = 84 gives
 // exactly 168 with 61 spilled values. Measured (8192 envs, ms/step): no cap (2 waves/SIMD, no spills) 3.26 -> N = 62 (129 VGPRs,
@@ -235,6 +255,15 @@ int kbj_env_reset_where(kbj_ctx* ctx, const float* mask_d, float* actor_next_d, 
   hipLaunchKernelGGL(env_reset_where_kernel, dim3(ctx->cfg_h.num_envs), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->mc_d, ctx->seed, ctx->ep_d, ctx->es_d,
                      mask_d, actor_next_d, critic_next_d, aux_next_d);
   KBJ_CHECK_LAUNCH(ctx, "env_reset_where_kernel");
+  return 0;
+}
+
+int kbj_env_set_command(kbj_ctx* ctx, const float* mask_d, const float* cmd_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {
+  if (!ctx || !cmd_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_set_command: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  const int N = ctx->cfg_h.num_envs, n = N * KBJ_NCMD;
+  hipLaunchKernelGGL(env_set_command_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, N, ctx->es_d, mask_d, cmd_d, actor_next_d, critic_next_d, aux_next_d);
+  KBJ_CHECK_LAUNCH(ctx, "env_set_command_kernel");
   return 0;
 }
 

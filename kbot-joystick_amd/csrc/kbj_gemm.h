@@ -10,9 +10,11 @@
 // K is consumed in 32-wide LDS tiles. k-contiguous operands sit in LDS as [row][36] (ds_read_b128 fragments,
 // conflict-free), row-contiguous ones as [k][row] (4 x ds_read_b32).
 // Pipeline: two LDS stages and one barrier per k tile — the global loads of tile k+1 are issued into registers before
-// the MFMAs of tile k and written to the other stage after them. A workgroup walks `ipw` consecutive work items
-// (output tile x k slice) and keeps that pipeline running across item boundaries, so the first-tile load latency and the
-// C write-back of the short-K shapes of this path (K = 256) hide behind the next item's loads.
+// the MFMAs of tile k and written to the other stage after them. One work item (output tile x k slice) per workgroup: with two
+// workgroups per CU the neighbour's k loop covers a workgroup's first-tile latency and C write-back. Interior tiles are fetched with
+// buffer_load_b128 from per-thread byte offsets computed once per item plus a SCALAR k offset, and the k loop is unrolled over the two
+// LDS stages, so a k tile costs no vector address arithmetic: fp32 MFMA and the vector ALU share a SIMD's issue slots (DESIGN.md
+// section 5), every VALU instruction in this loop is matrix time lost.
 // Work items are ordered n-tile fastest and handed out so that the workgroups of one XCD (blockIdx % 8) own a contiguous
 // range: the operand panel shared by neighbouring tiles is fetched into one L2, not eight.
 #pragma once
@@ -33,7 +35,6 @@ struct GemmArgs {
   int beta;             // 1: C += result, 0: C = result
   int splitk;           // >1: slices of K, results atomically added into C
   const int* a_rows;    // unused (reserved)
-  int ipw = 1;          // work items per workgroup (set by gemm_launch)
   // optional second source along k (k-contiguous operands only, k1 a multiple of 32, no split-K): for k >= k1 the operands are
   // A2[m][k - k1], B2[n][k - k1] with the same leading dimensions, i.e. C = [A | A2] [B | B2]^T without materialising the concatenation
   const float* A2 = nullptr; const float* B2 = nullptr; int k1 = 0;
@@ -189,7 +190,6 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < sb.NV; ++i) vob[i] = (unsigned)(((size_t)(kr0 + KROWS * i) * cur.ldb + cur.n0 + 4 * rq) * 4); }
   }
-  typedef unsigned u32x4g __attribute__((ext_vector_type(4)));
   // one k tile of both operands into the staging registers
   auto load_tile = [&](int k) {
     const float *pa = g.A, *pb = cur.B;

@@ -45,9 +45,22 @@ struct Sched {
 constexpr int MAX_BWD_CHUNKS = 10;
 bool env_flag(const char* name, bool dflt) { const char* v = getenv(name); return v ? atoi(v) != 0 : dflt; }
 
+constexpr int MAX_PAD_DESC = 2 * (4 + 3 * MAXD);
+
 struct NnWs {
   Sched sched;
   int H = 0, N = 0, B = 0, T = 0, D = 2;
+  // hidden_size is free (train.py:78-81); the kernels tile hidden units in groups of 64. Hu = the caller's value, H = the kernels'.
+  // Hu != H: every entry point that takes parameters, carries or a gradient converts at the boundary (zero padding is exact for this
+  // network: a padded unit has zero weights and bias, so its gates are sigma(0), tanh(0), its cell stays 0, its output 0, and every
+  // gradient into or out of it is 0) and runs the H-wide schedule on the internal copies below.
+  int Hu = 0;
+  bool inner = false;                 // set while an entry point runs on the internal copies
+  size_t unparams = 0, unactor = 0;   // parameter counts in the caller's layout
+  PadDesc* pad_desc = nullptr; int npad = 0;
+  float *pparams = nullptr, *pgrad = nullptr;
+  float *phc[4] = {nullptr, nullptr, nullptr, nullptr}, *pc0[4] = {nullptr, nullptr, nullptr, nullptr};   // carries / trajectory start carries [D][2][N][H]
+  bool padded() const { return Hu != H; }
   // deterministic mode: per-lane workspaces (lane = stream: caller's, second, side 0, side 1) for split-K slabs and reduction partials
   float* skws[4] = {nullptr, nullptr, nullptr, nullptr};
   size_t skws_cap[4] = {0, 0, 0, 0};
@@ -368,10 +381,37 @@ int kbj_nn_create(kbj_ctx* ctx) {
   NnWs* w = new NnWs();
   ctx->nn_ws = w;
   const kbj_config& c = ctx->cfg_h;
-  w->H = c.hidden_size; w->N = c.num_envs; w->B = c.batch_size; w->T = c.rollout_len;
+  w->Hu = c.hidden_size; w->H = (c.hidden_size + 63) / 64 * 64; w->N = c.num_envs; w->B = c.batch_size; w->T = c.rollout_len;
   if (w->B <= 0 || w->B > w->N) return kbj_fail(ctx, "kbj_create: batch_size must be in [1, num_envs]");
   layout_params(*w, w->H, ctx->cfg_h.depth);
   size_t N = w->N, H = w->H, B = w->B, T = w->T;
+  w->unparams = w->nparams; w->unactor = w->nactor;
+  if (w->padded()) {
+    NnWs u;
+    layout_params(u, w->Hu, c.depth);
+    w->unparams = u.nparams; w->unactor = u.nactor;
+    std::vector<PadDesc> pd;
+    const int Hu = w->Hu, Hi = w->H;
+    for (int n = 0; n < 2; ++n) {
+      const NetOff &a = u.net[n], &b = w->net[n];
+      pd.push_back(PadDesc{a.w_in, b.w_in, 1, Hu, Hi, a.nin, a.nin});
+      pd.push_back(PadDesc{a.b_in, b.b_in, 1, Hu, Hi, 1, 1});
+      for (int l = 0; l < w->D; ++l) {
+        pd.push_back(PadDesc{a.w_ih[l], b.w_ih[l], 4, Hu, Hi, Hu, Hi});
+        pd.push_back(PadDesc{a.w_hh[l], b.w_hh[l], 4, Hu, Hi, Hu, Hi});
+        pd.push_back(PadDesc{a.b[l], b.b[l], 4, Hu, Hi, 1, 1});
+      }
+      pd.push_back(PadDesc{a.w_out, b.w_out, 1, a.nout, a.nout, Hu, Hi});
+      pd.push_back(PadDesc{a.b_out, b.b_out, 1, a.nout, a.nout, 1, 1});
+    }
+    w->npad = (int)pd.size();
+    if (dalloc(ctx, *w, &w->pad_desc, pd.size())) return -1;
+    if (hipMemcpy(w->pad_desc, pd.data(), pd.size() * sizeof(PadDesc), hipMemcpyHostToDevice) != hipSuccess) return kbj_fail(ctx, "hipMemcpy pad descriptors");
+    if (dalloc(ctx, *w, &w->pparams, w->nparams) || dalloc(ctx, *w, &w->pgrad, w->nparams)) return -1;
+    const bool mir = c.actor_mirror_loss_scale != 0.0f || c.critic_mirror_loss_scale != 0.0f;
+    for (int k = 0; k < (mir ? 4 : 2); ++k)
+      if (dalloc(ctx, *w, &w->phc[k], (size_t)2 * w->D * N * H) || dalloc(ctx, *w, &w->pc0[k], (size_t)2 * w->D * N * H)) return -1;
+  }
   w->mirror = c.actor_mirror_loss_scale != 0.0f || c.critic_mirror_loss_scale != 0.0f;
   w->nnets = w->mirror ? 4 : 2;
   for (int n = 0; n < w->nnets; ++n) {
@@ -620,6 +660,49 @@ int carry_h_home(kbj_ctx* ctx, hipStream_t s, int net_lo, int net_hi, kbj_carry*
   return 0;
 }
 
+// ---- free hidden_size: conversions at the ABI boundary of a padded context (NnWs::Hu != NnWs::H) ----
+void pad_params(kbj_ctx* ctx, hipStream_t s, const float* user, float* internal) {
+  NnWs& w = *ws_of(ctx);
+  hipLaunchKernelGGL(pad_params_kernel, g1(w.nparams), dim3(256), 0, s, w.pad_desc, w.npad, const_cast<float*>(user), internal, w.nparams, 0);
+}
+void unpad_params(kbj_ctx* ctx, hipStream_t s, const float* internal, float* user) {
+  NnWs& w = *ws_of(ctx);
+  hipLaunchKernelGGL(pad_params_kernel, g1(w.nparams), dim3(256), 0, s, w.pad_desc, w.npad, user, const_cast<float*>(internal), w.nparams, 1);
+}
+// carries [D][2][N][width]: ws -> wd columns per row
+void repitch_hc(kbj_ctx* ctx, hipStream_t s, const float* src, float* dst, int ws, int wd) {
+  NnWs& w = *ws_of(ctx);
+  const size_t rows = (size_t)2 * w.D * w.N;
+  hipLaunchKernelGGL(repitch_pad_kernel, g1(rows * wd), dim3(256), 0, s, src, dst, rows, ws, wd);
+}
+// the caller's carry as an H-wide internal one (lpf state is not hidden-size dependent: shared)
+kbj_carry pad_carry(kbj_ctx* ctx, hipStream_t s, const kbj_carry& c) {
+  NnWs& w = *ws_of(ctx);
+  kbj_carry p = c;
+  float* const* src[4] = {&c.actor_hc_d, &c.critic_hc_d, &c.actor_mirror_hc_d, &c.critic_mirror_hc_d};
+  float** dst[4] = {&p.actor_hc_d, &p.critic_hc_d, &p.actor_mirror_hc_d, &p.critic_mirror_hc_d};
+  for (int k = 0; k < 4; ++k)
+    if (*src[k] && w.phc[k]) { repitch_hc(ctx, s, *src[k], w.phc[k], w.Hu, w.H); *dst[k] = w.phc[k]; }
+  return p;
+}
+void unpad_carry(kbj_ctx* ctx, hipStream_t s, const kbj_carry& c) {
+  NnWs& w = *ws_of(ctx);
+  float* user[4] = {c.actor_hc_d, c.critic_hc_d, c.actor_mirror_hc_d, c.critic_mirror_hc_d};
+  for (int k = 0; k < 4; ++k)
+    if (user[k] && w.phc[k]) repitch_hc(ctx, s, w.phc[k], user[k], w.H, w.Hu);
+}
+// the trajectory with its start carries as H-wide internal copies
+kbj_traj pad_traj_carry0(kbj_ctx* ctx, hipStream_t s, const kbj_traj& tr) {
+  NnWs& w = *ws_of(ctx);
+  kbj_traj p = tr;
+  float* const* src[4] = {&tr.carry0_actor_hc_d, &tr.carry0_critic_hc_d, &tr.carry0_actor_mirror_hc_d, &tr.carry0_critic_mirror_hc_d};
+  float** dst[4] = {&p.carry0_actor_hc_d, &p.carry0_critic_hc_d, &p.carry0_actor_mirror_hc_d, &p.carry0_critic_mirror_hc_d};
+  for (int k = 0; k < 4; ++k)
+    if (*src[k] && w.pc0[k]) { repitch_hc(ctx, s, *src[k], w.pc0[k], w.Hu, w.H); *dst[k] = w.pc0[k]; }
+  return p;
+}
+struct InnerScope { NnWs& w; explicit InnerScope(NnWs& ws) : w(ws) { w.inner = true; } ~InnerScope() { w.inner = false; } };
+
 }  // namespace
 
 extern "C" {
@@ -640,13 +723,15 @@ int kbj_init_params(kbj_ctx* ctx, uint32_t seed, float* params_d) {
   if (!ctx || !params_d) return kbj_fail(ctx, "kbj_init_params: null argument");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
-  int H = w.H;
+  NnWs u;                                // the caller's layout: fan-ins and offsets follow its hidden_size, not the kernels' padded one
+  layout_params(u, w.Hu, w.D);
+  int H = w.Hu;
   uint32_t leaf = 0;
   auto fill = [&](size_t off, size_t n, int fan_in) {
     hipLaunchKernelGGL(init_uniform_kernel, g1(n), dim3(256), 0, ctx->stream, params_d + off, n, 1.0f / std::sqrt((float)fan_in), seed, leaf++);
   };
   for (int n = 0; n < 2; ++n) {
-    const NetOff& o = w.net[n];
+    const NetOff& o = u.net[n];
     fill(o.w_in, (size_t)H * o.nin, o.nin); fill(o.b_in, H, o.nin);
     for (int l = 0; l < w.D; ++l) { fill(o.w_ih[l], (size_t)4 * H * H, H); fill(o.w_hh[l], (size_t)4 * H * H, H); fill(o.b[l], (size_t)4 * H, H); }
     fill(o.w_out, (size_t)o.nout * H, H); fill(o.b_out, o.nout, H);
@@ -660,9 +745,17 @@ int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_
   if (!ctx || !params_d || !actor_obs_d || !critic_obs_d || !carry || !action_d || !logp_d || !value_d) return kbj_fail(ctx, "kbj_policy_step: null argument");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
-  KbjTimed timed(ctx, true);
   if (w.mirror && (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d))
     return kbj_fail(ctx, "kbj_policy_step: the mirror losses are enabled, the carry needs the mirror-branch arrays");
+  if (w.padded() && !w.inner) {
+    InnerScope in(w);
+    pad_params(ctx, ctx->stream, params_d, w.pparams);
+    kbj_carry pc = pad_carry(ctx, ctx->stream, *carry);
+    const int rc = kbj_policy_step(ctx, w.pparams, actor_obs_d, critic_obs_d, &pc, seed, step_index, argmax, action_d, logp_d, value_d);
+    unpad_carry(ctx, ctx->stream, *carry);
+    return rc;
+  }
+  KbjTimed timed(ctx, true);
   if (policy_nets(ctx, ctx->stream, params_d, 0, w.nnets, 0, w.N, actor_obs_d, critic_obs_d, carry, seed, step_index, argmax, action_d, logp_d, value_d, 0,
                   fold_actor_weights(ctx, ctx->stream, params_d))) return -1;
   if (w.sched.rollout_step && carry_h_home(ctx, ctx->stream, 0, w.nnets, carry)) return -1;   // the new h sits in the partners: bring it home
@@ -675,6 +768,13 @@ int kbj_carry_reset(kbj_ctx* ctx, kbj_carry* carry, const float* done_d, int don
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
   if (w.mirror && (!carry->actor_mirror_hc_d || !carry->critic_mirror_hc_d || !carry->lpf_mirror_d)) return kbj_fail(ctx, "kbj_carry_reset: mirror-branch carry arrays are NULL");
+  if (w.padded() && !w.inner) {
+    InnerScope in(w);
+    kbj_carry pc = pad_carry(ctx, ctx->stream, *carry);
+    const int rc = kbj_carry_reset(ctx, &pc, done_d, done_stride);
+    unpad_carry(ctx, ctx->stream, *carry);
+    return rc;
+  }
   carry_reset_nets(ctx, ctx->stream, 0, w.nnets, 0, w.N, carry, done_d, done_stride, 0);
   KBJ_CHECK_LAUNCH(ctx, "carry_reset_kernel");
   return 0;
@@ -689,6 +789,23 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
   NnWs& w = *ws_of(ctx);
   int N = w.N, H = w.H, T = tr->T;
   if (tr->N != N || T <= 0) return kbj_fail(ctx, "kbj_rollout: trajectory shape does not match the context");
+  if (w.padded() && !w.inner) {   // the H-wide schedule on internal copies; the caller's start-carry snapshot is taken here, at its own width
+    InnerScope in(w);
+    const size_t ub = (size_t)2 * w.D * N * w.Hu * sizeof(float);
+    float* c0[4] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d, tr->carry0_actor_mirror_hc_d, tr->carry0_critic_mirror_hc_d};
+    float* cu[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
+    for (int k = 0; k < w.nnets; ++k) {
+      if (!c0[k] || !cu[k]) return kbj_fail(ctx, "kbj_rollout: carry / trajectory start-carry array is NULL");
+      KBJ_HIP(ctx, hipMemcpyAsync(c0[k], cu[k], ub, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    pad_params(ctx, ctx->stream, params_d, w.pparams);
+    kbj_carry pc = pad_carry(ctx, ctx->stream, *carry);
+    kbj_traj pt = *tr;
+    pt.carry0_actor_hc_d = w.pc0[0]; pt.carry0_critic_hc_d = w.pc0[1]; pt.carry0_actor_mirror_hc_d = w.pc0[2]; pt.carry0_critic_mirror_hc_d = w.pc0[3];
+    const int rc = kbj_rollout(ctx, w.pparams, &pc, seed, first_step_index, &pt);
+    unpad_carry(ctx, ctx->stream, *carry);
+    return rc;
+  }
   hipStream_t s = ctx->stream;
   size_t la = KBJ_LD_ACTOR, lc = KBJ_LD_CRITIC, lx = KBJ_AUX_SIZE;
   // observation row T of the previous rollout is row 0 of this one
@@ -896,6 +1013,12 @@ int kbj_ppo_forward(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, con
   const kbj_config& c = ctx->cfg_h;
   if (B != w.B) return kbj_fail(ctx, "kbj_ppo_forward: B must equal config.batch_size");
   if (tr->T != w.T || tr->N != w.N) return kbj_fail(ctx, "kbj_ppo_forward: trajectory shape does not match the context");
+  if (w.padded() && !w.inner) {
+    InnerScope in(w);
+    pad_params(ctx, ctx->stream, params_d, w.pparams);
+    kbj_traj pt = pad_traj_carry0(ctx, ctx->stream, *tr);
+    return kbj_ppo_forward(ctx, w.pparams, &pt, env_idx_d, B, out);
+  }
   const int T = tr->T, H = w.H, R = T * B, D = w.D;
   hipStream_t ns[2];
   if (ppo_forward_nets(ctx, params_d, tr, env_idx_d, nullptr, nullptr, nullptr, false, ns)) return -1;
@@ -932,6 +1055,17 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   int T = tr->T, N = tr->N, H = w.H;
   if (T != w.T || N != w.N) return kbj_fail(ctx, "kbj_ppo_grad: trajectory shape does not match the context");
   hipStream_t s = ctx->stream;
+  if (w.padded() && !w.inner) {
+    InnerScope in(w);
+    pad_params(ctx, s, params_d, w.pparams);
+    kbj_traj pt = pad_traj_carry0(ctx, s, *tr);
+    const int rc = kbj_ppo_grad(ctx, w.pparams, &pt, env_idx_d, B, adv_d, target_d, w.pgrad, metrics_d);
+    if (rc) return rc;
+    unpad_params(ctx, s, w.pgrad, grad_d);          // the poison markers of a timed-out recurrence sit on real elements: they travel
+    KBJ_HIP(ctx, hipEventRecord(ctx->ev_actor_grad, s));   // the caller's actor slice is final only now
+    KBJ_CHECK_LAUNCH(ctx, "pad_params_kernel");
+    return 0;
+  }
   const int R = T * B, D = w.D;
   KbjTimed timed(ctx, true);
   const bool one_stream = sc.one_stream, fold_actor = sc.fold_actor, fold_critic = sc.fold_critic;
@@ -1149,11 +1283,11 @@ int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const 
   double* sumsq = w.stats + 10;
   KBJ_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double), s));
   double* part = w.sched.deterministic ? w.detd : nullptr;
-  hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, s, grad_d, w.nparams, grad_scale, sumsq, part);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, s, grad_d, w.unparams, grad_scale, sumsq, part);
   if (part) hipLaunchKernelGGL(reduce_double_kernel, dim3(1), dim3(64), 0, s, part, 512, 1, sumsq);
   AdamParams ap{c.learning_rate, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay, c.max_grad_norm,
                 (float)(1.0 - std::pow((double)c.adam_b1, (double)step)), (float)(1.0 - std::pow((double)c.adam_b2, (double)step)), grad_scale};
-  hipLaunchKernelGGL(adamw_kernel, g1(w.nparams), dim3(256), 0, s, params_d, m_d, v_d, grad_d, w.nparams, sumsq, ap, w.seq_err);
+  hipLaunchKernelGGL(adamw_kernel, g1(w.unparams), dim3(256), 0, s, params_d, m_d, v_d, grad_d, w.unparams, sumsq, ap, w.seq_err);
   KBJ_CHECK_LAUNCH(ctx, "adamw_kernel");
   return 0;
 }

@@ -534,6 +534,33 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float
   p[i] -= ap.lr * (mh / (sqrtf(vh) + ap.eps) + ap.wd * p[i]);
 }
 
+// ---- free hidden_size: the caller's layout (hidden size Hu) <-> the kernels' (H = Hu rounded up to 64 units, zero padded) --------------
+// one parameter tensor as [nblk][rows][cols] in both layouts (LSTM weights: nblk = 4 gate blocks of Hu / H rows)
+struct PadDesc { unsigned long long uoff, ioff; int nblk, rows_u, rows_i, cols_u, cols_i; };
+
+// one thread per element of the INTERNAL vector; to_user == 0: internal <- caller's value or 0; != 0: caller's <- internal (padding dropped)
+__global__ void pad_params_kernel(const PadDesc* __restrict__ desc, int nd, float* user, float* internal, size_t n_internal, int to_user) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_internal) return;
+  int d = 0;
+  while (d + 1 < nd && desc[d + 1].ioff <= i) ++d;
+  const PadDesc t = desc[d];
+  const size_t local = i - t.ioff;
+  const int c = (int)(local % t.cols_i), r = (int)((local / t.cols_i) % t.rows_i), b = (int)(local / ((size_t)t.cols_i * t.rows_i));
+  const bool real = r < t.rows_u && c < t.cols_u;
+  const size_t u = t.uoff + ((size_t)b * t.rows_u + r) * t.cols_u + c;
+  if (to_user) { if (real) user[u] = internal[i]; }
+  else internal[i] = real ? user[u] : 0.0f;
+}
+
+// rows of width ws -> rows of width wd: the common columns copied, the rest of a wider destination zeroed
+__global__ void repitch_pad_kernel(const float* __restrict__ src, float* __restrict__ dst, size_t rows, int ws, int wd) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * wd) return;
+  const size_t r = i / wd; const int c = (int)(i % wd);
+  dst[i] = c < ws ? src[r * ws + c] : 0.0f;
+}
+
 // ---- parameter init: U(+-1/sqrt(fan_in)) per leaf (equinox default), threefry stream KBJ_RNG_INIT ------------------------
 __global__ void init_uniform_kernel(float* __restrict__ p, size_t n, float bound, uint32_t seed, uint32_t leaf) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -58,6 +58,7 @@ SIGNATURES = {
     "kbj_env_reset_all": (_i, [_vp, _u32, _vp, _vp, _vp]),
     "kbj_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "kbj_env_reset_where": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "kbj_env_set_command": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "kbj_env_get_state": (_i, [_vp, _vp, _vp]),
     "kbj_env_set_state": (_i, [_vp, _vp, _vp]),
     "kbj_env_get_reward_carry": (_i, [_vp, _vp]),
@@ -176,6 +177,10 @@ class Context:
 
     def env_reset_where(self, mask, actor_next, critic_next, aux_next):
         self.call("kbj_env_reset_where", _ptr(mask), _ptr(actor_next), _ptr(critic_next), _ptr(aux_next))
+
+    def env_set_command(self, mask, cmd, actor_next, critic_next, aux_next):
+        """mask None = every env; cmd [N, 16] float32 on the device."""
+        self.call("kbj_env_set_command", _ptr(mask) if mask is not None else None, _ptr(cmd), _ptr(actor_next), _ptr(critic_next), _ptr(aux_next))
 
     def env_get_state(self):
         import numpy as np

@@ -160,7 +160,8 @@ class HumanoidWalkingTask:
     """
 
     def __init__(self, config: HumanoidWalkingTaskConfig, device: Optional[torch.device] = None, rank: int = 0, world_size: int = 1,
-                 extra_rewards: Optional[dict] = None, extra_terminations: Optional[dict] = None, extra_observations: Optional[dict] = None):
+                 extra_rewards: Optional[dict] = None, extra_terminations: Optional[dict] = None, extra_observations: Optional[dict] = None,
+                 command=None):
         """extra_rewards: {name: term} of Python reward terms in ksim's Reward protocol (`scale`, `get_reward(trajectory)` or the stateful
         pair), evaluated on `TrajectoryView` after every rollout and added to the built-in stack's reward (host/traj_view.py).
         extra_terminations: {name: term}, `term(state, curriculum_level) -> [N] in {-1, 0, 1}` (train.py:817) on a `StepView` after every
@@ -168,11 +169,18 @@ class HumanoidWalkingTask:
         cut there. extra_observations: {name: term}, `term.observe(state, curriculum_level, rng)` or a plain callable -> [N, d]
         (train.py:635, 682, 706), evaluated per control step and kept as [T + 1, N, d] tensors for the Python reward / termination terms
         (`TrajectoryView.extra_observations[name]`); the networks' input rows stay the reference's 65 / 475 floats.
-        With either of the two the rollout runs step by step from the host (policy step, env step, user terms, carry reset: the same calls
+        command: ONE term in the reference's Command protocol (train.py:724, 768) that replaces the built-in UnifiedCommand sampler:
+        `command.initial_command(state, curriculum_level, rng) -> [N, 16]` for the envs that have just been reset and
+        `command(prev_command, state, curriculum_level, rng) -> [N, 16]` for the running ones, evaluated on the device after every
+        control step and written into the env state and the next observation rows by kbj_env_set_command (`rng` is a torch.Generator of
+        the task's device, seeded from (seed, step index)). The library then runs with command_mode = 1 so its own switch draw stays off.
+        With any of the three the rollout runs step by step from the host (policy step, env step, user terms, carry reset: the same calls
         kbj_rollout fuses, bit-identical when no user term fires) instead of as one kbj_rollout call."""
         self.extra_rewards = dict(extra_rewards or {})
         self.extra_terminations = dict(extra_terminations or {})
         self.extra_observations = dict(extra_observations or {})
+        self.command_term = command
+        self._command_started = False
         self.extra_obs_buffers: dict = {}
         self._extra_carries: dict = {}
         self.extra_reward_means: dict = {}
@@ -183,6 +191,8 @@ class HumanoidWalkingTask:
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.N, env_off = dist_util.env_shard(config.num_envs, rank, world_size)
         self.kcfg = config.to_kbj(self.N, env_id_offset=env_off)
+        if command is not None:
+            self.kcfg.command_mode = 1          # resets write fixed_command (zeros unless configured); the term overwrites it every step
         self.T, self.H, self.B = self.kcfg.rollout_len, self.kcfg.hidden_size, self.kcfg.batch_size
         self.model_blob = self.get_mujoco_model()
         torch.cuda.set_device(self.device)     # torch ops of this task and the library's launches must target the same GPU
@@ -227,7 +237,7 @@ class HumanoidWalkingTask:
     # ---- the hot path ----
     def rollout(self):
         """T control steps of all envs, trajectory + rewards on the device."""
-        if self.extra_terminations or self.extra_observations:
+        if self.extra_terminations or self.extra_observations or self.command_term is not None:
             self._rollout_stepwise()
         else:
             self.ctx.rollout(self.params, self.carry.c, self.config.seed, self.iteration * self.T, self.traj.c)
@@ -258,6 +268,24 @@ class HumanoidWalkingTask:
                     self.extra_obs_buffers[name] = torch.zeros(T + 1, self.N, v.shape[1], device=self.device)
                 self.extra_obs_buffers[name][row].copy_(v)
 
+        def command_rng(step_index: int):
+            g = torch.Generator(device=self.device)
+            g.manual_seed((self.config.seed * 2654435761 + step_index * 40503 + self.rank) & 0x7FFFFFFFFFFFFFFF)
+            return g
+
+        def update_command(row: int, view, fresh):
+            """row: the observation row the command lands in; fresh [N] bool: envs whose episode starts at that row."""
+            term, prev = self.command_term, tr.aux[row][:, L.AUX["CMD"]:L.AUX["CMD"] + L.NCMD].clone()
+            g = command_rng(first + row)
+            new = term.initial_command(view, 1.0, g).reshape(self.N, L.NCMD).to(torch.float32)
+            if not bool(fresh.all()):
+                new = torch.where(fresh[:, None], new, term(prev, view, 1.0, g).reshape(self.N, L.NCMD).to(torch.float32))
+            c.env_set_command(None, new.contiguous(), tr.actor_obs[row], tr.critic_obs[row], tr.aux[row])
+
+        if self.command_term is not None and not self._command_started:      # the rows env_reset_all wrote: every env starts an episode
+            view0 = StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob)
+            update_command(0, view0, torch.ones(self.N, dtype=torch.bool, device=self.device))
+            self._command_started = True
         for name, buf in self.extra_obs_buffers.items():
             buf[0].copy_(buf[T])
         for t in range(T):
@@ -270,6 +298,8 @@ class HumanoidWalkingTask:
                 c.env_reset_where(fire.to(torch.float32), tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
                 tr.aux[t][:, L.AUX["DONE"]] = torch.where(fire, user, tr.aux[t][:, L.AUX["DONE"]])
                 view = StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob)
+            if self.command_term is not None:
+                update_command(t + 1, view, tr.aux[t][:, L.AUX["DONE"]] != 0)
             if self.extra_observations:
                 observe(t + 1, view)
             c.carry_reset(self.carry.c, tr.aux[t].data_ptr() + done_col, L.AUX["SIZE"])
@@ -433,6 +463,7 @@ class HumanoidWalkingTask:
         # `opt_step` is this build's key; an upstream checkpoint only has the optax `count` leaf (and xax's num_steps)
         self.opt_step = int(st.get("opt_step", opt["count"] if opt is not None else 0))
         self.iteration = int(st.get("num_steps", 0))
+        self._command_started = self.iteration > 0      # a resumed run's row 0 already carries the user command term's commands
         x = z["extras"]
         if "es" not in x:
             return            # a model-only checkpoint (e.g. written by the reference): parameters and optimizer only

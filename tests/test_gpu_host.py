@@ -322,3 +322,113 @@ def test_python_termination_and_observation_terms():
     with pytest.raises(KeyError):
         _small(termination_params={"bad_z": {"nope": 1.0}}).to_kbj(64)
     stock.ctx.close(); user.ctx.close()
+
+
+def test_python_command_term():
+    """f3: a user-written Command term in the reference's protocol (train.py:724 initial_command, :768 __call__) replaces the built-in
+    sampler through kbj_env_set_command. A term that always answers one fixed command must reproduce the library's own fixed-command
+    mode (BASELINE configs[1]) BIT FOR BIT; a term that ramps the forward speed with the episode time must show up in the env state,
+    the observation rows of both networks, the record the rewards read, and the zero-command flag."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+
+    class Fixed:
+        def __init__(self, v):
+            self.v = torch.tensor(list(v) + [0.0] * (L.NCMD - len(v)), device="cuda")
+
+        def initial_command(self, state, curriculum_level, rng):
+            return self.v.expand(state.N, L.NCMD)
+
+        def __call__(self, prev_command, state, curriculum_level, rng):
+            return prev_command
+
+    class Ramp:                                         # starts standing (zero command), then +0.05 m/s forward per control step
+        def initial_command(self, state, curriculum_level, rng):
+            return torch.zeros(state.N, L.NCMD, device="cuda")
+
+        def __call__(self, prev_command, state, curriculum_level, rng):
+            out = prev_command.clone()
+            out[:, 0] = prev_command[:, 0] + 0.05
+            out[:, 6] = torch.rand(state.N, device="cuda", generator=rng) * 0.1     # an arm command drawn from the step's generator
+            return out
+
+    kw = dict(num_envs=128, batch_size=64, rollout_length_seconds=0.6)
+    stock = HumanoidWalkingTask(_small(fixed_command=(0.7, 0.0, 0.2), **kw))
+    user = HumanoidWalkingTask(_small(**kw), command=Fixed((0.7, 0.0, 0.2)))
+    assert user.kcfg.command_mode == 1
+    for it in range(2):
+        stock.rollout(); user.rollout()
+        torch.cuda.synchronize()
+        for name in ("aux", "actor_obs", "critic_obs", "action", "logp", "value", "reward"):
+            assert torch.equal(getattr(stock.traj, name), getattr(user.traj, name)), (it, name)
+        stock.iteration += 1; user.iteration += 1
+    es, eu = stock.ctx.env_get_state(), user.ctx.env_get_state()
+    assert np.array_equal(es[1].view(np.uint32), eu[1].view(np.uint32))
+    stock.ctx.close(); user.ctx.close()
+
+    ramp = HumanoidWalkingTask(_small(**kw), command=Ramp())
+    twin = HumanoidWalkingTask(_small(**kw), command=Ramp())
+    ramp.rollout(); twin.rollout()
+    torch.cuda.synchronize()
+    assert torch.equal(ramp.traj.aux, twin.traj.aux) and torch.equal(ramp.traj.reward, twin.traj.reward)      # the step generator is seeded
+    T, tr = ramp.T, ramp.traj
+    C, A, O = L.AUX["CMD"], L.AUX, L.OBS
+    done = tr.aux[:T, :, A["DONE"]] != 0
+    vx = tr.aux[:, :, C]
+    assert torch.all(vx[0] == 0)
+    expect = torch.where(done, torch.zeros_like(vx[1:]), vx[:-1] + 0.05)            # restart at zero after a reset, else the ramp
+    assert torch.equal(vx[1:], expect)
+    assert float(vx.max()) >= 0.05 * 10
+    assert torch.equal(tr.actor_obs[:, :, O["CMD"][0]:O["CMD"][0] + L.NCMD], tr.aux[:, :, C:C + L.NCMD])
+    assert torch.equal(tr.critic_obs[:, :, O["CMD"][0]:O["CMD"][0] + L.NCMD], tr.aux[:, :, C:C + L.NCMD])
+    zero = (tr.aux[:, :, C:C + 3].norm(dim=-1) < 1e-3).float()
+    assert torch.equal(tr.actor_obs[:, :, O["ZEROCMD"][0]], zero) and torch.equal(tr.critic_obs[:, :, O["ZEROCMD"][0]], zero)
+    arm = tr.aux[1:, :, C + 6][~done]
+    assert float(arm.min()) >= 0 and float(arm.max()) <= 0.1 and float(arm.std()) > 0.01
+    _, es = ramp.ctx.env_get_state()
+    assert np.array_equal(es[:, L.ES["CMD"]:L.ES["CMD"] + L.NCMD], tr.aux[T, :, C:C + L.NCMD].cpu().numpy())
+    ramp.train_iteration()
+    torch.cuda.synchronize()
+    assert torch.isfinite(ramp.params).all()
+    ramp.ctx.close(); twin.ctx.close()
+
+
+@pytest.mark.parametrize("H,mirror", [(96, False), (160, True)])
+def test_free_hidden_size_end_to_end(tmp_path, H, mirror):
+    """hidden_size is an unconstrained field of the reference's config (train.py:78-81). A hidden size between the kernels' 64-unit steps
+    runs zero padded behind the ABI; parameters, carries, gradients and checkpoints keep the CALLER's layout. Checks on a whole task:
+    parameter count = the formula for H; the step-by-step rollout (kbj_policy_step / kbj_carry_reset, one boundary conversion per call)
+    equals the fused kbj_rollout bit for bit; deterministic training is reproducible and resumes bit-identically from a checkpoint;
+    the exported actor carries H-wide leaves."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    kw = dict(actor_mirror_loss_scale=1.0, critic_mirror_loss_scale=0.01) if mirror else {}
+    cfg = _small(hidden_size=H, deterministic=True, num_passes=2, **kw)
+    a = HumanoidWalkingTask(cfg)
+    pa, pc = L.param_count(H)
+    assert a.P == pa + pc and a.ctx.actor_param_count() == pa and a.carry.actor_hc.shape == (2, 2, 64, H)
+    never = lambda state, level: torch.zeros(state.N, device="cuda")
+    s = HumanoidWalkingTask(cfg, extra_terminations={"never": never})
+    a.rollout(); s.rollout()
+    torch.cuda.synchronize()
+    for name in ("aux", "actor_obs", "critic_obs", "action", "logp", "value", "reward", "carry0_actor_hc", "carry0_critic_hc"):
+        assert torch.equal(getattr(a.traj, name), getattr(s.traj, name)), name
+    assert torch.equal(a.carry.actor_hc, s.carry.actor_hc) and torch.equal(a.carry.critic_hc, s.carry.critic_hc)
+    assert float(a.carry.actor_hc.abs().max()) > 0.01
+    a.update(); s.update()
+    a.iteration += 1; s.iteration += 1
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, s.params) and torch.isfinite(a.params).all() and float(a.grad.abs().max()) > 0
+    # on-policy re-evaluation of the stored trajectory with the pre-update parameters is covered by test_gpu_switches; here: resume
+    path = str(tmp_path / "ckpt.bin")
+    a.save_checkpoint(path)
+    a.train_iteration()
+    b = HumanoidWalkingTask.load_task(path)
+    assert b.config.hidden_size == H
+    b.train_iteration()
+    torch.cuda.synchronize()
+    assert torch.equal(a.params, b.params) and torch.equal(a.traj.value, b.traj.value) and torch.equal(a.carry.critic_hc, b.carry.critic_hc)
+    mv = b.load_ckpt(path, part="model")[0]
+    assert mv.leaves["actor.rnns.0.weight_hh"].shape == (4 * H, H) and mv.carry_size == 2 * 2 * H + 20
+    for t in (a, s, b):
+        t.ctx.close()

@@ -151,10 +151,12 @@ def test_ppo_grad_matches_autograd(H, N, B, T):
     ctx.close()
 
 
-@pytest.mark.parametrize("H,D", [(192, 2), (128, 1), (64, 3), (256, 4)])
+@pytest.mark.parametrize("H,D", [(192, 2), (128, 1), (64, 3), (256, 4), (96, 2), (200, 2), (40, 1), (7, 3)])
 def test_other_depths_and_hidden_sizes_match_oracle(H, D):
-    """`hidden_size` and `depth` are user fields of the reference config (train.py:78-85). The library serves hidden 64 / 128 / 192 / 256
-    and depth 1..4: one policy step (mode, value, every carry plane) and one minibatch gradient against the torch oracle / autograd."""
+    """`hidden_size` and `depth` are user fields of the reference config (train.py:78-85). The library serves any hidden size up to 256
+    (multiples of 64 natively; the others zero padded to the next one at the ABI boundary: parameters, carries and gradients keep the
+    caller's hidden_size layout) and depth 1..4: one policy step (mode, value, every carry plane) and one minibatch gradient against the
+    torch oracle / autograd."""
     N, B, T = 70, 35, 6
     m, cfg, ctx, torch, buffers = _setup(N, B, T, H, depth=D)
     from oracle import nn as ON

@@ -205,7 +205,7 @@ def test_deterministic_gradient_at_the_baseline_minibatch(monkeypatch):
     assert float((grads[1][0] - grads[0][0]).norm() / grads[0][0].norm()) < 1e-5
 
 
-@pytest.mark.parametrize("H,N,B,T", [(64, 24, 8, 7), (256, 128, 64, 9)])
+@pytest.mark.parametrize("H,N,B,T", [(64, 24, 8, 7), (256, 128, 64, 9), (100, 40, 20, 5)])      # 100: a zero-padded hidden size
 def test_ppo_forward_matches_oracle_and_gradient_pass(monkeypatch, H, N, B, T):
     """kbj_ppo_forward (get_ppo_variables, train.py:1510-1524) on a trajectory the rollout did not produce: log_probs / values / entropy /
     action_std against the oracle's ppo_variables (the a9 tolerances), for every minibatch of the env set."""
