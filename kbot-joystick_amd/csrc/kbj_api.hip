@@ -113,6 +113,7 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
     for (int n = 0; n < 2; ++n) KBJ_TRY(hipStreamCreateWithPriority(&ctx->dxs[n], hipStreamNonBlocking, n == 1 ? prio_greatest : 0));
   for (int k = 0; k < 32; ++k) KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_pool[k], hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_actor_grad, hipEventDisableTiming));
+  KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_small, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
 #undef KBJ_TRY

@@ -570,12 +570,29 @@ __global__ __launch_bounds__(256 * UW) void lstm_step_kernel(StepArgs a) {
   const int grow = gate * H + u0 + SEQ_UNITS * uh + (lane & 15);
   float wreg[H / 4], wxreg[KXS];
   {
-    const float* wrow = a.Whh + (size_t)grow * H;
+    // registers 4j..4j+3 of a lane are 4 CONSECUTIVE k (SeqK::kidx): 16-byte loads, 16 half cache lines per instruction instead of 64
+    // per 4-byte load - this kernel reads its weight slices once per launch, not once per 100 steps like the recurrences
+    const float* wrow = a.Whh + (size_t)grow * H + 4 * (lane >> 4);
 #pragma unroll
-    for (int s = 0; s < H / 4; ++s) wreg[s] = wrow[KH::kidx(s, lane >> 4)];
+    for (int j = 0; j < KH::NB; ++j) {
+      const f32x4m q = *reinterpret_cast<const f32x4m*>(wrow + 16 * j);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) wreg[4 * j + e] = q[e];
+    }
     const float* xrow = a.Wih + (size_t)grow * a.ldw;
+    if (a.kx == 0 && (a.ldw & 3) == 0) {
 #pragma unroll
-    for (int s = 0; s < KXS; ++s) { const int k = KXK::kidx(s, lane >> 4); wxreg[s] = k < kxv ? xrow[k] : 0.0f; }
+      for (int j = 0; j < KXK::NB; ++j) {
+        const f32x4m q = *reinterpret_cast<const f32x4m*>(xrow + 4 * (lane >> 4) + 16 * j);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wxreg[4 * j + e] = q[e];
+      }
+#pragma unroll
+      for (int s = 4 * KXK::NB; s < KXS; ++s) wxreg[s] = xrow[KXK::kidx(s, lane >> 4)];
+    } else {
+#pragma unroll
+      for (int s = 0; s < KXS; ++s) { const int k = KXK::kidx(s, lane >> 4); wxreg[s] = k < kxv ? xrow[k] : 0.0f; }
+    }
   }
   const float bias_col = a.bias[grow];
   int erow[2], eunit[2];

@@ -621,14 +621,19 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
       x = h;
     }
     if (n == 3) continue;  // the mirrored critic's value is only needed under the gradient; at rollout time only its carry advances
+    if (n == 0) {   // output projection + low-pass + sample + log-prob as one launch (the chain env -> actor -> env waits for it)
+      hipLaunchKernelGGL(actor_head_fused_kernel, dim3((cnt + HEAD_ENVS - 1) / HEAD_ENVS), dim3(256), (size_t)(40 + HEAD_ENVS) * (H + 4) * sizeof(float), s, x, H,
+                         params_d + o.w_out, params_d + o.b_out, obs, carry->lpf_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, hp, seed, (uint32_t)(c.env_id_offset + n0),
+                         step_index, argmax, cnt, action_d + (size_t)n0 * KBJ_NU, logp_d + n0);
+      continue;
+    }
+    if (n == 1 && o.nout == 1) {
+      hipLaunchKernelGGL(critic_value_fused_kernel, g1((size_t)cnt * 32), dim3(256), 0, s, x, H, params_d + o.w_out, params_d + o.b_out, cnt, value_d + n0);
+      continue;
+    }
+    // n == 2: the mirrored actor only advances its low-pass state (no sample)
     linear_fwd(s, x, H, params_d + o.w_out, H, params_d + o.b_out, Out, 40, cnt, o.nout, H, 0);
-    if (n == 0)
-      hipLaunchKernelGGL(actor_head_sample_kernel, g1((size_t)cnt * 32), dim3(256), 0, s, Out, obs, carry->lpf_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, hp, seed,
-                         (uint32_t)(c.env_id_offset + n0), step_index, argmax, cnt, action_d + (size_t)n0 * KBJ_NU, logp_d + n0);
-    else if (n == 1)
-      hipLaunchKernelGGL(critic_value_kernel, g1(cnt), dim3(256), 0, s, Out, 40, cnt, value_d + n0);
-    else
-      hipLaunchKernelGGL(actor_head_lpf_kernel, g1((size_t)cnt * KBJ_NU), dim3(256), 0, s, Out, obs, carry->lpf_mirror_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, c.lpf_alpha, cnt);
+    hipLaunchKernelGGL(actor_head_lpf_kernel, g1((size_t)cnt * KBJ_NU), dim3(256), 0, s, Out, obs, carry->lpf_mirror_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, c.lpf_alpha, cnt);
   }
   return 0;
 }
@@ -914,11 +919,6 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, KBJ_LD_ACTOR, 0, 1, nullptr};
     gemm_launch<true, false>(s, g);
     hipLaunchKernelGGL(matvec_kernel, dim3((4 * H + 3) / 4), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
-    // each accumulator is cleared on the lane whose side stream later accumulates into it (actor-type nets: the caller's stream,
-    // critic-type nets with the backward fold: the second stream), so the clear is always ordered before the split-K accumulation
-    if (grad)
-      for (int n = 0; n < w.nnets; ++n)
-        if ((n & 1) == 0 || sc.fold_critic) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), ns[n & 1]));
   }
   auto gather = [&](hipStream_t st, const float* src, int wdt, int lds, float* dst, int ldd) {
     if (wdt % 4 == 0 && lds % 4 == 0 && ldd % 4 == 0 && ((size_t)src & 15) == 0 && ((size_t)dst & 15) == 0)
@@ -930,7 +930,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
   gather(ns[1], tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);
   gather(s, tr->actor_obs_d, KBJ_LD_ACTOR, KBJ_LD_ACTOR, w.tb[0].obs, KBJ_LD_ACTOR);
   GatherSmallArgs gs{tr->action_d, grad ? tr->logp_d : nullptr, grad ? tr->value_d : nullptr, adv_d, target_d, tr->aux_d, w.act, w.logp_old, w.val_old, w.adv, w.target, w.keep};
-  hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R * (KBJ_NU + 5)), dim3(256), 0, s, gs, idx, T, N, B);
+  hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R), dim3(256), 0, s, gs, idx, T, N, B, KBJ_NU + 4, KBJ_NU + 5);   // keep flags: all the recurrences need of these
   const float* carry0[4] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d, tr->carry0_actor_mirror_hc_d, tr->carry0_critic_mirror_hc_d};
   if (w.mirror && (!carry0[2] || !carry0[3] || !tr->carry0_lpf_mirror_d))
     return kbj_fail(ctx, "PPO pass: the mirror losses are enabled, the trajectory needs the mirror-branch carries");
@@ -945,12 +945,25 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
   gc.src[gc.nplanes] = tr->carry0_lpf_d; gc.dst[gc.nplanes] = w.lpf0; gc.nlpf++;
   if (w.mirror) { gc.src[gc.nplanes + 1] = tr->carry0_lpf_mirror_d; gc.dst[gc.nplanes + 1] = w.lpf0_m; gc.nlpf++; }
   hipLaunchKernelGGL(gather_carry_kernel, dim3((B * H + 255) / 256, gc.nplanes + gc.nlpf), dim3(256), 0, s, gc, idx, B, H);
-  if (grad) {
-    // nothing on the forward path needs these: the advantage statistics and the cleared accumulators are ready long before the loss
-    KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), s));
-    hipLaunchKernelGGL(adv_stats_kernel, dim3(32), dim3(256), 0, s, w.adv, R, w.stats, sc.deterministic ? w.detd : (double*)nullptr);
-    if (sc.deterministic) hipLaunchKernelGGL(reduce_double_kernel, dim3(1), dim3(64), 0, s, w.detd, 32, 2, w.stats);
-    KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), s));
+  {
+    // Nothing on the forward path needs the rest: actions, old log-probs / values, advantages, targets, the advantage statistics and the
+    // cleared accumulators (gradient, folded layer-0 products) are wanted at the loss, two recurrences later. They run on the actor's
+    // side lane, idle until the backward pass, instead of in front of the first recurrence (where they were ~170 us of a 6 ms
+    // minibatch with the matrix cores idle); both net lanes wait for them behind their last forward recurrence, and the side lanes
+    // fork from the net lanes after that point, so every later reader and accumulator is ordered behind the clears.
+    hipStream_t sm = sc.one_stream ? s : ctx->side[0];
+    if (!sc.one_stream) KBJ_HIP(ctx, hipStreamWaitEvent(sm, ctx->ev_fork, 0));
+    hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R * (KBJ_NU + 4)), dim3(256), 0, sm, gs, idx, T, N, B, 0, KBJ_NU + 4);
+    if (grad) {
+      KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), sm));
+      hipLaunchKernelGGL(adv_stats_kernel, dim3(32), dim3(256), 0, sm, w.adv, R, w.stats, sc.deterministic ? w.detd : (double*)nullptr);
+      if (sc.deterministic) hipLaunchKernelGGL(reduce_double_kernel, dim3(1), dim3(64), 0, sm, w.detd, 32, 2, w.stats);
+      KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), sm));
+      if (sc.fold_actor)
+        for (int n = 0; n < w.nnets; ++n)
+          if ((n & 1) == 0 || sc.fold_critic) KBJ_HIP(ctx, hipMemsetAsync(w.Zeff[n], 0, (size_t)4 * H * w.net[n & 1].ld_obs * sizeof(float), sm));
+    }
+    if (!sc.one_stream) KBJ_HIP(ctx, hipEventRecord(ctx->ev_small, sm));
   }
   // the critic's lane needs keep / carries (gathered above on the caller's stream) before its first recurrence - not before its input
   // projection, which only reads its own gather: the wait sits in front of the recurrences below
@@ -999,6 +1012,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
       if (seq_fwd(ctx, ns[n & 1], H, fa)) return -1;
     }
   }
+  if (!sc.one_stream) for (int k = 0; k < 2; ++k) KBJ_HIP(ctx, hipStreamWaitEvent(ns[k], ctx->ev_small, 0));   // the side-lane gathers / clears above
   return 0;
 }
 
@@ -1249,9 +1263,9 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   if (fold_actor) fold_bias_terms(0, ctx->stream);
   hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d);
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_actor_grad, ctx->stream));
+  if (fold_actor && fold_critic) fold_bias_terms(1, ns[1]);   // on the critic's own lane (its side lane has joined it above), beside the actor's
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-  if (fold_actor && fold_critic) fold_bias_terms(1, ctx->stream);
   // a recurrence that timed out left a truncated gradient: poison it so that every data-parallel rank skips the optimizer step
   hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d + w.nactor);
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_grad");

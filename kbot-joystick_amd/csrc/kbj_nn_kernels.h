@@ -55,34 +55,79 @@ __device__ __forceinline__ void nn_threefry(uint32_t k0, uint32_t k1, uint32_t c
 }
 
 // ---- actor head at rollout time (train.py:924-941, 1545-1572): 32 lanes per env, one per joint (20 active) --------------
-// (one thread per env walked the 20 joints serially - threefry, log, cos, softplus each - on 128 wavefronts: 48 us on the rollout's
-// critical chain; per joint it is 10 us)
 struct HeadParams { float min_std, max_std, var_scale, alpha; };
-__global__ void actor_head_sample_kernel(const float* __restrict__ out /*[N][40]*/, const float* __restrict__ obs /*[N][68]*/,
-                                         float* __restrict__ lpf /*[N][20]*/, const float* __restrict__ joint_bias, HeadParams hp, uint32_t seed,
-                                         uint32_t env_off, uint32_t step, int argmax, int N, float* __restrict__ action, float* __restrict__ logp) {
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int n = tid >> 5, j = tid & 31;
-  float lp = 0;
-  if (n < N && j < KBJ_NU) {
-    float mean = out[n * 40 + j] + joint_bias[j] + (j >= 10 ? obs[(size_t)n * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
-    float sd = fminf((softplusf_(out[n * 40 + KBJ_NU + j]) + hp.min_std) * hp.var_scale, hp.max_std);
-    float y0 = lpf[n * KBJ_NU + j];
-    float y = y0 + hp.alpha * (mean - y0);
-    lpf[n * KBJ_NU + j] = y;
-    float a = y;
-    if (!argmax) {
-      uint32_t b0, b1;
-      nn_threefry(seed ^ ((uint32_t)KBJ_RNG_ACTION * 0x9E3779B9u), env_off + (uint32_t)n, step, (uint32_t)j, b0, b1);
-      float u1 = (float)((b0 >> 8) + 1u) * (1.0f / 16777216.0f), u2 = (float)(b1 >> 8) * (1.0f / 16777216.0f);
-      a = y + sd * (sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2));
-    }
-    action[n * KBJ_NU + j] = a;
-    float z = (a - y) / sd;
-    lp = -0.5f * z * z - logf(sd) - 0.5f * kLog2Pi;
+// The rollout's actor head as ONE launch on the env -> actor -> env chain: output projection (H -> 40), low-pass, Gaussian sample and
+// log-prob. (As a 64x64-tile GEMM the 40-column projection was 29 us of mostly latency, the sampling kernel 20 us more.) 32 lanes per
+// env: lane j < 20 owns joint j and accumulates its mean and its std logit over the hidden row; W_out sits in LDS ([40][H + 4]: the
+// lanes of an env read different rows 16 bytes at a time without bank conflicts), the hidden rows of the workgroup's 16 envs beside it.
+constexpr int HEAD_ENVS = 16;   // envs per workgroup (two passes of 8)
+__global__ __launch_bounds__(256) void actor_head_fused_kernel(const float* __restrict__ hin /*[N][H]*/, int H, const float* __restrict__ Wout /*[40][H]*/,
+                                                               const float* __restrict__ bout, const float* __restrict__ obs /*[N][68]*/, float* __restrict__ lpf,
+                                                               const float* __restrict__ joint_bias, HeadParams hp, uint32_t seed, uint32_t env_off, uint32_t step,
+                                                               int argmax, int N, float* __restrict__ action, float* __restrict__ logp) {
+  extern __shared__ __attribute__((aligned(16))) float head_lds[];
+  const int LD = H + 4, tid = threadIdx.x, q4 = H / 4;
+  float* Ws = head_lds;                 // [40][LD]
+  float* hs = head_lds + 40 * LD;       // [HEAD_ENVS][LD]
+  const int n0 = blockIdx.x * HEAD_ENVS;
+  for (int i = tid; i < 40 * q4; i += 256) {
+    const int r = i / q4, c = i % q4;
+    *reinterpret_cast<float4*>(Ws + r * LD + 4 * c) = *reinterpret_cast<const float4*>(Wout + (size_t)r * H + 4 * c);
   }
-  for (int o = 16; o > 0; o >>= 1) lp += __shfl_xor(lp, o);   // sum over the env's 32 lanes (inactive ones hold 0)
-  if (n < N && j == 0) logp[n] = lp;
+  for (int i = tid; i < HEAD_ENVS * q4; i += 256) {
+    const int r = i / q4, c = i % q4, n = n0 + r;
+    *reinterpret_cast<float4*>(hs + r * LD + 4 * c) = n < N ? *reinterpret_cast<const float4*>(hin + (size_t)n * H + 4 * c) : float4{0, 0, 0, 0};
+  }
+  __syncthreads();
+  const int j = tid & 31, jj = j < KBJ_NU ? j : 0;
+#pragma unroll
+  for (int pass = 0; pass < HEAD_ENVS / 8; ++pass) {
+    const int e = pass * 8 + (tid >> 5), n = n0 + e;
+    const float4* hr = reinterpret_cast<const float4*>(hs + e * LD);
+    const float4* wm = reinterpret_cast<const float4*>(Ws + jj * LD);
+    const float4* wsd = reinterpret_cast<const float4*>(Ws + (KBJ_NU + jj) * LD);
+    float am[4] = {0, 0, 0, 0}, as[4] = {0, 0, 0, 0};
+    for (int c = 0; c < q4; ++c) {
+      const float4 h = hr[c], a = wm[c], b = wsd[c];
+      am[0] = fmaf(h.x, a.x, am[0]); am[1] = fmaf(h.y, a.y, am[1]); am[2] = fmaf(h.z, a.z, am[2]); am[3] = fmaf(h.w, a.w, am[3]);
+      as[0] = fmaf(h.x, b.x, as[0]); as[1] = fmaf(h.y, b.y, as[1]); as[2] = fmaf(h.z, b.z, as[2]); as[3] = fmaf(h.w, b.w, as[3]);
+    }
+    float lp = 0;
+    if (n < N && j < KBJ_NU) {
+      const float om = (am[0] + am[1]) + (am[2] + am[3]) + bout[j], os = (as[0] + as[1]) + (as[2] + as[3]) + bout[KBJ_NU + j];
+      float mean = om + joint_bias[j] + (j >= 10 ? obs[(size_t)n * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
+      float sd = fminf((softplusf_(os) + hp.min_std) * hp.var_scale, hp.max_std);
+      float y0 = lpf[n * KBJ_NU + j];
+      float y = y0 + hp.alpha * (mean - y0);
+      lpf[n * KBJ_NU + j] = y;
+      float a = y;
+      if (!argmax) {
+        uint32_t b0, b1;
+        nn_threefry(seed ^ ((uint32_t)KBJ_RNG_ACTION * 0x9E3779B9u), env_off + (uint32_t)n, step, (uint32_t)j, b0, b1);
+        float u1 = (float)((b0 >> 8) + 1u) * (1.0f / 16777216.0f), u2 = (float)(b1 >> 8) * (1.0f / 16777216.0f);
+        a = y + sd * (sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2));
+      }
+      action[n * KBJ_NU + j] = a;
+      float z = (a - y) / sd;
+      lp = -0.5f * z * z - logf(sd) - 0.5f * kLog2Pi;
+    }
+    for (int o = 16; o > 0; o >>= 1) lp += __shfl_xor(lp, o);
+    if (n < N && j == 0) logp[n] = lp;
+  }
+}
+
+// the rollout's critic head as one launch: value[n] = h[n] . w_out + b_out (one output; 32 lanes per env)
+__global__ __launch_bounds__(256) void critic_value_fused_kernel(const float* __restrict__ hin /*[N][H]*/, int H, const float* __restrict__ wout /*[H]*/,
+                                                                 const float* __restrict__ bout, int N, float* __restrict__ value) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x, n = tid >> 5, j = tid & 31;
+  float acc = 0;
+  if (n < N)
+    for (int c = j; c < H / 4; c += 32) {
+      const float4 h = *reinterpret_cast<const float4*>(hin + (size_t)n * H + 4 * c), w = *reinterpret_cast<const float4*>(wout + 4 * c);
+      acc = fmaf(h.x, w.x, acc); acc = fmaf(h.y, w.y, acc); acc = fmaf(h.z, w.z, acc); acc = fmaf(h.w, w.w, acc);
+    }
+  for (int o = 16; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (n < N && j == 0) value[n] = acc + bout[0];
 }
 
 // value_d[n] = out[n][0]
@@ -138,12 +183,14 @@ struct GatherSmallArgs {
   const float *action, *logp, *value, *adv, *target, *aux;
   float *action_o, *logp_o, *value_o, *adv_o, *target_o, *keep_o;
 };
-__global__ void gather_small_kernel(GatherSmallArgs a, const int* __restrict__ idx, int T, int N, int B) {
-  constexpr int W = KBJ_NU + 5;
+// columns [c0, c1) of the 25 per sample: 0..19 action, 20 old log-prob, 21 old value, 22 advantage, 23 target, 24 keep. The forward recurrences
+// need the keep flags only (one launch of column 24 on their lane); the rest is gathered on a side lane, off the chain that starts them.
+__global__ void gather_small_kernel(GatherSmallArgs a, const int* __restrict__ idx, int T, int N, int B, int c0, int c1) {
+  const int W = c1 - c0;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)T * B * W) return;
   size_t r = i / W;
-  int c = (int)(i - r * W), b = (int)(r % B);
+  int c = c0 + (int)(i - r * W), b = (int)(r % B);
   size_t src = (r / B) * N + idx[b];
   if (c < KBJ_NU) a.action_o[r * KBJ_NU + c] = a.action[src * KBJ_NU + c];
   else if (c == KBJ_NU) { if (a.logp) a.logp_o[r] = a.logp[src]; }          // the forward-only pass (kbj_ppo_forward) gathers actions and keep flags only
