@@ -622,7 +622,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
     }
     if (n == 3) continue;  // the mirrored critic's value is only needed under the gradient; at rollout time only its carry advances
     if (n == 0) {   // output projection + low-pass + sample + log-prob as one launch (the chain env -> actor -> env waits for it)
-      hipLaunchKernelGGL(actor_head_fused_kernel, dim3((cnt + HEAD_ENVS - 1) / HEAD_ENVS), dim3(256), (size_t)(40 + HEAD_ENVS) * (H + 4) * sizeof(float), s, x, H,
+      hipLaunchKernelGGL(actor_head_fused_kernel, dim3((cnt + HEAD_ENVS * HEAD_WAVES - 1) / (HEAD_ENVS * HEAD_WAVES)), dim3(64 * HEAD_WAVES), 0, s, x, H,
                          params_d + o.w_out, params_d + o.b_out, obs, carry->lpf_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, hp, seed, (uint32_t)(c.env_id_offset + n0),
                          step_index, argmax, cnt, action_d + (size_t)n0 * KBJ_NU, logp_d + n0);
       continue;

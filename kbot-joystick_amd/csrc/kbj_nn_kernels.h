@@ -57,62 +57,73 @@ __device__ __forceinline__ void nn_threefry(uint32_t k0, uint32_t k1, uint32_t c
 // ---- actor head at rollout time (train.py:924-941, 1545-1572): 32 lanes per env, one per joint (20 active) --------------
 struct HeadParams { float min_std, max_std, var_scale, alpha; };
 // The rollout's actor head as ONE launch on the env -> actor -> env chain: output projection (H -> 40), low-pass, Gaussian sample and
-// log-prob. (As a 64x64-tile GEMM the 40-column projection was 29 us of mostly latency, the sampling kernel 20 us more.) 32 lanes per
-// env: lane j < 20 owns joint j and accumulates its mean and its std logit over the hidden row; W_out sits in LDS ([40][H + 4]: the
-// lanes of an env read different rows 16 bytes at a time without bank conflicts), the hidden rows of the workgroup's 16 envs beside it.
-constexpr int HEAD_ENVS = 16;   // envs per workgroup (two passes of 8)
-__global__ __launch_bounds__(256) void actor_head_fused_kernel(const float* __restrict__ hin /*[N][H]*/, int H, const float* __restrict__ Wout /*[40][H]*/,
-                                                               const float* __restrict__ bout, const float* __restrict__ obs /*[N][68]*/, float* __restrict__ lpf,
-                                                               const float* __restrict__ joint_bias, HeadParams hp, uint32_t seed, uint32_t env_off, uint32_t step,
-                                                               int argmax, int N, float* __restrict__ action, float* __restrict__ logp) {
-  extern __shared__ __attribute__((aligned(16))) float head_lds[];
-  const int LD = H + 4, tid = threadIdx.x, q4 = H / 4;
-  float* Ws = head_lds;                 // [40][LD]
-  float* hs = head_lds + 40 * LD;       // [HEAD_ENVS][LD]
-  const int n0 = blockIdx.x * HEAD_ENVS;
-  for (int i = tid; i < 40 * q4; i += 256) {
-    const int r = i / q4, c = i % q4;
-    *reinterpret_cast<float4*>(Ws + r * LD + 4 * c) = *reinterpret_cast<const float4*>(Wout + (size_t)r * H + 4 * c);
-  }
-  for (int i = tid; i < HEAD_ENVS * q4; i += 256) {
-    const int r = i / q4, c = i % q4, n = n0 + r;
-    *reinterpret_cast<float4*>(hs + r * LD + 4 * c) = n < N ? *reinterpret_cast<const float4*>(hin + (size_t)n * H + 4 * c) : float4{0, 0, 0, 0};
+// log-prob. (As a 64x64-tile GEMM the 40-column projection was 45 us of mostly latency at 8192 envs, the sampling kernel 22 us more.)
+// It runs beside the critic's GEMMs of the same step, which hold most of every CU's LDS and registers, so it is built to fit in the
+// gaps: one wavefront per 16 envs, the projection as 3 x H / 4 v_mfma_f32_16x16x4_f32 with both operands fetched straight from global
+// memory in fragment layout (16-byte loads: 4 consecutive k per lane; W_out is 40 KB and stays in L2 / L1), ~5 KB of LDS per
+// workgroup for the hand-over to the per-joint stage.
+constexpr int HEAD_ENVS = 16;    // envs per wavefront (one MFMA row block)
+constexpr int HEAD_WAVES = 4;    // wavefronts per workgroup
+typedef float head_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64 * HEAD_WAVES) void actor_head_fused_kernel(const float* __restrict__ hin /*[N][H]*/, int H, const float* __restrict__ Wout /*[40][H]*/,
+                                                                          const float* __restrict__ bout, const float* __restrict__ obs /*[N][68]*/,
+                                                                          float* __restrict__ lpf, const float* __restrict__ joint_bias, HeadParams hp, uint32_t seed,
+                                                                          uint32_t env_off, uint32_t step, int argmax, int N, float* __restrict__ action,
+                                                                          float* __restrict__ logp) {
+  __shared__ float outs[HEAD_WAVES][HEAD_ENVS][49];          // [env][output], 48 columns used (40 real)
+  __shared__ float lps[HEAD_WAVES][HEAD_ENVS][KBJ_NU + 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+  const int n0 = (blockIdx.x * HEAD_WAVES + wv) * HEAD_ENVS;
+  if (n0 < N) {   // wavefront-uniform
+    const float* arow = hin + (size_t)min(n0 + c, N - 1) * H + 4 * g;
+    const float* brow[3] = {Wout + (size_t)c * H + 4 * g, Wout + (size_t)(16 + c) * H + 4 * g, Wout + (size_t)min(32 + c, 2 * KBJ_NU - 1) * H + 4 * g};
+    head_f32x4 acc[3] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+    for (int k = 0; k < H; k += 16) {   // lane (g, c) feeds k + 4 g + q to MFMA q of the block: the same k for A and B
+      const head_f32x4 a = *reinterpret_cast<const head_f32x4*>(arow + k);
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const head_f32x4 b = *reinterpret_cast<const head_f32x4*>(brow[t] + k);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[q], acc[t], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) outs[wv][4 * g + r][16 * t + c] = acc[t][r];   // C[row = 4 g + r][col = c]
   }
   __syncthreads();
-  const int j = tid & 31, jj = j < KBJ_NU ? j : 0;
-#pragma unroll
-  for (int pass = 0; pass < HEAD_ENVS / 8; ++pass) {
-    const int e = pass * 8 + (tid >> 5), n = n0 + e;
-    const float4* hr = reinterpret_cast<const float4*>(hs + e * LD);
-    const float4* wm = reinterpret_cast<const float4*>(Ws + jj * LD);
-    const float4* wsd = reinterpret_cast<const float4*>(Ws + (KBJ_NU + jj) * LD);
-    float am[4] = {0, 0, 0, 0}, as[4] = {0, 0, 0, 0};
-    for (int c = 0; c < q4; ++c) {
-      const float4 h = hr[c], a = wm[c], b = wsd[c];
-      am[0] = fmaf(h.x, a.x, am[0]); am[1] = fmaf(h.y, a.y, am[1]); am[2] = fmaf(h.z, a.z, am[2]); am[3] = fmaf(h.w, a.w, am[3]);
-      as[0] = fmaf(h.x, b.x, as[0]); as[1] = fmaf(h.y, b.y, as[1]); as[2] = fmaf(h.z, b.z, as[2]); as[3] = fmaf(h.w, b.w, as[3]);
-    }
-    float lp = 0;
-    if (n < N && j < KBJ_NU) {
-      const float om = (am[0] + am[1]) + (am[2] + am[3]) + bout[j], os = (as[0] + as[1]) + (as[2] + as[3]) + bout[KBJ_NU + j];
-      float mean = om + joint_bias[j] + (j >= 10 ? obs[(size_t)n * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
-      float sd = fminf((softplusf_(os) + hp.min_std) * hp.var_scale, hp.max_std);
-      float y0 = lpf[n * KBJ_NU + j];
-      float y = y0 + hp.alpha * (mean - y0);
-      lpf[n * KBJ_NU + j] = y;
-      float a = y;
-      if (!argmax) {
-        uint32_t b0, b1;
-        nn_threefry(seed ^ ((uint32_t)KBJ_RNG_ACTION * 0x9E3779B9u), env_off + (uint32_t)n, step, (uint32_t)j, b0, b1);
-        float u1 = (float)((b0 >> 8) + 1u) * (1.0f / 16777216.0f), u2 = (float)(b1 >> 8) * (1.0f / 16777216.0f);
-        a = y + sd * (sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2));
+  if (n0 < N) {
+    for (int item = lane; item < HEAD_ENVS * KBJ_NU; item += 64) {   // one (env, joint) per lane and pass
+      const int e = item / KBJ_NU, j = item - e * KBJ_NU, n = n0 + e;
+      float lp = 0;
+      if (n < N) {
+        const float om = outs[wv][e][j] + bout[j], os = outs[wv][e][KBJ_NU + j] + bout[KBJ_NU + j];
+        float mean = om + joint_bias[j] + (j >= 10 ? obs[(size_t)n * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
+        float sd = fminf((softplusf_(os) + hp.min_std) * hp.var_scale, hp.max_std);
+        float y0 = lpf[n * KBJ_NU + j];
+        float y = y0 + hp.alpha * (mean - y0);
+        lpf[n * KBJ_NU + j] = y;
+        float a = y;
+        if (!argmax) {
+          uint32_t b0, b1;
+          nn_threefry(seed ^ ((uint32_t)KBJ_RNG_ACTION * 0x9E3779B9u), env_off + (uint32_t)n, step, (uint32_t)j, b0, b1);
+          float u1 = (float)((b0 >> 8) + 1u) * (1.0f / 16777216.0f), u2 = (float)(b1 >> 8) * (1.0f / 16777216.0f);
+          a = y + sd * (sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2));
+        }
+        action[n * KBJ_NU + j] = a;
+        float z = (a - y) / sd;
+        lp = -0.5f * z * z - logf(sd) - 0.5f * kLog2Pi;
       }
-      action[n * KBJ_NU + j] = a;
-      float z = (a - y) / sd;
-      lp = -0.5f * z * z - logf(sd) - 0.5f * kLog2Pi;
+      lps[wv][e][j] = lp;
     }
-    for (int o = 16; o > 0; o >>= 1) lp += __shfl_xor(lp, o);
-    if (n < N && j == 0) logp[n] = lp;
+  }
+  __syncthreads();
+  if (n0 < N && lane < HEAD_ENVS && n0 + lane < N) {
+    float lp = 0;
+#pragma unroll
+    for (int j = 0; j < KBJ_NU; ++j) lp += lps[wv][lane][j];   // fixed order: the log-prob of an env does not depend on the launch shape
+    logp[n0 + lane] = lp;
   }
 }
 
