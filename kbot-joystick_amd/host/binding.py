@@ -94,20 +94,24 @@ def build_library(force: bool = False) -> str:
 _lib = None
 
 
+def load_library_at(path: str) -> C.CDLL:
+    """dlopen one build of the ABI (RTLD_LOCAL: several builds can live in one process, e.g. the A/B solver test) and type its symbols."""
+    if not os.path.exists(path):
+        raise KbjError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch bundles its own ROCm runtime: import it first so that libkbj.so binds to the SAME libamdhip64
+    # (loading /opt/rocm's copy first leaves the process with two HIP runtimes and no visible device)
+    import torch  # noqa: F401
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here means the library does not match include/kbj.h
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
 def load_library() -> C.CDLL:
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise KbjError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950). "
-                           "There is no CPU fallback.")
-        # torch bundles its own ROCm runtime: import it first so that libkbj.so binds to the SAME libamdhip64
-        # (loading /opt/rocm's copy first leaves the process with two HIP runtimes and no visible device)
-        import torch  # noqa: F401
-        lib = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(lib, name)  # AttributeError here means the library does not match include/kbj.h
-            fn.restype, fn.argtypes = res, args
-        _lib = lib
+        _lib = load_library_at(LIB_PATH)
     return _lib
 
 
@@ -136,8 +140,8 @@ def _ptr(t):
 class Context:
     """RAII wrapper of kbj_ctx."""
 
-    def __init__(self, model: L.Model, config: L.Config, device: int = 0, stream: int | None = None):
-        self.lib = load_library()
+    def __init__(self, model: L.Model, config: L.Config, device: int = 0, stream: int | None = None, lib: C.CDLL | None = None):
+        self.lib = lib if lib is not None else load_library()
         if self.lib.kbj_sizeof_model() != C.sizeof(L.Model) or self.lib.kbj_sizeof_config() != C.sizeof(L.Config):
             raise KbjError("struct layout mismatch between spec/layout.py and libkbj.so")
         if self.lib.kbj_sizeof_traj() != C.sizeof(Traj) or self.lib.kbj_sizeof_carry() != C.sizeof(Carry):
