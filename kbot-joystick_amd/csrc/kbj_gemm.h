@@ -42,6 +42,10 @@ struct GemmArgs {
   // 0 = ldb) and go to C2[m][n - n1] (ldc2, 0 = ldc) — two products that share A in one launch, so neighbouring workgroups share
   // the A panel in L2
   float* C2 = nullptr; int n1 = 0, ldb2 = 0, ldc2 = 0;
+  // optional row gather of a k-contiguous A (A_KC kernels, no second k source): logical row m = t * a_B + b is read from stored row
+  // t * a_N + a_idx[b] - the minibatch view [T][B] of a trajectory array [T][N] through the minibatch's env indices, without a
+  // gathered copy in front of the GEMM (the per-thread row offsets are computed once per work item either way)
+  const int* a_idx = nullptr; int a_B = 0, a_N = 0;
   // deterministic split-K (kbj_config.deterministic): instead of fp32 atomics into C, k slice ks stores its partial tile into
   // skws[ks][M][N] (N = all columns of the launch, both problems) and splitk_reduce_kernel adds the slices to C in slice order
   float* skws = nullptr;
@@ -73,7 +77,8 @@ struct GemmStage {
     }
   }
   // P: operand base, ld, R: number of valid rows, r0: first row of the tile, k0/kend: k range
-  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int R, int r0, int k0, int kend, bool vec) {
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int R, int r0, int k0, int kend, bool vec, const int* idx = nullptr, int iB = 0,
+                                       int iN = 0) {
     const int tid = threadIdx.x;
     if (KC) {
       const int kq = tid & 7, rr = tid >> 3;
@@ -83,6 +88,7 @@ struct GemmStage {
         f32x4 x = {0, 0, 0, 0};
         if (r < R) {
           size_t base = (size_t)r * ld;
+          if (idx) { const int t = r / iB; base = ((size_t)t * iN + idx[r - t * iB]) * ld; }   // GemmArgs::a_idx
           if (vec && k + 3 < kend) x = *reinterpret_cast<const f32x4*>(P + base + k);
           else { for (int e = 0; e < 4; ++e) if (k + e < kend) x[e] = P[base + k + e]; }
         }
@@ -179,7 +185,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
   {
     if (A_KC) { const int kq = tid & 7, rr = tid >> 3;
 #pragma unroll
-      for (int i = 0; i < sa.NV; ++i) voa[i] = (unsigned)(((size_t)(cur.m0 + rr + sa.RPP * i) * g.lda + 4 * kq) * 4); }
+      for (int i = 0; i < sa.NV; ++i) {
+        size_t row = (size_t)(cur.m0 + rr + sa.RPP * i);
+        if (g.a_idx && rows_a) {   // gathered rows, relative to the tile's first time step (a_base below): offsets stay small
+          const int m = (int)row, t = m / g.a_B;
+          row = (size_t)(t - cur.m0 / g.a_B) * g.a_N + g.a_idx[m - t * g.a_B];
+        }
+        voa[i] = (unsigned)((row * g.lda + 4 * kq) * 4);
+      } }
     else { constexpr int QPR = BM / 4, KROWS = NTH / QPR; const int rq = tid % QPR, kr0 = tid / QPR;
 #pragma unroll
       for (int i = 0; i < sa.NV; ++i) voa[i] = (unsigned)(((size_t)(kr0 + KROWS * i) * g.lda + cur.m0 + 4 * rq) * 4); }
@@ -200,11 +213,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
     }
     const bool kfull = kk + GEMM_BK <= ke;
     if (rows_a && kfull) {
+      if (A_KC && g.a_idx) pa += (size_t)(cur.m0 / g.a_B) * g.a_N * g.lda;   // first time step of the tile
       __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pa), 0, 0x7FFFFFFF, 0x00020000);
       const unsigned so = (unsigned)(A_KC ? (size_t)kk * 4 : (size_t)kk * g.lda * 4);      // scalar: the k advance costs no vector instruction
 #pragma unroll
       for (int i = 0; i < sa.NV; ++i) sa.v[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, voa[i], so, 0));
-    } else sa.load(pa, g.lda, g.M, cur.m0, kk, ke, a_vec);
+    } else sa.load(pa, g.lda, g.M, cur.m0, kk, ke, a_vec, A_KC ? g.a_idx : nullptr, g.a_B, g.a_N);
     if (rows_b && kfull) {
       __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pb), 0, 0x7FFFFFFF, 0x00020000);
       const unsigned so = (unsigned)(B_KC ? (size_t)kk * 4 : (size_t)kk * cur.ldb * 4);

@@ -926,8 +926,12 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
                          reinterpret_cast<float4*>(dst));
     else hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)R * wdt), dim3(256), 0, st, src, idx, T, N, B, wdt, lds, ldd, dst);
   };
-  // the large critic observation block on the critic's stream, everything else on the caller's
-  gather(ns[1], tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);
+  // The large critic observation block (97 MB per minibatch, 45 us at HBM speed): the forward pass reads it once, through the critic's
+  // input projection - which fetches its rows straight from the trajectory through the minibatch's indices (GemmArgs::a_idx) - so the
+  // gathered copy, which the backward pass and the mirror branch want, is made on the critic's side lane, off the chain that starts the
+  // critic's first recurrence. (One stream, mirror branches or an unfolded actor: gathered in front of the projection as before.)
+  const bool gather_late = !sc.one_stream && !w.mirror && sc.fold_actor;
+  if (!gather_late) gather(ns[1], tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);
   gather(s, tr->actor_obs_d, KBJ_LD_ACTOR, KBJ_LD_ACTOR, w.tb[0].obs, KBJ_LD_ACTOR);
   GatherSmallArgs gs{tr->action_d, grad ? tr->logp_d : nullptr, grad ? tr->value_d : nullptr, adv_d, target_d, tr->aux_d, w.act, w.logp_old, w.val_old, w.adv, w.target, w.keep};
   hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R), dim3(256), 0, s, gs, idx, T, N, B, KBJ_NU + 4, KBJ_NU + 5);   // keep flags: all the recurrences need of these
@@ -990,6 +994,17 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     // re-pitched copy with the observation rows' stride (zeros behind column nin, as in the observation rows) is made first; the
     // contraction then runs over the padded width
     if (n < 2) hipLaunchKernelGGL(repitch_rows_kernel, g1((size_t)H * o.ld_obs), dim3(256), 0, ns[n & 1], params_d + o.w_in, H, o.nin, o.ld_obs, w.WinP[n & 1]);
+    if (n == 1 && gather_late) {
+      GemmArgs g{tr->critic_obs_d, w.WinP[1], w.tb[1].X0, params_d + o.b_in, R, H, o.ld_obs, o.ld_obs, o.ld_obs, H, 0, 1, nullptr};
+      g.a_idx = idx; g.a_B = B; g.a_N = N;
+      gemm_launch<true, true>(ns[1], g);
+      // the copy behind the projection, under the recurrences (beside it the two would share HBM: 175 instead of 144 us for the GEMM)
+      KBJ_HIP(ctx, hipEventRecord(ctx->ev_obs, ns[1]));
+      KBJ_HIP(ctx, hipStreamWaitEvent(ctx->side[1], ctx->ev_obs, 0));
+      if (grad) gather(ctx->side[1], tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);   // the forward-only pass never reads the copy
+      KBJ_HIP(ctx, hipEventRecord(ctx->ev_obs, ctx->side[1]));
+      continue;
+    }
     linear_fwd(ns[n & 1], w.tb[n].obs, o.ld_obs, w.WinP[n & 1], o.ld_obs, params_d + o.b_in, w.tb[n].X0, H, R, H, o.ld_obs, 0);
   }
   if (!sc.one_stream) KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));   // keep / carries gathered on the caller's stream
@@ -1013,6 +1028,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     }
   }
   if (!sc.one_stream) for (int k = 0; k < 2; ++k) KBJ_HIP(ctx, hipStreamWaitEvent(ns[k], ctx->ev_small, 0));   // the side-lane gathers / clears above
+  if (gather_late) KBJ_HIP(ctx, hipStreamWaitEvent(ns[1], ctx->ev_obs, 0));   // the critic's gathered rows (its backward pass reads them on this lane or its side lane)
   return 0;
 }
 
@@ -1192,7 +1208,13 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       hipStream_t s = ns[n & 1], ws = side_of(n);
       const unsigned* prog = w.bwd_progress + (size_t)(4 * l + n) * MAX_BWD_CHUNKS;
       const bool folded = fold_actor && l == 0 && ((n & 1) == 0 || fold_critic);
-      if (nch == 1) fork_side(n);     // the side lane starts behind the whole recurrence
+      // The last thing a lane does - layer 0 of its net - needs no side lane: nothing is left on the net's lane for the weight
+      // gradients to run beside, and a cross-lane hop costs 15-20 us each way (fork + join) in the minibatch's tail. (Not with mirror
+      // branches: two nets per lane then read-modify-write the same dW_ih0 through their small products, which only the shared side
+      // lane orders.)
+      const bool own_lane = l == 0 && nch == 1 && !w.mirror && folded;
+      if (own_lane) ws = s;
+      else if (nch == 1) fork_side(n);     // the side lane starts behind the whole recurrence
       // (the dx and side lanes need no event from the net's lane here: a gate passes only once this layer's recurrence runs, and that
       // recurrence started behind everything the lane did before - the previous readers of the dX buffer included)
       for (int c = nch - 1; c >= 0; --c) {
