@@ -247,6 +247,18 @@ class HumanoidWalkingTask:
             view.extra_observations = {k: v[:self.T] for k, v in self.extra_obs_buffers.items()}
             self.extra_reward_means = apply_extra_rewards(self.extra_rewards, self._extra_carries, view, self.traj.reward)
 
+    def _apply_command(self, ctx, tr, row: int, view, fresh, step_index: int):
+        """The user's Command term for observation row `row` of `tr` (train.py:724, 768): `initial_command` for the envs whose episode
+        starts there (`fresh` [N] bool), `__call__(prev_command, ...)` for the others, written by kbj_env_set_command."""
+        term, n = self.command_term, tr.aux[row].shape[0]
+        g = torch.Generator(device=self.device)
+        g.manual_seed((self.config.seed * 2654435761 + step_index * 40503 + self.rank) & 0x7FFFFFFFFFFFFFFF)
+        prev = tr.aux[row][:, L.AUX["CMD"]:L.AUX["CMD"] + L.NCMD].clone()
+        new = term.initial_command(view, 1.0, g).reshape(n, L.NCMD).to(torch.float32)
+        if not bool(fresh.all()):
+            new = torch.where(fresh[:, None], new, term(prev, view, 1.0, g).reshape(n, L.NCMD).to(torch.float32))
+        ctx.env_set_command(None, new.contiguous(), tr.actor_obs[row], tr.critic_obs[row], tr.aux[row])
+
     def _rollout_stepwise(self):
         """kbj_rollout's steps as separate ABI calls with the user's Termination / Observation terms between the env step and the carry
         reset (train.py:817, 635 protocols on host/traj_view.StepView)."""
@@ -268,19 +280,8 @@ class HumanoidWalkingTask:
                     self.extra_obs_buffers[name] = torch.zeros(T + 1, self.N, v.shape[1], device=self.device)
                 self.extra_obs_buffers[name][row].copy_(v)
 
-        def command_rng(step_index: int):
-            g = torch.Generator(device=self.device)
-            g.manual_seed((self.config.seed * 2654435761 + step_index * 40503 + self.rank) & 0x7FFFFFFFFFFFFFFF)
-            return g
-
         def update_command(row: int, view, fresh):
-            """row: the observation row the command lands in; fresh [N] bool: envs whose episode starts at that row."""
-            term, prev = self.command_term, tr.aux[row][:, L.AUX["CMD"]:L.AUX["CMD"] + L.NCMD].clone()
-            g = command_rng(first + row)
-            new = term.initial_command(view, 1.0, g).reshape(self.N, L.NCMD).to(torch.float32)
-            if not bool(fresh.all()):
-                new = torch.where(fresh[:, None], new, term(prev, view, 1.0, g).reshape(self.N, L.NCMD).to(torch.float32))
-            c.env_set_command(None, new.contiguous(), tr.actor_obs[row], tr.critic_obs[row], tr.aux[row])
+            self._apply_command(c, tr, row, view, fresh, first + row)
 
         if self.command_term is not None and not self._command_started:      # the rows env_reset_all wrote: every env starts an episode
             view0 = StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob)
@@ -519,6 +520,8 @@ class HumanoidWalkingTask:
         if getattr(self, "_valid", None) is None or self._valid[0] != key:
             vcfg = self.config.to_kbj(num_envs) if num_envs % self.config.batch_size == 0 else dataclasses.replace(self.config, batch_size=num_envs).to_kbj(num_envs)
             vcfg.rollout_len = T
+            if self.command_term is not None:
+                vcfg.command_mode = 1
             vctx = B.Context(self.model_blob, vcfg, self.device.index or 0, torch.cuda.current_stream().cuda_stream)
             self._valid = (key, vctx, CarryBuffers(num_envs, self.H, self.kcfg.depth, self.device, mirror=self.mirror),
                            TrajBuffers(T, num_envs, self.H, self.kcfg.depth, self.device, mirror=self.mirror, reward_comps=True))
@@ -526,9 +529,16 @@ class HumanoidWalkingTask:
         seed = self.config.seed + seed_offset
         carry.zero_()
         vctx.env_reset_all(seed, tr.actor_obs[0], tr.critic_obs[0], tr.aux[0])
+        if self.command_term is not None:       # the user's Command term drives the validation envs as it drives the training ones
+            from .traj_view import StepView
+            self._apply_command(vctx, tr, 0, StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob),
+                                torch.ones(num_envs, dtype=torch.bool, device=self.device), seed_offset)
         for t in range(T):
             vctx.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], carry.c, seed, t, True, tr.action[t], tr.logp[t], tr.value[t])
             vctx.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
+            if self.command_term is not None:
+                self._apply_command(vctx, tr, t + 1, StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob),
+                                    tr.aux[t][:, L.AUX["DONE"]] != 0, seed_offset + t + 1)
             vctx.carry_reset(carry.c, tr.aux[t].data_ptr() + 4 * L.AUX["DONE"], L.AUX["SIZE"])
         vctx.rewards(tr.aux, T, tr.reward, tr.comps)
         vctx.synchronize()

@@ -390,6 +390,13 @@ def test_python_command_term():
     ramp.train_iteration()
     torch.cuda.synchronize()
     assert torch.isfinite(ramp.params).all()
+    # the deterministic validation rollout is driven by the same term (its own env set and context)
+    v = ramp.validate(num_envs=64, seconds=0.4)
+    vtr = ramp._valid[3]
+    vdone = vtr.aux[:20, :, A["DONE"]] != 0
+    vvx = vtr.aux[:21, :, C]
+    assert torch.all(vvx[0] == 0) and torch.equal(vvx[1:], torch.where(vdone, torch.zeros_like(vvx[1:]), vvx[:-1] + 0.05))
+    assert np.isfinite(v["valid/reward_per_step"])
     ramp.ctx.close(); twin.ctx.close()
 
 
