@@ -98,5 +98,11 @@ int main(int argc, char** argv) {
   run<true, true>("rollout ih (N x 4H x H)", 8192, 1024, 256, 1, -1, A, B, C, false);
   run<true, true>("rollout half (N/2 x 4H x H)", 4096, 1024, 256, 1, -1, A, B, C, false);
   run<true, true>("square 4096", 4096, 4096, 4096, 1, -1, A, B, C, false);
+  // the same product with the other operand layouts: what a row-contiguous operand (4 x ds_read_b32 per fragment) costs by itself
+  run<true, false>("square 4096 (B row-contig)", 4096, 4096, 4096, 1, -1, A, B, C, false);
+  run<false, false>("square 4096 (A, B row-contig)", 4096, 4096, 4096, 1, -1, A, B, C, false);
+  // the in-situ shapes of the update's tail: long k slices (sk 16 / 32)
+  run<false, false>("dW critic L0 (4H x 768 x R) sk16", 1024, 768, 51200, 16, 1, A, B, C, false);
+  run<false, false>("dW actor L0 (4H x 384 x R) sk32", 1024, 384, 51200, 32, 1, A, B, C, false);
   return 0;
 }
