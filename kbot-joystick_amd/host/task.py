@@ -308,10 +308,24 @@ class HumanoidWalkingTask:
 
     def update(self):
         """GAE, then num_passes x (N / B) minibatch steps: BPTT gradient, all-reduce, AdamW."""
-        self.ctx.gae(self.traj.c, self.traj.adv, self.traj.target)
-        for p in range(self.kcfg.num_passes):
+        # the passes' permutations: drawn on the host (same streams as the oracle trainer), staged in pinned memory and uploaded with
+        # stream-ordered copies BEFORE anything of the update is enqueued - a pageable `.to(device)` per pass blocks the host until the
+        # queued work has drained and leaves the GPU idle (~0.3 ms) while the next minibatch is being enqueued
+        npass = self.kcfg.num_passes
+        if getattr(self, "_perm_pinned", None) is None or self._perm_pinned.shape != (npass, self.N):
+            self._perm_pinned = torch.empty(npass, self.N, dtype=torch.int32).pin_memory()
+            self._perm_dev = torch.empty(npass, self.N, dtype=torch.int32, device=self.device)
+            self._perm_event = torch.cuda.Event()
+        else:
+            self._perm_event.synchronize()       # the previous upload has left the staging buffer (it has, unless the caller never syncs)
+        for p in range(npass):
             self._perm_gen.manual_seed((self.config.seed * 1000003 + self.iteration * 97 + p) & 0x7FFFFFFF)
-            perm = torch.randperm(self.N, generator=self._perm_gen).int().to(self.device)
+            self._perm_pinned[p].copy_(torch.randperm(self.N, generator=self._perm_gen))
+        self._perm_dev.copy_(self._perm_pinned, non_blocking=True)
+        self._perm_event.record()
+        self.ctx.gae(self.traj.c, self.traj.adv, self.traj.target)
+        for p in range(npass):
+            perm = self._perm_dev[p]
             nmb = self.N // self.B
             per_pass = self.config.allreduce == "per_pass"
             if per_pass:
