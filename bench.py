@@ -262,7 +262,7 @@ def main():
         env_roof = dict(bound="hbm", kernel="env_step_kernel", achieved=round(ach_gbs, 2), peak=PEAK_HBM_GBS, unit="GB/s",
                         frac=round(ach_gbs / PEAK_HBM_GBS, 5), traffic=traffic.get("env_step_kernel"), avg_launch_us=round(per_launch * 1e6, 1),
                         launches=prof["env_step_launches"], envs_per_launch=int(envs_per_launch), total_ms=round(prof["env_step_ms"], 2),
-                        note="latency/issue-bound per-env solver; HBM is not the limiter (DESIGN.md)")
+                        note="vector-issue bound (wave64 VALU instruction = 4 SIMD cycles; valu_issue_utilisation in profiles/*_pmc_env_step.json); HBM is not the limiter (DESIGN.md section 5)")
         kernels = [env_roof]
         for k in prof["kernels"]:      # every launch bracketed by HIP events on its own stream inside libkbj.so
             if k["name"] == "env_step_kernel":

@@ -40,6 +40,11 @@ typedef struct kbj_ctx kbj_ctx;
 int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const kbj_config* cfg, int device, void* hip_stream);
 int kbj_destroy(kbj_ctx* ctx);
 const char* kbj_last_error(const kbj_ctx* ctx); /* ctx may be NULL: error of a failed kbj_create */
+/* Host-only check of the sizes a configuration asks for (no device needed; kbj_create applies it first): 0 = served, -1 = refused with the
+ * reason in `why`. Besides the range checks (hidden_size 1..256, depth 1..4, Newton solver) it refuses configurations whose largest
+ * operand - the minibatch stash [rollout_len x batch_size][4 hidden_size | 476] or one control step's [num_envs][...] rows - reaches
+ * 2 GiB: those arrays are fetched with 32-bit byte offsets. (The reference has no such limit: XLA addresses with 64 bits.) */
+int kbj_check_config(const kbj_config* cfg, char* why, size_t why_bytes);
 int kbj_sizeof_model(void);
 int kbj_sizeof_config(void);
 int kbj_sizeof_traj(void);    /* sizeof(kbj_traj), sizeof(kbj_carry): let a binding verify its struct mirrors */

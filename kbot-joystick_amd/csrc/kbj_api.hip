@@ -1,5 +1,6 @@
 // kbj_api.hip — context lifetime and the rollout driver of libkbj.so (C ABI in include/kbj.h).
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstring>
 #include "kbj_ctx.h"
 #include "kbj_env_core.h"
@@ -43,6 +44,34 @@ int kbj_sizeof_config(void) { return (int)sizeof(kbj_config); }
 int kbj_sizeof_traj(void) { return (int)sizeof(kbj_traj); }
 int kbj_sizeof_carry(void) { return (int)sizeof(kbj_carry); }
 
+// Host-only validation of the sizes the kernels are built for (no device needed; kbj_create runs it first). Besides the plain range
+// checks: the GEMM's interior tiles and the recurrences' hand-off tiles are fetched with buffer loads whose per-thread and scalar byte
+// offsets are 32-bit against a descriptor of 2^31 - 1 bytes (kbj_gemm.h load_tile, kbj_lstm_seq.h SeqTile::load) - an operand that
+// reaches 2 GiB would be read as zeros beyond that offset, silently. The largest operands are the BPTT stash of one minibatch
+// [T * B][4 H] (and the gathered critic observations [T * B][476]) and, per control step, the [N][476] observation rows and [N][4 H] gates.
+int kbj_check_config(const kbj_config* cfg, char* why, size_t why_bytes) {
+  auto fail = [&](const std::string& msg) {
+    if (why && why_bytes) { std::snprintf(why, why_bytes, "%s", msg.c_str()); }
+    return -1;
+  };
+  if (!cfg) return fail("null config");
+  if (cfg->num_envs <= 0 || cfg->substeps <= 0 || cfg->rollout_len <= 0) return fail("bad config sizes");
+  if (cfg->solver_newton != 1) return fail("only the Newton solver is implemented on the GPU (solver_newton = 1)");
+  if (cfg->hidden_size < 1 || cfg->hidden_size > 256 || cfg->depth < 1 || cfg->depth > KBJ_MAX_DEPTH)
+    return fail("hidden_size must be in 1..256 (multiples of 64 run unpadded) and depth in 1..4 (train.py:78-85 defaults 128 / 2, launch 256 / 2)");
+  const unsigned long long lim = 1ull << 31;
+  const unsigned long long Hp = (unsigned long long)((cfg->hidden_size + 63) / 64 * 64), T = (unsigned long long)cfg->rollout_len;
+  const unsigned long long B = (unsigned long long)(cfg->batch_size > 0 ? cfg->batch_size : cfg->num_envs), N = (unsigned long long)cfg->num_envs;
+  const unsigned long long wide = 4 * Hp > KBJ_LD_CRITIC ? 4 * Hp : KBJ_LD_CRITIC;
+  if (T * B * wide * sizeof(float) >= lim)
+    return fail("rollout_len x batch_size x max(4 hidden_size, 476) x 4 bytes reaches 2 GiB: the minibatch's stash arrays are addressed with 32-bit "
+                "byte offsets (buffer loads) - use a smaller batch_size (" + std::to_string(T * B * wide * sizeof(float)) + " bytes)");
+  if (N * wide * sizeof(float) >= lim)
+    return fail("num_envs x max(4 hidden_size, 476) x 4 bytes reaches 2 GiB: one control step's observation / gate rows are addressed with 32-bit byte "
+                "offsets - shard the envs over more GPUs (" + std::to_string(N * wide * sizeof(float)) + " bytes)");
+  return 0;
+}
+
 const char* kbj_last_error(const kbj_ctx* ctx) { return ctx ? ctx->error.c_str() : kbj_global_error.c_str(); }
 
 int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const kbj_config* cfg, int device, void* hip_stream) {
@@ -54,11 +83,9 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   ctx->cfg_h = *cfg;
   std::string why;
   if (!topology_ok(ctx->model_h, why)) { delete ctx; return kbj_fail(nullptr, "kbj_create: " + why); }
-  if (cfg->num_envs <= 0 || cfg->substeps <= 0 || cfg->rollout_len <= 0) { delete ctx; return kbj_fail(nullptr, "kbj_create: bad config sizes"); }
-  if (cfg->solver_newton != 1) { delete ctx; return kbj_fail(nullptr, "kbj_create: only the Newton solver is implemented on the GPU (solver_newton = 1)"); }
-  if (cfg->hidden_size < 1 || cfg->hidden_size > 256 || cfg->depth < 1 || cfg->depth > KBJ_MAX_DEPTH) {
-    delete ctx;
-    return kbj_fail(nullptr, "kbj_create: hidden_size must be in 1..256 (multiples of 64 run unpadded) and depth in 1..4 (train.py:78-85 defaults 128 / 2, launch 256 / 2)");
+  {
+    char msg[512];
+    if (kbj_check_config(cfg, msg, sizeof(msg)) != 0) { delete ctx; return kbj_fail(nullptr, std::string("kbj_create: ") + msg); }
   }
   ctx->device = device;
   ctx->stream = (hipStream_t)hip_stream;

@@ -50,6 +50,7 @@ SIGNATURES = {
     "kbj_create": (_i, [C.POINTER(_vp), _vp, _sz, _cfgp, _i, _vp]),
     "kbj_destroy": (_i, [_vp]),
     "kbj_last_error": (C.c_char_p, [_vp]),
+    "kbj_check_config": (_i, [_vp, _vp, _sz]),
     "kbj_sizeof_model": (_i, []),
     "kbj_sizeof_config": (_i, []),
     "kbj_sizeof_traj": (_i, []),
@@ -113,6 +114,13 @@ def load_library() -> C.CDLL:
     if _lib is None:
         _lib = load_library_at(LIB_PATH)
     return _lib
+
+
+def check_config(cfg) -> str:
+    """kbj_check_config (host-only): '' when the library serves this kbj_config, else the reason kbj_create would refuse it with."""
+    why = C.create_string_buffer(512)
+    rc = load_library().kbj_check_config(C.addressof(cfg), why, C.sizeof(why))
+    return "" if rc == 0 else why.value.decode()
 
 
 def mirror_table(model, critic: bool):

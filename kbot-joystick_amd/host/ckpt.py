@@ -81,8 +81,10 @@ def _add(tar: tarfile.TarFile, name: str, data: bytes):
 
 
 def save_ckpt(path: str, params: np.ndarray, opt_m: np.ndarray, opt_v: np.ndarray, opt_count: int, hidden_size: int, depth: int,
-              state: dict, config: dict, extras: Optional[Dict[str, np.ndarray]] = None) -> None:
-    """Write `ckpt.bin`. `extras` (name -> array) are this build's resume payload (kbj_* members)."""
+              state: dict, config: dict, extras: Optional[Dict[str, np.ndarray]] = None, schedule_count: Optional[int] = None) -> None:
+    """Write `ckpt.bin`. `extras` (name -> array) are this build's resume payload (kbj_* members). `schedule_count`: with a learning-rate
+    schedule (train.py:1067-1077, either branch) optax's state tree ends in a ScaleByScheduleState(count) leaf - (count, mu.., nu.., count);
+    pass the optimizer-step count to write that trailing leaf so that the reference's optimizer tree has as many leaves as the file."""
     model = [a for _, a in split_leaves(np.asarray(params), hidden_size, depth)]
     mu = [a for _, a in split_leaves(np.asarray(opt_m), hidden_size, depth)]
     nu = [a for _, a in split_leaves(np.asarray(opt_v), hidden_size, depth)]
@@ -90,7 +92,8 @@ def save_ckpt(path: str, params: np.ndarray, opt_m: np.ndarray, opt_v: np.ndarra
     tmp = path + ".tmp"        # never leave a truncated ckpt.bin behind: write beside it, flush to disk, then rename over it
     with open(tmp, "wb") as fh, tarfile.open(fileobj=fh, mode="w:gz") as tar:
         _add(tar, "model_0", _npy_blobs(model))
-        _add(tar, "opt_state_0", _npy_blobs([np.asarray(opt_count, np.int32)] + mu + nu))
+        tail = [] if schedule_count is None else [np.asarray(schedule_count, np.int32)]
+        _add(tar, "opt_state_0", _npy_blobs([np.asarray(opt_count, np.int32)] + mu + nu + tail))
         _add(tar, "state", json.dumps(state).encode())
         _add(tar, "config", _yaml(config).encode())
         for k, v in (extras or {}).items():
@@ -156,3 +159,8 @@ def load_ckpt(path: str, part: str = "all", hidden_size: Optional[int] = None, d
         raise ValueError(f"unknown part {part!r}")
     extras = {k[4:]: _read_blobs(v, 1)[0] for k, v in members.items() if k.startswith("kbj_")}
     return dict(model=model(), opt_state=opt_state(), state=state, config=config, extras=extras)
+
+
+def has_member(path: str, name: str) -> bool:
+    with tarfile.open(path, "r:gz") as tar:
+        return any(m.name == name for m in tar.getmembers())

@@ -89,6 +89,10 @@ class HumanoidWalkingTaskConfig:
     # bit-reproducible update: fixed-order reductions instead of fp32 / fp64 atomics in the gradient (kbj_config.deterministic); the
     # reference's XLA program is deterministic by default, here it costs a few percent and is off unless asked for
     deterministic: bool = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_DETERMINISTIC", "0") not in ("0", ""))
+    # use_lr_decay with adam_weight_decay == 0 is train.py:1074-1075 AS WRITTEN: optax.chain(scale_by_adam(), scale_by_schedule(cosine)) has
+    # no sign flip, i.e. gradient ASCENT. Served only with this explicit opt-in (recorded in the checkpoint's config member); without it
+    # that combination is an error.
+    reproduce_reference_lr_sign: bool = False
 
     def to_kbj(self, num_envs_local: int, env_id_offset: int = 0) -> L.Config:
         if self.batch_size <= 0 or num_envs_local % self.batch_size != 0:
@@ -96,7 +100,12 @@ class HumanoidWalkingTaskConfig:
         # use_lr_decay with adam_weight_decay == 0 is train.py:1074-1075: optax.chain(scale_by_adam(), scale_by_schedule(cosine_schedule)).
         # AS WRITTEN that chain has no sign flip (optax.adam ends in scale_by_learning_rate = scale(-lr); scale_by_schedule does not), so
         # the parameters move ALONG the Adam direction: p += lr_t * m / (sqrt(v) + eps). It is served as written - kbj_adamw_step with
-        # weight_decay 0 and the learning rate -cosine_decay_lr (update()) - and update() warns once, because it is gradient ascent.
+        # weight_decay 0 and the learning rate -cosine_decay_lr (update()) - behind reproduce_reference_lr_sign only; every rank says so at
+        # construction and update() warns once, because it is gradient ascent.
+        if self.use_lr_decay and self.adam_weight_decay == 0.0 and not self.reproduce_reference_lr_sign:
+            raise ValueError("use_lr_decay with adam_weight_decay == 0 is train.py:1074-1075: optax.chain(scale_by_adam, scale_by_schedule) "
+                             "has no sign flip, so the update ASCENDS the loss. Set reproduce_reference_lr_sign=True to run it as written, "
+                             "or use a non-zero adam_weight_decay (the adamw branch, train.py:1076-1077)")
         T = int(round(self.rollout_length_seconds / self.ctrl_dt))
         kw = dict(num_envs=num_envs_local, env_id_offset=env_id_offset, rollout_len=T, substeps=int(round(self.ctrl_dt / self.dt)),
                   solver_iterations=self.iterations, ls_iterations=self.ls_iterations, hidden_size=self.hidden_size, depth=self.depth,
@@ -127,7 +136,7 @@ class HumanoidWalkingTaskConfig:
                 elif (name, k) == ("not_upright", "max_radians"):
                     kw["max_tilt_rad"] = min(v, math.pi)
                 elif (name, k) == ("episode_length", "max_length_sec"):
-                    kw["max_episode_steps"] = int(min(v / self.ctrl_dt, 2 ** 30))
+                    kw["max_episode_steps"] = int(min(round(v / self.ctrl_dt), 2 ** 30))     # round like T and substeps: 2.3 / 0.02 is 115, not 114
                 else:
                     raise KeyError(f"unknown termination parameter {name}.{k} (bad_z.unhealthy_z | not_upright.max_radians | episode_length.max_length_sec)")
         kcfg = L.default_config(**kw)
@@ -188,6 +197,10 @@ class HumanoidWalkingTask:
             raise B.KbjError("HumanoidWalkingTask needs a HIP device (no CPU fallback)")
         self.config = config
         self.rank, self.world_size = rank, world_size
+        if config.use_lr_decay and config.adam_weight_decay == 0.0 and config.reproduce_reference_lr_sign:
+            import sys                       # every rank, at construction: a single warnings.warn is easy to lose in a multi-rank log
+            print(f"[kbj rank {rank}] reproduce_reference_lr_sign: optax.chain(scale_by_adam, scale_by_schedule) as written in "
+                  "train.py:1074-1075 has no sign flip - this run ASCENDS the loss", file=sys.stderr, flush=True)
         self.device = device or torch.device("cuda", torch.cuda.current_device())
         self.N, env_off = dist_util.env_shard(config.num_envs, rank, world_size)
         self.kcfg = config.to_kbj(self.N, env_id_offset=env_off)
@@ -247,15 +260,17 @@ class HumanoidWalkingTask:
             view.extra_observations = {k: v[:self.T] for k, v in self.extra_obs_buffers.items()}
             self.extra_reward_means = apply_extra_rewards(self.extra_rewards, self._extra_carries, view, self.traj.reward)
 
-    def _apply_command(self, ctx, tr, row: int, view, fresh, step_index: int):
+    def _apply_command(self, ctx, tr, row: int, view, fresh, step_index: int, all_fresh: bool = False):
         """The user's Command term for observation row `row` of `tr` (train.py:724, 768): `initial_command` for the envs whose episode
-        starts there (`fresh` [N] bool), `__call__(prev_command, ...)` for the others, written by kbj_env_set_command."""
+        starts there (`fresh` [N] bool), `__call__(prev_command, ...)` for the others, written by kbj_env_set_command. `all_fresh`: the
+        caller KNOWS every env starts an episode (rows written by a reset of all envs); otherwise both are evaluated and selected on the
+        device - asking `fresh.all()` would drain the queue once per control step."""
         term, n = self.command_term, tr.aux[row].shape[0]
         g = torch.Generator(device=self.device)
         g.manual_seed((self.config.seed * 2654435761 + step_index * 40503 + self.rank) & 0x7FFFFFFFFFFFFFFF)
         prev = tr.aux[row][:, L.AUX["CMD"]:L.AUX["CMD"] + L.NCMD].clone()
         new = term.initial_command(view, 1.0, g).reshape(n, L.NCMD).to(torch.float32)
-        if not bool(fresh.all()):
+        if not all_fresh:
             new = torch.where(fresh[:, None], new, term(prev, view, 1.0, g).reshape(n, L.NCMD).to(torch.float32))
         ctx.env_set_command(None, new.contiguous(), tr.actor_obs[row], tr.critic_obs[row], tr.aux[row])
 
@@ -280,12 +295,12 @@ class HumanoidWalkingTask:
                     self.extra_obs_buffers[name] = torch.zeros(T + 1, self.N, v.shape[1], device=self.device)
                 self.extra_obs_buffers[name][row].copy_(v)
 
-        def update_command(row: int, view, fresh):
-            self._apply_command(c, tr, row, view, fresh, first + row)
+        def update_command(row: int, view, fresh, all_fresh: bool = False):
+            self._apply_command(c, tr, row, view, fresh, first + row, all_fresh)
 
         if self.command_term is not None and not self._command_started:      # the rows env_reset_all wrote: every env starts an episode
             view0 = StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob)
-            update_command(0, view0, torch.ones(self.N, dtype=torch.bool, device=self.device))
+            update_command(0, view0, torch.ones(self.N, dtype=torch.bool, device=self.device), all_fresh=True)
             self._command_started = True
         for name, buf in self.extra_obs_buffers.items():
             buf[0].copy_(buf[T])
@@ -465,7 +480,7 @@ class HumanoidWalkingTask:
         state = dict(num_steps=self.iteration, opt_step=self.opt_step, num_samples=self.iteration * self.N * self.T * self.world_size,
                      rank=self.rank, world_size=self.world_size)
         ckpt_io.save_ckpt(path, self.params.cpu().numpy(), self.opt_m.cpu().numpy(), self.opt_v.cpu().numpy(), self.opt_step, self.H, self.kcfg.depth,
-                          state, cfg, extras)
+                          state, cfg, extras, schedule_count=self.opt_step if self.config.use_lr_decay else None)
 
     def load_checkpoint(self, path: str):
         """Resume from save_checkpoint(): the next train_iteration() is bit-identical to the one the saved run would have made."""
@@ -473,10 +488,19 @@ class HumanoidWalkingTask:
         dev = self.device
         self.params.copy_(torch.from_numpy(z["model"]))
         opt, st = z["opt_state"], z["state"]
-        if opt is not None:       # None: no optimizer member, or one this build cannot map onto (mu, nu): keep the fresh moments
+        if opt is not None:
             self.opt_m.copy_(torch.from_numpy(opt["mu"])); self.opt_v.copy_(torch.from_numpy(opt["nu"]))
-        # `opt_step` is this build's key; an upstream checkpoint only has the optax `count` leaf (and xax's num_steps)
-        self.opt_step = int(st.get("opt_step", opt["count"] if opt is not None else 0))
+            # `opt_step` is this build's key; an upstream checkpoint only has the optax `count` leaf (and xax's num_steps)
+            self.opt_step = int(st.get("opt_step", opt["count"]))
+        else:
+            # no optimizer member, or one this build cannot map onto (mu, nu): the moments restart from zero, and so must the step count -
+            # Adam's bias correction at the OLD count on empty moments would be ~1 instead of 1 / (1 - beta^t) and shrink the first steps
+            self.opt_m.zero_(); self.opt_v.zero_()
+            self.opt_step = 0
+            if ckpt_io.has_member(path, "opt_state_0"):
+                import warnings
+                warnings.warn(f"{path}: opt_state_0 is present but does not map onto (count, mu, nu) of this model - "
+                              "resuming with FRESH Adam moments and optimizer step 0 (parameters were loaded)")
         self.iteration = int(st.get("num_steps", 0))
         self._command_started = self.iteration > 0      # a resumed run's row 0 already carries the user command term's commands
         x = z["extras"]
@@ -546,7 +570,7 @@ class HumanoidWalkingTask:
         if self.command_term is not None:       # the user's Command term drives the validation envs as it drives the training ones
             from .traj_view import StepView
             self._apply_command(vctx, tr, 0, StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob),
-                                torch.ones(num_envs, dtype=torch.bool, device=self.device), seed_offset)
+                                torch.ones(num_envs, dtype=torch.bool, device=self.device), seed_offset, all_fresh=True)
         for t in range(T):
             vctx.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], carry.c, seed, t, True, tr.action[t], tr.logp[t], tr.value[t])
             vctx.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])

@@ -66,6 +66,17 @@ class StepView:
     the next observation rows (the state the policy will see: post-reset for the envs the kernel's own terminations finished). [N, ...]
     torch views on the device, no copies."""
 
+    _joint_tables: dict = {}       # (device, joint tables) -> (bias, range) tensors: uploaded once, not twice per control step
+
+    @classmethod
+    def joint_tables(cls, model, device):
+        key = (str(device), tuple(model.joint_bias), tuple(model.joint_lo), tuple(model.joint_hi))
+        if key not in cls._joint_tables:
+            bias = torch.tensor(list(model.joint_bias), device=device)
+            rng = torch.tensor([max(b - lo, hi - b) for b, lo, hi in zip(model.joint_bias, model.joint_lo, model.joint_hi)], device=device)
+            cls._joint_tables[key] = (bias, rng)
+        return cls._joint_tables[key]
+
     def __init__(self, aux_t: torch.Tensor, actor_next: torch.Tensor, critic_next: torch.Tensor, aux_next: torch.Tensor, model):
         A, O = L.AUX, L.OBS
         self.N = aux_t.shape[0]
@@ -83,8 +94,7 @@ class StepView:
         self.done = aux_t[:, A["DONE"]]                         # the kernel's own terminations: -1 failure, +1 episode length
         # ---- the next observation (clean critic pieces, train.py:1381-1433 order; KBJ_OBS_* offsets) ----
         piece = lambda name: critic_next[:, O[name][0]:O[name][0] + O[name][1]]
-        bias = torch.tensor(list(model.joint_bias), device=aux_t.device)
-        rng = torch.tensor([max(b - lo, hi - b) for b, lo, hi in zip(model.joint_bias, model.joint_lo, model.joint_hi)], device=aux_t.device)
+        bias, rng = self.joint_tables(model, aux_t.device)
         self.joint_position = piece("JPOS") * rng + bias         # qpos[7:]
         self.joint_velocity = piece("JVEL") * L.OBS_JVEL_DIV     # qvel[6:]
         self.projected_gravity = critic_next[:, O["PG"][0] + 2:O["PG"][0] + 5]

@@ -88,5 +88,24 @@ def test_cosine_decay_schedule():
     assert abs(cosine_decay_lr(c, 500) - 5e-4 * (0.99 * 0.5 + 0.01)) < 1e-12
     assert abs(cosine_decay_lr(c, 1000) - 5e-6) < 1e-12 and abs(cosine_decay_lr(c, 5000) - 5e-6) < 1e-12
     c.to_kbj(4096)                                               # adamw + schedule (train.py:1076-1077)
-    z = launch_config(use_lr_decay=True, adam_weight_decay=0.0).to_kbj(4096)   # scale_by_adam + scale_by_schedule (train.py:1074-1075): served too
+    z = launch_config(use_lr_decay=True, adam_weight_decay=0.0, reproduce_reference_lr_sign=True).to_kbj(4096)   # scale_by_adam + scale_by_schedule (train.py:1074-1075): served behind the opt-in
     assert z.weight_decay == 0.0
+
+
+def test_check_config_refuses_operands_of_two_gib():
+    """The GEMM / recurrence tiles are fetched with 32-bit byte offsets (kbj_gemm.h load_tile, kbj_lstm_seq.h SeqTile::load): a stash
+    array of >= 2 GiB would be read as zeros beyond the limit. The guard's arithmetic, on the host: T x B x max(4 H, 476) x 4 bytes and
+    N x max(4 H, 476) x 4 bytes must stay below 2^31."""
+    from kbot_joystick_amd.host import binding
+    ok = lambda **kw: binding.check_config(L.default_config(**kw))
+    assert ok(num_envs=8192, batch_size=512, rollout_len=100, hidden_size=256) == ""
+    assert ok(num_envs=65536, batch_size=512, rollout_len=100, hidden_size=256) == ""
+    # 1024 x 512 x 1024 floats = 2^31 bytes exactly: refused; one step shorter: served
+    assert "2 GiB" in ok(num_envs=8192, batch_size=512, rollout_len=1024, hidden_size=256)
+    assert ok(num_envs=8192, batch_size=512, rollout_len=1023, hidden_size=256) == ""
+    # hidden 64: the 476-float critic rows are the wider operand (T x B x 476 x 4)
+    assert "2 GiB" in ok(num_envs=8192, batch_size=4096, rollout_len=276, hidden_size=64)
+    assert ok(num_envs=8192, batch_size=4096, rollout_len=275, hidden_size=64) == ""
+    # one control step's rows: N x 1024 x 4 bytes
+    assert "num_envs" in ok(num_envs=524288, batch_size=512, rollout_len=10, hidden_size=256)
+    assert "hidden_size" in ok(num_envs=64, batch_size=64, hidden_size=320)

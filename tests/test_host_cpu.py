@@ -126,6 +126,42 @@ def test_upstream_style_checkpoint_without_kbj_members(tmp_path):
     assert ckpt.load_ckpt(path)["opt_state"] is None and np.array_equal(ckpt.load_ckpt(path, "model"), p)
 
 
+def test_schedule_count_leaf_and_episode_length_rounding(tmp_path):
+    """With use_lr_decay optax's state tree is (count, mu.., nu.., count) in either branch of train.py:1067-1077: the writer emits the
+    trailing ScaleByScheduleState leaf so that the reference can restore its optimizer from the file, and the reader maps it back.
+    `max_length_sec` rounds like T and substeps do (2.3 s / 0.02 s is 115 control steps, not 114)."""
+    import tarfile
+    from kbot_joystick_amd.host import ckpt
+    from kbot_joystick_amd.host.task import launch_config
+    H, depth = 64, 2
+    pa, pc = L.param_count(H, depth)
+    nleaf = len(L.param_leaves(H, depth))
+    p = np.arange(pa + pc, dtype=np.float32)
+    path = str(tmp_path / "ckpt.bin")
+    for sched, want in ((None, 1 + 2 * nleaf), (17, 2 + 2 * nleaf)):
+        ckpt.save_ckpt(path, p, p, p, 17, H, depth, dict(num_steps=1, opt_step=17), dict(hidden_size=H, depth=depth), schedule_count=sched)
+        with tarfile.open(path, "r:gz") as tar:
+            blobs = ckpt._read_blobs(tar.extractfile("opt_state_0").read())
+        assert len(blobs) == want
+        if sched is not None:
+            assert blobs[-1].dtype == np.int32 and int(blobs[-1]) == 17
+        z = ckpt.load_ckpt(path, "opt_state")
+        assert z["count"] == 17 and z["counts"] == ([17] if sched is None else [17, 17]) and np.array_equal(z["mu"], p)
+    assert ckpt.has_member(path, "opt_state_0") and not ckpt.has_member(path, "kbj_es")
+    k = launch_config(termination_params={"episode_length": {"max_length_sec": 2.3}}).to_kbj(4096)
+    assert k.max_episode_steps == 115
+
+
+def test_lr_decay_without_weight_decay_needs_an_explicit_opt_in():
+    """train.py:1074-1075 as written (scale_by_adam chained with scale_by_schedule, no sign flip) is gradient ASCENT: flipping one
+    documented flag must not silently produce a diverging run."""
+    from kbot_joystick_amd.host.task import launch_config
+    with pytest.raises(ValueError, match="reproduce_reference_lr_sign"):
+        launch_config(use_lr_decay=True, adam_weight_decay=0.0).to_kbj(4096)
+    launch_config(use_lr_decay=True, adam_weight_decay=0.0, reproduce_reference_lr_sign=True).to_kbj(4096)
+    launch_config(use_lr_decay=True).to_kbj(4096)                         # the adamw branch (train.py:1076-1077) descends
+
+
 def test_checkpoint_write_is_atomic(tmp_path, monkeypatch):
     """save_ckpt writes ckpt.bin.tmp, fsyncs and renames: a crash in the middle of a save leaves the previous checkpoint intact."""
     from kbot_joystick_amd.host import ckpt

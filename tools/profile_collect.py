@@ -63,7 +63,13 @@ def main():
             cyc = v["SQ_BUSY_CYCLES"] / 32
             d["derived"] = dict(kernel_cycles=cyc, valu_instructions_per_env_step=v.get("SQ_INSTS_VALU", 0) / n, lds_instructions_per_env_step=v.get("SQ_INSTS_LDS", 0) / n,
                                 vmem_reads_per_env_step=v.get("SQ_INSTS_VMEM_RD", 0) / n, vmem_writes_per_env_step=v.get("SQ_INSTS_VMEM_WR", 0) / n,
-                                valu_pipe_utilisation=(v.get("SQ_INSTS_VALU", 0) * 2) / (1024 * cyc),
+                                # issue cost of a wave64 vector instruction on a 16-lane SIMD: 4 cycles (v_add / v_fma ...), 8 for transcendentals
+                                # (MI355X_MICROARCH.md, cycle constants; round 3 priced it at 2 and called an 85 %-busy kernel "42 % busy")
+                                valu_issue_utilisation=((v.get("SQ_INSTS_VALU", 0) - v.get("SQ_INSTS_VALU_TRANS_F32", 0)) * 4 + v.get("SQ_INSTS_VALU_TRANS_F32", 0) * 8) / (1024 * cyc),
+                                # independent check: SQ_ACTIVE_INST_VALU counts quad-cycles in which a wave had a vector instruction executing
+                                valu_active_utilisation=v.get("SQ_ACTIVE_INST_VALU", 0) * 4 / (1024 * cyc),
+                                fp32_arith_share_of_valu=(v.get("SQ_INSTS_VALU_ADD_F32", 0) + v.get("SQ_INSTS_VALU_MUL_F32", 0) + v.get("SQ_INSTS_VALU_FMA_F32", 0)) / max(v.get("SQ_INSTS_VALU", 1), 1),
+                                mean_active_lanes_per_valu=v.get("SQ_THREAD_CYCLES_VALU", 0) / max(v.get("SQ_INSTS_VALU", 1), 1) if v.get("SQ_THREAD_CYCLES_VALU") else None,
                                 wave_cycles_per_env_step=4 * v.get("SQ_WAVE_CYCLES", 0) / n, waiting_fraction=v.get("SQ_WAIT_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 1), 1),
                                 issue_stall_fraction=v.get("SQ_WAIT_INST_ANY", 0) / max(v.get("SQ_WAVE_CYCLES", 1), 1),
                                 lds_bank_conflict_fraction=v.get("SQ_LDS_BANK_CONFLICT", 0) / max(v.get("SQ_LDS_IDX_ACTIVE", 1), 1),
