@@ -17,6 +17,7 @@ __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restri
   const int env = blockIdx.x;
   PFOR(k, (int)(sizeof(KbjModelLds) / sizeof(float))) reinterpret_cast<float*>(&S.mc)[k] = mc[k];
   PFOR(k, KBJ_ES_SIZE) S.es[k] = 0;
+  PFOR(k, 12) S.zrow[k] = 0;
   KBJ_SYNC();
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
   PhysConst pc = phys_const(*c, *m);
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(64) void env_reset_where_kernel(const kbj_model* __
   PFOR(k, (int)(sizeof(KbjModelLds) / sizeof(float))) reinterpret_cast<float*>(&S.mc)[k] = mc[k];
   PFOR(k, KBJ_EP_SIZE) S.ep[k] = ep[(size_t)env * KBJ_EP_SIZE + k];
   PFOR(k, KBJ_ES_SIZE) S.es[k] = es[(size_t)env * KBJ_ES_SIZE + k];
+  PFOR(k, 12) S.zrow[k] = 0;
   KBJ_SYNC();
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
   PhysConst pc = phys_const(*c, *m);
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR
   PFOR(k, (int)(sizeof(KbjModelLds) / sizeof(float))) reinterpret_cast<float*>(&S.mc)[k] = mc[k];
   PFOR(k, KBJ_EP_SIZE) S.ep[k] = ep[(size_t)env * KBJ_EP_SIZE + k];
   PFOR(k, KBJ_ES_SIZE) S.es[k] = es[(size_t)env * KBJ_ES_SIZE + k];
+  PFOR(k, 12) S.zrow[k] = 0;
   KBJ_SYNC();
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
   PhysConst pc = phys_const(*c, *m);

@@ -88,7 +88,7 @@ struct KbjShared {
     struct { float crb[NB][10]; };
     struct { float cfrc[NB][6], cfrc_acc[NB][6]; };
     struct { float jp[NCON][11][3]; };   // contact-frame point Jacobians (normal, tangent 1, tangent 2) while the constraint rows are built
-#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)
+#if defined(KBJ_ARROW_LDS)
     struct {
       float A[4][12][12];  // chain-local blocks [ankle..hip | base 6], row 11 = right-hand side
       float B[7][8];       // base block, row 6 = right-hand side
@@ -97,8 +97,9 @@ struct KbjShared {
   } u;
   float Mb[6][6];       // mass matrix, base block
   float Mc[4][5][11];   // limb c, dof a (hip..ankle): columns 0..5 base dofs, 6..10 the limb's own dofs
+  float zrow[12];       // zeros (directly behind Mc: the solver's per-lane offset table points here for the entries a lane does not have)
   float qfrc_act[NV], qfrc_smooth[NV], qacc[NV];
-#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)   // the LDS formulation of the solver keeps its vectors here; the product kernel keeps them in registers
+#if defined(KBJ_ARROW_LDS)   // the LDS formulation of the solver keeps its vectors here; the product kernel keeps them in registers
   float qacc_smooth[NV], Ma[NV], grad[NV], search[NV], mv[NV], vec[NV];
   float jar[NROW], jv[NROW];
 #endif

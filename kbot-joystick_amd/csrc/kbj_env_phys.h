@@ -11,6 +11,8 @@
 // complements are summed into the 6x6 base block, and the right-hand side rides along as an extra row.
 #pragma once
 #include "kbj_env_core.h"
+#include "kbj_wave.h"
+#include <cstddef>
 #include <type_traits>
 
 // diagnostics (tools/env_stamps.py, -DKBJ_ENV_STAMPS): shader-clock cycles of env 0 per phase, accumulated in a device array
@@ -356,7 +358,7 @@ KBJ_DEV int tri_count(int p) { return 65 - p * (23 - p) / 2; }  // entries with 
 #define KBJ_RCP(x) __frcp_rn(x)
 #endif
 
-#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)
+#if defined(KBJ_ARROW_LDS)
 // LDS formulation (host emulation / A-B builds): one phase per pivot over the block entries spread across the lanes
 KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
   PFOR(w, 4 * 77) {
@@ -433,98 +435,9 @@ KBJ_DEV void arrow_solve(KbjShared& S, const float* rhs, bool hess) {
   }
   KBJ_SYNC();
 }
-#else
-// Register formulation (the product kernel). Lane 16 c + r of DPP row c holds ROW r of chain c's augmented block in registers
-// a[0..10] (r = 0..4 chain dofs ankle..hip, 5..10 base dofs, 11 right-hand side; lanes 12..15 shadow row 11 and are never read).
-// A pivot is pure VALU: `row_newbcast` hands lane j's entry of the pivot column to the whole row, so a[j] -= l_p * A[j][p] is one
-// DPP move + one FMA, with no LDS traffic and no phase boundary. The four Schur complements are summed across the rows
-// (xor-16 / xor-32 exchanges), every row then factors the 6 x 6 base block redundantly, and both back-substitutions are
-// 16-lane DPP row sums. ~0.35k instructions per solve instead of 16 LDS phases.
-template <int I, int N, class F> KBJ_DEV void static_for(F&& f) {
-  if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-template <int J> KBJ_DEV float row_bcast(float v) {   // value of lane J of each 16-lane row, in every lane of that row
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x150 + J, 0xF, 0xF, true));
-}
-KBJ_DEV float row_sum16(float v) {  // sum over the 16 lanes of each DPP row, in every lane of the row
-  v = dpp_add<0xB1>(v); v = dpp_add<0x4E>(v); v = dpp_add<0x141>(v); v = dpp_add<0x140>(v);
-  return v;
-}
-KBJ_DEV float rows_sum4(float v) {  // sum over the four rows (same lane-in-row), in every row: (r0 + r1) + (r2 + r3)
-#ifdef KBJ_ROWS_SUM_LDS   // LDS-crossbar form (A/B)
-  v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));                       // lane ^ 16
-  v += __int_as_float(__builtin_amdgcn_ds_bpermute((KBJ_LANE ^ 32) << 2, __float_as_int(v)));      // lane ^ 32
-#else                     // gfx950 lane swaps, VALU only: swap odd rows of one copy with even rows of the other, then the 32-lane halves
-  auto p = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(p[0]) + __uint_as_float(p[1]);
-  auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-  v = __uint_as_float(q[0]) + __uint_as_float(q[1]);
-#endif
-  return v;
-}
-
-// Solves G x = g with G = M (+ J^T D J of the rows in their quadratic zone when HESS). Everything is in the SOLVER LAYOUT of the
-// wavefront: lane 16 c + r holds, for r = 0..4, chain dof 10 + 5 c - r (ankle .. hip of limb c) and, for r = 5..10, base dof r - 5
-// (replicated in the four DPP rows); m[0..10] is that dof's row of M against (its chain's dofs ankle..hip | the six base dofs).
-// g comes in and x goes out in that layout: a solve touches no memory at all.
-template <bool HESS> KBJ_DEV float arrow_solve_reg(const float (&m)[11], const float (&h)[11], float g, float diag_add, int r) {
-  float bc[11];
-  static_for<0, 11>([&](auto Jc_) { constexpr int j = decltype(Jc_)::value; bc[j] = row_bcast<j>(g); });
-  float a[11];
-#pragma unroll
-  for (int j = 0; j < 5; ++j) a[j] = r < 11 ? m[j] : bc[j];   // rows 0..10: M; row 11 (and its shadows 12..15): the right-hand side
-#pragma unroll
-  for (int j = 5; j < 11; ++j) a[j] = 0.0f;
-  if (HESS) {   // h: this row of J^T D J over the leg's pyramid rows in their quadratic zone (kept up to date by the caller)
-#pragma unroll
-    for (int j = 0; j < 11; ++j) a[j] += r < 11 ? h[j] : 0.0f;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) a[j] += r == j ? diag_add : 0.0f;   // friction-loss / joint-limit rows are unit vectors: diagonal only
-  }
-  // eliminate the five chain dofs; column p keeps its unscaled entries (L_ip D_p)
-  float inv[5];
-  static_for<0, 5>([&](auto P) {
-    constexpr int p = decltype(P)::value;
-    inv[p] = KBJ_RCP(row_bcast<p>(a[p]));
-    const float lp = -a[p] * inv[p];
-    static_for<p + 1, 11>([&](auto Jc_) {
-      constexpr int j = decltype(Jc_)::value;
-      a[j] = fmaf(lp, row_bcast<j>(a[p]), a[j]);
-    });
-  });
-  // base block: M_base + the four Schur complements (rows 5..10) and the reduced right-hand side (row 11), identical in every DPP row
-  float b[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) b[j] = rows_sum4(a[5 + j]) + (r < 11 ? m[5 + j] : bc[5 + j]);
-  float binv[6];
-  static_for<0, 6>([&](auto Q) {
-    constexpr int q = decltype(Q)::value;
-    binv[q] = KBJ_RCP(row_bcast<5 + q>(b[q]));
-    const float lp = -b[q] * binv[q];
-    static_for<q + 1, 6>([&](auto Jc_) {
-      constexpr int j = decltype(Jc_)::value;
-      b[j] = fmaf(lp, row_bcast<5 + j>(b[q]), b[j]);
-    });
-  });
-  // back-substitution: xm = this row's unknown once solved (-1 on the right-hand-side row, so a row sum gives rhs - sum of products)
-  float xm = r == 11 ? -1.0f : 0.0f;
-  static_for<0, 6>([&](auto K) {
-    constexpr int p = 5 - decltype(K)::value;
-    const float prod = (r > 5 + p && r <= 11) ? b[p] * xm : 0.0f;
-    const float xp = -row_sum16(prod) * binv[p];
-    xm = r == 5 + p ? xp : xm;
-  });
-  static_for<0, 5>([&](auto K) {
-    constexpr int p = 4 - decltype(K)::value;
-    const float prod = (r > p && r <= 11) ? a[p] * xm : 0.0f;
-    const float xp = -row_sum16(prod) * inv[p];
-    xm = r == p ? xp : xm;
-  });
-  return xm;   // lanes r <= 10: the solution for this lane's dof
-}
 #endif
 
-#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)
+#if defined(KBJ_ARROW_LDS)
 // y = M v using the tree sparsity
 KBJ_DEV float mul_M_row(const KbjShared& S, int i, const float* v) {
   float s = 0;
@@ -622,7 +535,7 @@ KBJ_DEV void phys_make_constraints(KbjShared& S, const KbjModelLds& m, const Phy
   KBJ_SYNC();
 }
 
-#if defined(KBJ_EMU) || defined(KBJ_ARROW_LDS)   // ---- LDS formulation of the solver (host emulation / A-B builds) ----
+#if defined(KBJ_ARROW_LDS)   // ---- LDS formulation of the solver (A/B builds on the GPU and in the host emulation) ----
 // J q for row r (r active)
 KBJ_DEV float row_dot(const KbjShared& S, int r, const float* q) {
   if (r < ROW_LIM) return q[6 + r];
@@ -776,189 +689,294 @@ KBJ_DEV void phys_solve(KbjShared& S, const KbjModelLds& m, const PhysConst& pc)
   S.iters = iters;
 }
 #else
-// Newton iterations on the convex constraint cost with an exact (safeguarded Newton) line search - register-resident form.
-// The whole solve lives in the solver layout of arrow_solve_reg: a lane keeps its dof's scalars (qfrc_smooth, qacc_smooth, qacc,
-// M qacc, search, M search), its dof's row of M, the friction-loss and limit rows of its joint (unit-vector rows: same lane as
-// the dof) and ONE pyramid row of its leg (contact row 16 c + r of leg c sits in lane 16 c + r, so J^T f of a leg is a 16-lane DPP
-// row sum inside the DPP row that also holds the leg's dofs). Matrix-vector products broadcast the vector along the DPP row
-// (row_newbcast) and sum the base part over the four rows with gfx950 lane swaps. LDS is touched for the initial loads, for the
-// Hessian's contact rows (quad flags out, Jc rows in) and for the results (qacc, contact forces).
-KBJ_DEV void phys_solve(KbjShared& S, const KbjModelLds& mdl, const PhysConst& pc) {
-  const int lane = KBJ_LANE, c = lane >> 4, r = lane & 15;
-  const bool is_chain = r < 5, is_base = r >= 5 && r <= 10;
-  const bool own = is_chain || (is_base && c == 0);   // every dof exactly once in the wave sums (base dofs are replicated per row)
-  const bool is_con = lane < 32;                        // lanes 0..31 = the 2 x 16 pyramid rows
-  const int d = is_chain ? 10 + 5 * c - r : (is_base ? r - 5 : 0);
-  const int u = is_chain ? d - 6 : 0;
-  // ---- this lane's row of M: columns 0..4 = its chain's dofs (ankle..hip), 5..10 = base dofs ----
-  float m[11];
-  {
-    const int rc = r <= 10 ? r : 10;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      const int rowi = rc < 5 ? 4 - (rc < j ? rc : j) : 4 - j, coli = rc < 5 ? 10 - (rc > j ? rc : j) : rc - 5;
-      m[j] = S.Mc[c][rowi][coli];
-    }
-#pragma unroll
-    for (int j = 5; j < 11; ++j) {
-      const int bj = j - 5, br = rc - 5;
-      const float* p = rc < 5 ? &S.Mc[c][4 - rc][bj] : &S.Mb[br > bj ? br : bj][br < bj ? br : bj];
-      m[j] = *p;
-    }
-  }
-  const float qs = S.qfrc_smooth[d];
-  const float warm = S.es[KBJ_ES_WARM + d];
-  // friction-loss + limit row of this lane's joint (chain lanes), one pyramid row (lanes 0..31); inactive rows have D = 0
-  float Df = 0, thr = 0, fl = 0, aref_f = 0, Dl = 0, aref_l = 0, ls = 0;
-  if (is_chain) {
-    Df = S.D[u]; fl = S.floss[u]; thr = S.Rf[u] * fl; aref_f = S.aref[u];
-    Dl = S.D[ROW_LIM + u]; aref_l = S.aref[ROW_LIM + u]; ls = S.lsign[u];
-  }
-  float Dc = 0, aref_c = 0, jc[11];
-#pragma unroll
-  for (int k = 0; k < 11; ++k) jc[k] = is_con ? S.Jc[lane & 31][k] : 0.0f;
-  if (is_con) { Dc = S.D[ROW_CON + lane]; aref_c = S.aref[ROW_CON + lane]; }
+// ---- register-resident Newton solver (the product kernel; the host emulation runs the same source lane by lane, kbj_wave.h) ----
+//
+// SOLVER LAYOUT of the wavefront: lane 16 c + r of DPP row c (= limb c: two legs, two arms).
+//   r = 0..4   chain dof 10 + 5 c - r (ankle .. hip of limb c), together with the friction-loss and limit rows of that joint (unit rows)
+//   r = 5..10  base dof r - 5, replicated in the four rows; its base-base part of M lives in row 0 only (the rows are summed)
+//   r = 11     idle (a zero row)
+//   r = 12..15 the right-hand side of an arrow solve (DPP bank 3, so ONE bank-masked `row_newbcast` move per column writes it)
+//   lanes 0..31 additionally own pyramid row `lane` (row 16 c + k of leg c sits in DPP row c, where the leg's dofs are)
+// A lane keeps: its row of M against (its chain's dofs ankle..hip | the six base dofs) m[11]; the same row of the contact part of the
+// Hessian h[11] (kept incrementally; bank 3 carries the right-hand side); its pyramid row jc[11] and - transposed - column `col(r)` of its
+// leg's sixteen pyramid rows jt[16]; the scalars of its dof and rows. Matrix-vector products are `v_fmac_f32_dpp` chains: M v and J v
+// broadcast v along the DPP row, J^T f broadcasts f (16 instructions instead of eleven 16-lane reductions). Instruction counts matter
+// here: the kernel is bound by vector issue.
 
-  auto bcast11 = [&](float v, float (&vj)[11]) { static_for<0, 11>([&](auto J_) { constexpr int j = decltype(J_)::value; vj[j] = row_bcast<j>(v); }); };
-  auto mul_M = [&](const float (&vj)[11]) {   // (M v) for this lane's dof
-    float p1 = 0, p2 = 0;
+// byte offsets (from S.Mb) of the eleven entries of a lane's row of M; entries a lane does not have point at S.zrow
+struct MRowTab { unsigned short off[11][64]; };
+constexpr MRowTab make_mrow_tab() {
+  MRowTab t{};
+  for (int lane = 0; lane < 64; ++lane) {
+    const int c = lane >> 4, r = lane & 15;
+    for (int j = 0; j < 11; ++j) {
+      int idx = 36 + 220;   // zrow[0], in floats from Mb[0][0]
+      if (r < 5) idx = j < 5 ? 36 + (c * 5 + (4 - (r < j ? r : j))) * 11 + (10 - (r > j ? r : j)) : 36 + (c * 5 + (4 - r)) * 11 + (j - 5);
+      else if (r <= 10) {
+        const int br = r - 5, bj = j - 5;
+        if (j < 5) idx = 36 + (c * 5 + (4 - j)) * 11 + br;
+        else if (c == 0) idx = (br > bj ? br : bj) * 6 + (br < bj ? br : bj);
+      }
+      t.off[j][lane] = (unsigned short)(4 * idx);
+    }
+  }
+  return t;
+}
+#ifdef KBJ_EMU
+static const MRowTab MROW = make_mrow_tab();
+#else
+__device__ const MRowTab MROW = make_mrow_tab();
+#endif
+static_assert(offsetof(KbjShared, Mc) - offsetof(KbjShared, Mb) == 36 * 4 && offsetof(KbjShared, zrow) - offsetof(KbjShared, Mb) == (36 + 220) * 4,
+              "MRowTab addresses Mb, Mc and zrow as one array");
+
+KBJ_DEV float kbj_fdiv(float a, float b) {   // a / b: hardware reciprocal + one Newton step on the quotient (wave-uniform scalars of the line search)
+#ifdef KBJ_EMU
+  return a / b;
+#else
+  const float r = __builtin_amdgcn_rcpf(b), q = a * r;
+  return fmaf(fmaf(-q, b, a), r, q);
+#endif
+}
+
+// Solves G x = g, G = M + (contact part of the Hessian in h) + (dnow on the diagonal of the chain dofs), in the solver layout: g comes
+// in and x goes out as one value per lane (lanes r <= 10), nothing touches memory. Arrow-matrix LDL^T: every DPP row eliminates its
+// chain's five dofs from its augmented block (rows = lanes), the four Schur complements are summed over the rows with lane swaps, every
+// row factors the 6 x 6 base block redundantly. A pivot column is stored as the NEGATED multipliers -L_ip, so both back-substitutions
+// are plain row sums of (multiplier x known unknowns) with the right-hand-side lane holding -1.
+KBJ_DEV WF arrow_solve_w(const WF (&m)[11], const WF (&h)[11], const WF (&oh)[5], const WF& dnow, const WF& g) {
+  WF a[11];
+  WLANES(l) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) p1 = fmaf(m[j], vj[j], p1);
+    for (int j = 0; j < 5; ++j) WL(a[j], l) = fmaf(WL(oh[j], l), WL(dnow, l), WL(m[j], l) + WL(h[j], l));
 #pragma unroll
-    for (int j = 5; j < 11; ++j) p2 = fmaf(m[j], vj[j], p2);
-    const float t = rows_sum4(p1);            // base dofs couple to every chain: sum the chain parts over the four rows
-    return (is_base ? t : p1) + p2;
+    for (int j = 5; j < 11; ++j) WL(a[j], l) = WL(m[j], l) + WL(h[j], l);
+  }
+  // right-hand side into bank 3 (m, h and oh are zero there); its base part in DPP row 0 only: the four rows are summed
+  static_for<0, 5>([&](auto J_) { constexpr int j = decltype(J_)::value; wset_rhs<j, 0xF>(a[j], g); });
+  static_for<5, 11>([&](auto J_) { constexpr int j = decltype(J_)::value; wset_rhs<j, 0x1>(a[j], g); });
+  static_for<0, 5>([&](auto P_) {
+    constexpr int p = decltype(P_)::value;
+    const WF lp = wneg_div_bcast<p>(a[p]);
+    static_for<p + 1, 11>([&](auto J_) { constexpr int j = decltype(J_)::value; wfmac_bcast<j>(a[j], a[p], lp); });
+    a[p] = lp;
+  });
+  wrows_sum2(a[5], a[6]); wrows_sum2(a[7], a[8]); wrows_sum2(a[9], a[10]);
+  static_for<0, 6>([&](auto Q_) {
+    constexpr int q = decltype(Q_)::value;
+    const WF lp = wneg_div_bcast<5 + q>(a[5 + q]);
+    static_for<q + 1, 6>([&](auto J_) { constexpr int j = decltype(J_)::value; wfmac_bcast<5 + j>(a[5 + j], a[5 + q], lp); });
+    a[5 + q] = lp;
+  });
+  WF xm;
+  WLANES(l) WL(xm, l) = (l & 15) == 12 ? -1.0f : 0.0f;
+  static_for<0, 11>([&](auto K_) {
+    constexpr int p = 10 - decltype(K_)::value;   // lane (= block row) whose unknown this step produces: base dofs 10..5, then hip..ankle 4..0
+    WF prod;
+    WLANES(l) WL(prod, l) = WL(a[p], l) * WL(xm, l);
+    wopaque(prod);
+    xm = wsel<wmask_r(p)>(wrow_sum16(prod), xm);
+  });
+  return xm;
+}
+
+KBJ_DEV void phys_solve(KbjShared& S, const KbjModelLds& mdl, const PhysConst& pc) {
+  constexpr unsigned long long CHAIN = wmask_r_below(5), BASE = wmask_r_below(11) & ~CHAIN, OWN = CHAIN | (BASE & 0xFFFFull);
+  WF m[11], h[11], jc[11], jt[16], oh[5];
+  WF qs, warm, Df, fl, thr, aref_f, actf, Dl, aref_l, lsa, Dc, aref_c;
+  WLANES(l) {
+    const int c = l >> 4, r = l & 15;
+    const bool is_chain = r < 5;
+    const int d = is_chain ? 10 + 5 * c - r : (r <= 10 ? r - 5 : 0), u = is_chain ? d - 6 : 0;
+    const char* mb = reinterpret_cast<const char*>(&S.Mb[0][0]);
+#pragma unroll
+    for (int j = 0; j < 11; ++j) { WL(m[j], l) = *reinterpret_cast<const float*>(mb + MROW.off[j][l]); WL(h[j], l) = 0.0f; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) WL(oh[j], l) = r == j ? 1.0f : 0.0f;
+    WL(qs, l) = S.qfrc_smooth[d]; WL(warm, l) = S.es[KBJ_ES_WARM + d];
+    // friction-loss and limit row of this lane's joint; rows that do not exist (or are inactive: D = 0) carry zeros throughout
+    const float D_f = is_chain ? S.D[u] : 0.0f, D_l = is_chain ? S.D[ROW_LIM + u] : 0.0f, f_l = is_chain ? S.floss[u] : 0.0f;
+    WL(Df, l) = D_f; WL(fl, l) = f_l; WL(thr, l) = is_chain ? S.Rf[u] * f_l : 0.0f;
+    WL(actf, l) = D_f != 0 ? 1.0f : 0.0f; WL(aref_f, l) = D_f != 0 ? S.aref[u] : 0.0f;
+    WL(Dl, l) = D_l; WL(lsa, l) = D_l != 0 ? S.lsign[u] : 0.0f; WL(aref_l, l) = D_l != 0 ? S.aref[ROW_LIM + u] : 0.0f;
+    // pyramid row `lane` (lanes 0..31; an inactive contact's row is all zeros, aref and D included) and, transposed, column col(r) of
+    // the sixteen rows of leg c. The arms' rows (c = 2, 3) read leg c & 1: finite values that only ever meet a zero force.
+    const float* jrow = l < 32 ? S.Jc[l] : S.zrow;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) WL(jc[k], l) = jrow[k];
+    WL(Dc, l) = l < 32 ? S.D[ROW_CON + (l & 31)] : 0.0f; WL(aref_c, l) = l < 32 ? S.aref[ROW_CON + (l & 31)] : 0.0f;
+    const int colr = r < 5 ? 10 - r : (r <= 10 ? r - 5 : 0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) WL(jt[k], l) = S.Jc[16 * (c & 1) + k][colr];
+  }
+  auto mul_M = [&](const WF& v) {       // (M v) of this lane's dof: v broadcast along the DPP row, the base dofs summed over the four limbs
+    WF q = wmul_bcast<0>(v, m[0]);
+    static_for<1, 11>([&](auto J_) { constexpr int j = decltype(J_)::value; wfmac_bcast<j>(q, v, m[j]); });
+    return wsel<BASE>(wrows_sum1(q), q);
   };
-  auto jdot = [&](const float (&vj)[11]) {    // pyramid row . v  (Jc columns: 0..5 base, 6..10 the leg's dofs hip..ankle)
-    float x = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) x = fmaf(jc[k], vj[5 + k], x);
-#pragma unroll
-    for (int a = 0; a < 5; ++a) x = fmaf(jc[6 + a], vj[4 - a], x);
+  auto jdot = [&](const WF& v) {        // pyramid row . v  (Jc columns: 0..5 base dofs = lanes 5..10, 6..10 hip..ankle = lanes 4..0)
+    WF x = wmul_bcast<5>(v, jc[0]);
+    static_for<1, 6>([&](auto K_) { constexpr int k = decltype(K_)::value; wfmac_bcast<5 + k>(x, v, jc[k]); });
+    static_for<0, 5>([&](auto A_) { constexpr int a = decltype(A_)::value; wfmac_bcast<4 - a>(x, v, jc[6 + a]); });
     return x;
   };
-  auto cost_f = [&](float x) { if (Df == 0) return 0.0f; if (x <= -thr) return fl * (-0.5f * thr - x); if (x >= thr) return fl * (-0.5f * thr + x); return 0.5f * Df * x * x; };
-  auto cost_u = [&](float D, float x) { return (D != 0 && x < 0) ? 0.5f * D * x * x : 0.0f; };
-
   // ---- unconstrained acceleration ----
-  float h[11];
-#pragma unroll
-  for (int j = 0; j < 11; ++j) h[j] = 0.0f;
-  float w_prev = 0.0f;   // weight (D when in the quadratic zone, else 0) with which this lane's pyramid row currently sits in h
-  const float qas = arrow_solve_reg<false>(m, h, qs, 0.0f, r);
+  WF zero;
+  WLANES(l) WL(zero, l) = 0.0f;
+  const WF qas = arrow_solve_w(m, h, oh, zero, qs);
   KBJ_STAMP(7);
-  // ---- warm start: the cheaper of the previous step's acceleration and the unconstrained one ----
-  float vj[11];
-  bcast11(qas, vj);
-  const float Ma_s = mul_M(vj);
-  const float jf_s = Df != 0 ? qas - aref_f : 0.0f, jl_s = Dl != 0 ? ls * qas - aref_l : 0.0f, jc_s = Dc != 0 ? jdot(vj) - aref_c : 0.0f;
-  const float cs = wsum_lanes(cost_f(jf_s) + cost_u(Dl, jl_s) + cost_u(Dc, jc_s));          // the Gauss term vanishes at qacc_smooth
-  bcast11(warm, vj);
-  const float Ma_w = mul_M(vj);
-  const float jf_w = Df != 0 ? warm - aref_f : 0.0f, jl_w = Dl != 0 ? ls * warm - aref_l : 0.0f, jc_w = Dc != 0 ? jdot(vj) - aref_c : 0.0f;
-  const float cw = wsum_lanes((own ? 0.5f * (Ma_w - qs) * (warm - qas) : 0.0f) + cost_f(jf_w) + cost_u(Dl, jl_w) + cost_u(Dc, jc_w));
+  // ---- warm start: the cheaper of the previous step's acceleration and the unconstrained one (both costs on one reduction tree) ----
+  const WF Ma_s = mul_M(qas), Ma_w = mul_M(warm), jd_s = jdot(qas), jd_w = jdot(warm);
+  WF jf_s, jl_s, jc_s, jf_w, jl_w, jc_w, cs_l, cw_l;
+  WLANES(l) {
+    auto cost_f = [&](float x) { const float ax = fabsf(x); return ax >= WL(thr, l) ? WL(fl, l) * (ax - 0.5f * WL(thr, l)) : 0.5f * WL(Df, l) * x * x; };
+    auto cost_u = [&](float D, float x) { const float n = wmin0(x); return 0.5f * D * n * n; };
+    WL(jf_s, l) = fmaf(WL(actf, l), WL(qas, l), -WL(aref_f, l)); WL(jl_s, l) = fmaf(WL(lsa, l), WL(qas, l), -WL(aref_l, l)); WL(jc_s, l) = WL(jd_s, l) - WL(aref_c, l);
+    WL(jf_w, l) = fmaf(WL(actf, l), WL(warm, l), -WL(aref_f, l)); WL(jl_w, l) = fmaf(WL(lsa, l), WL(warm, l), -WL(aref_l, l)); WL(jc_w, l) = WL(jd_w, l) - WL(aref_c, l);
+    WL(cs_l, l) = cost_f(WL(jf_s, l)) + cost_u(WL(Dl, l), WL(jl_s, l)) + cost_u(WL(Dc, l), WL(jc_s, l));          // the Gauss term vanishes at qacc_smooth
+    WL(cw_l, l) = cost_f(WL(jf_w, l)) + cost_u(WL(Dl, l), WL(jl_w, l)) + cost_u(WL(Dc, l), WL(jc_w, l));
+  }
+  {
+    WF gauss;
+    WLANES(l) WL(gauss, l) = 0.5f * (WL(Ma_w, l) - WL(qs, l)) * (WL(warm, l) - WL(qas, l));
+    gauss = wsel0<OWN>(gauss);            // every dof exactly once (the base dofs are replicated per row)
+    WLANES(l) WL(cw_l, l) += WL(gauss, l);
+  }
+  float cs, cw;
+  wsum2(cs_l, cw_l, cs, cw);
   const bool use_warm = cw < cs;
-  float qa = use_warm ? warm : qas, Ma = use_warm ? Ma_w : Ma_s;
-  float jar_f = use_warm ? jf_w : jf_s, jar_l = use_warm ? jl_w : jl_s, jar_c = use_warm ? jc_w : jc_s;
+  WF qa, Ma, jar_f, jar_l, jar_c;
+  WLANES(l) {
+    WL(qa, l) = use_warm ? WL(warm, l) : WL(qas, l); WL(Ma, l) = use_warm ? WL(Ma_w, l) : WL(Ma_s, l);
+    WL(jar_f, l) = use_warm ? WL(jf_w, l) : WL(jf_s, l); WL(jar_l, l) = use_warm ? WL(jl_w, l) : WL(jl_s, l); WL(jar_c, l) = use_warm ? WL(jc_w, l) : WL(jc_s, l);
+  }
   KBJ_STAMP(8);
   const float scale = 1.0f / (mdl.meaninertia * NV);
+  const float tol2 = (pc.tolerance / scale) * (pc.tolerance / scale);   // scale sqrt(gg) < tolerance  <=>  gg < (tolerance / scale)^2
   int iters = 0;
-  float ff = 0, flm = 0, fc = 0;
-  bool qf = false, ql = false, qc = false;
-  auto rows_force_reg = [&]() {
-    ff = 0; qf = false; flm = 0; ql = false; fc = 0; qc = false;
-    if (Df != 0) { if (jar_f <= -thr) ff = fl; else if (jar_f >= thr) ff = -fl; else { ff = -Df * jar_f; qf = true; } }
-    if (Dl != 0 && jar_l < 0) { flm = -Dl * jar_l; ql = true; }
-    if (Dc != 0 && jar_c < 0) { fc = -Dc * jar_c; qc = true; }
+  WF ff, flm, fc, dnow, w_prev;
+  WLANES(l) WL(w_prev, l) = 0.0f;     // weight (D in the quadratic zone, else 0) with which this lane's pyramid row currently sits in h
+  // forces of the rows at the current residuals; dnow = friction-loss + limit rows in their quadratic zone (unit rows: diagonal of H)
+  auto rows_force = [&]() {
+    WLANES(l) {
+      const float t = wclamp(WL(jar_f, l), WL(thr, l));     // Huber: force = -D clamp(residual, +-R f)
+      const bool qf = fabsf(WL(jar_f, l)) < WL(thr, l), ql = WL(jar_l, l) < 0.0f;
+      WL(ff, l) = -WL(Df, l) * t;
+      WL(flm, l) = -WL(Dl, l) * wmin0(WL(jar_l, l));
+      WL(fc, l) = -WL(Dc, l) * wmin0(WL(jar_c, l));
+      WL(dnow, l) = (qf ? WL(Df, l) : 0.0f) + (ql ? WL(Dl, l) : 0.0f);
+    }
   };
   for (int it = 0; it < pc.iterations; ++it) {
-    rows_force_reg();
+    rows_force();
     // contact part of the Hessian, incrementally: only rows whose quadratic-zone flag flipped since the last solve change h (all active
     // rows on the first iteration). The weight changes go through LDS (S.force is free until the solve ends), the changed rows are a
     // ballot mask, so an iteration without flips costs nothing here.
-    const float w_now = qc ? Dc : 0.0f, dw = w_now - w_prev;
-    w_prev = w_now;
-    if (is_con) S.force[ROW_CON + lane] = dw;
-    const unsigned long long chg = __builtin_amdgcn_ballot_w64(is_con && dw != 0.0f);
-    // gradient: M qacc - qfrc_smooth - J^T force
-    float s[11];
-#pragma unroll
-    for (int k = 0; k < 11; ++k) s[k] = row_sum16(jc[k] * fc);     // per leg (DPP row): column k of J^T f
-    float gcon = 0;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) { const float t = rows_sum4(s[k]); gcon = r == 5 + k ? t : gcon; }   // base dofs: both legs
-#pragma unroll
-    for (int a = 0; a < 5; ++a) gcon = r == 4 - a ? s[6 + a] : gcon;                                  // leg dof hip + a sits in lane 4 - a
-    const float gr = Ma - qs - (ff + ls * flm) - gcon;
-    const float gg = wsum_lanes(own ? gr * gr : 0.0f);
+    WF dw;
+    WLANES(l) {
+      const float w_now = WL(jar_c, l) < 0.0f ? WL(Dc, l) : 0.0f;
+      WL(dw, l) = w_now - WL(w_prev, l); WL(w_prev, l) = w_now;
+      if (l < 32) S.force[ROW_CON + l] = WL(dw, l);
+    }
+    const unsigned long long chg = wballot([&](int l) { return l < 32 && WL(dw, l) != 0.0f; });
+    // gradient: M qacc - qfrc_smooth - J^T force; J^T f broadcasts the leg's sixteen forces over the transposed rows
+    WF gcon = wmul_bcast<0>(fc, jt[0]);
+    static_for<1, 16>([&](auto K_) { constexpr int k = decltype(K_)::value; wfmac_bcast<k>(gcon, fc, jt[k]); });
+    gcon = wsel<BASE>(wrows_sum1(gcon), gcon);     // base dofs: both legs
+    WF gr, g2;
+    WLANES(l) {
+      WL(gr, l) = ((WL(Ma, l) - WL(qs, l)) - (WL(ff, l) + WL(lsa, l) * WL(flm, l))) - WL(gcon, l);
+      WL(g2, l) = WL(gr, l) * WL(gr, l);
+    }
+    const float gg = wsum(wsel0<OWN>(g2));
     KBJ_SYNC();
     KBJ_STAMP(9);
-    if (scale * sqrtf(gg) < pc.tolerance) break;
+    if (gg < tol2) break;
     {
       unsigned rows = (unsigned)(chg & 0xFFFFu) | (unsigned)((chg >> 16) & 0xFFFFu);   // row k of either leg changed
-      const int col = r < 5 ? 10 - r : (r <= 10 ? r - 5 : 0);                            // column of Jc this lane's block row stands for
       while (rows) {
         const int k = __builtin_ctz(rows);
         rows &= rows - 1;
-        if (c < 2 && r <= 10) {
-          const int row = 16 * c + k;
-          const float* J = S.Jc[row];
-          const float t = S.force[ROW_CON + row] * J[col];
-          h[0] = fmaf(t, J[10], h[0]); h[1] = fmaf(t, J[9], h[1]); h[2] = fmaf(t, J[8], h[2]); h[3] = fmaf(t, J[7], h[3]); h[4] = fmaf(t, J[6], h[4]);
-          h[5] = fmaf(t, J[0], h[5]); h[6] = fmaf(t, J[1], h[6]); h[7] = fmaf(t, J[2], h[7]); h[8] = fmaf(t, J[3], h[8]); h[9] = fmaf(t, J[4], h[9]);
-          h[10] = fmaf(t, J[5], h[10]);
+        WLANES(l) {
+          const int c = l >> 4, r = l & 15;
+          if (c < 2 && r <= 10) {
+            const int row = 16 * c + k, col = r < 5 ? 10 - r : r - 5;     // column of Jc this lane's block row stands for
+            const float* J = S.Jc[row];
+            const float t = S.force[ROW_CON + row] * J[col];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) WL(h[j], l) = fmaf(t, J[10 - j], WL(h[j], l));
+#pragma unroll
+            for (int j = 5; j < 11; ++j) WL(h[j], l) = fmaf(t, J[j - 5], WL(h[j], l));
+          }
         }
       }
     }
-    const float se = arrow_solve_reg<true>(m, h, -gr, (qf ? Df : 0.0f) + (ql ? Dl : 0.0f), r);
+    WF ngr;
+    WLANES(l) WL(ngr, l) = -WL(gr, l);
+    const WF se = arrow_solve_w(m, h, oh, dnow, ngr);
     KBJ_STAMP(10);
-    bcast11(se, vj);
-    const float mv = mul_M(vj);
-    const float jv_f = Df != 0 ? se : 0.0f, jv_l = Dl != 0 ? ls * se : 0.0f, jv_c = Dc != 0 ? jdot(vj) : 0.0f;
+    const WF mv = mul_M(se), jv_c = jdot(se);
     KBJ_STAMP(11);
-    float g1, g2;
-    {
-      float x1 = own ? se * (Ma - qs) : 0.0f, x2 = own ? se * mv : 0.0f;
-      g1 = wsum_lanes(x1); g2 = wsum_lanes(x2);
+    // exact line search on the piecewise-quadratic cost along se: phi'(a) = g1 + a g2 + sum over rows of D jv x(a) [in the quadratic
+    // zone; the Huber rows saturate at +-f jv], phi''(a) = g2 + sum of D jv^2 over the rows in their quadratic zone
+    WF jv_f, jv_l, Dfjv, Dfjv2, Dljv, Dljv2, Dcjv, Dcjv2, x1, x2;
+    WLANES(l) {
+      WL(jv_f, l) = WL(actf, l) * WL(se, l); WL(jv_l, l) = WL(lsa, l) * WL(se, l);
+      WL(Dfjv, l) = WL(Df, l) * WL(jv_f, l); WL(Dfjv2, l) = WL(Dfjv, l) * WL(jv_f, l);
+      WL(Dljv, l) = WL(Dl, l) * WL(jv_l, l); WL(Dljv2, l) = WL(Dljv, l) * WL(jv_l, l);
+      WL(Dcjv, l) = WL(Dc, l) * WL(jv_c, l); WL(Dcjv2, l) = WL(Dcjv, l) * WL(jv_c, l);
+      WL(x1, l) = WL(se, l) * (WL(Ma, l) - WL(qs, l)); WL(x2, l) = WL(se, l) * WL(mv, l);
     }
+    float g1, g2s;
+    wsum2(wsel0<OWN>(x1), wsel0<OWN>(x2), g1, g2s);
     auto eval = [&](float a, float& d1, float& d2) {
-      float x1 = 0, x2 = 0;
-      if (Df != 0) {
-        const float x = jar_f + a * jv_f;
-        if (x <= -thr) x1 -= fl * jv_f; else if (x >= thr) x1 += fl * jv_f; else { x1 += Df * x * jv_f; x2 += Df * jv_f * jv_f; }
+      WF y1, y2;
+      WLANES(l) {
+        const float xf = fmaf(a, WL(jv_f, l), WL(jar_f, l)), xl = fmaf(a, WL(jv_l, l), WL(jar_l, l)), xc = fmaf(a, WL(jv_c, l), WL(jar_c, l));
+        const float tf = wclamp(xf, WL(thr, l));
+        float s1 = WL(Dfjv, l) * tf, s2 = fabsf(xf) < WL(thr, l) ? WL(Dfjv2, l) : 0.0f;
+        s1 = fmaf(WL(Dljv, l), wmin0(xl), s1); s2 += xl < 0.0f ? WL(Dljv2, l) : 0.0f;
+        s1 = fmaf(WL(Dcjv, l), wmin0(xc), s1); s2 += xc < 0.0f ? WL(Dcjv2, l) : 0.0f;
+        WL(y1, l) = s1; WL(y2, l) = s2;
       }
-      if (Dl != 0) { const float x = jar_l + a * jv_l; if (x < 0) { x1 += Dl * x * jv_l; x2 += Dl * jv_l * jv_l; } }
-      if (Dc != 0) { const float x = jar_c + a * jv_c; if (x < 0) { x1 += Dc * x * jv_c; x2 += Dc * jv_c * jv_c; } }
-      d1 = wsum_lanes(x1) + g1 + a * g2; d2 = wsum_lanes(x2) + g2;
+      float r1, r2;
+      wsum2(y1, y2, r1, r2);
+      d1 = r1 + fmaf(a, g2s, g1); d2 = r2 + g2s;
     };
     float d1, d2, alpha = 0;
     eval(0.0f, d1, d2);
     if (d1 < 0 && d2 > 0) {
       float lo = 0, hi = 0;
       bool hi_valid = false;
-      float a = -d1 / d2;
+      float a = -kbj_fdiv(d1, d2);
       const float d1_stop = 0.01f * fabsf(d1);  // MuJoCo's default ls_tolerance: relative slope reduction
       for (int lsi = 0; lsi < pc.ls_iterations; ++lsi) {
         eval(a, d1, d2);
         if (fabsf(d1) <= d1_stop) break;
         if (d1 < 0) lo = a; else { hi = a; hi_valid = true; }
-        float an = a - d1 / d2;
+        float an = a - kbj_fdiv(d1, d2);
         if (an <= lo || (hi_valid && an >= hi)) an = hi_valid ? 0.5f * (lo + hi) : 2 * a;
         a = an;
       }
       alpha = a;
     }
     KBJ_STAMP(12);
-    qa += alpha * se; Ma += alpha * mv;
-    jar_f += alpha * jv_f; jar_l += alpha * jv_l; jar_c += alpha * jv_c;
+    WLANES(l) {
+      WL(qa, l) = fmaf(alpha, WL(se, l), WL(qa, l)); WL(Ma, l) = fmaf(alpha, WL(mv, l), WL(Ma, l));
+      WL(jar_f, l) = fmaf(alpha, WL(jv_f, l), WL(jar_f, l)); WL(jar_l, l) = fmaf(alpha, WL(jv_l, l), WL(jar_l, l)); WL(jar_c, l) = fmaf(alpha, WL(jv_c, l), WL(jar_c, l));
+    }
     KBJ_STAMP(13);
     iters = it + 1;
     if (alpha == 0) break;
   }
-  rows_force_reg();
-  if (own) S.qacc[d] = qa;
-  if (is_con) S.force[ROW_CON + lane] = fc;
-  if (lane == 0) S.iters = iters;
+  rows_force();
+  WLANES(l) {
+    const int c = l >> 4, r = l & 15;
+    if (r < 5) S.qacc[10 + 5 * c - r] = WL(qa, l);
+    else if (r <= 10 && c == 0) S.qacc[r - 5] = WL(qa, l);
+    if (l < 32) S.force[ROW_CON + l] = WL(fc, l);
+  }
+  PFOR(w, 1) S.iters = iters;
   KBJ_SYNC();
 }
 #endif

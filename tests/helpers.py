@@ -21,17 +21,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOL = dict(qpos=(4e-7, 2e-6, 4e-6, 0.1), qvel=(1.5e-6, 1e-5, 2e-5, 1.0), qacc=(6e-6, 4e-5, 1e-4, 4.0))   # (median, p99, p99.9, max)
 
 
-def emu_lib() -> C.CDLL:
-    """Host emulation build of the kernel body (tests/emu) — test infrastructure."""
-    out = os.path.join(ROOT, "tests", "emu", "_build", "libkbj_emu.so")
+def emu_lib(solver: str = "reg", sanitize: bool = False) -> C.CDLL:
+    """Host emulation build of the kernel body (tests/emu) — test infrastructure. solver = "reg": the product kernel's register-resident
+    Newton solver, its wave primitives (DPP broadcasts, butterflies, lane swaps) emulated lane by lane (kbj_wave.h); "lds": the LDS
+    formulation that `make ldssolver` builds for the GPU A/B test. sanitize: -fsanitize=address,undefined (load it in a child process
+    with libasan preloaded, tests/test_sanitize.py)."""
+    name = "libkbj_emu" + ("" if solver == "reg" else "_lds") + ("_asan" if sanitize else "") + ".so"
+    out = os.path.join(ROOT, "tests", "emu", "_build", name)
     src = os.path.join(ROOT, "tests", "emu", "kbj_env_emu.cpp")
-    deps = [src] + [os.path.join(ROOT, "kbot-joystick_amd", "csrc", f) for f in ("kbj_env_core.h", "kbj_env_phys.h", "kbj_env_task.h")]
+    deps = [src] + [os.path.join(ROOT, "kbot-joystick_amd", "csrc", f) for f in ("kbj_env_core.h", "kbj_env_phys.h", "kbj_env_task.h", "kbj_wave.h")]
     deps.append(os.path.join(ROOT, "include", "kbj_model.h"))
     if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+        flags = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if sanitize else ["-O2"]
+        if solver == "lds":
+            flags.append("-DKBJ_ARROW_LDS")
+        subprocess.check_call(["g++", *flags, "-std=c++17", "-fPIC", "-fopenmp", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
                                "-shared", "-o", out, src])
-    return C.CDLL(out)
+    return C.CDLL(out) if not sanitize else out
 
 
 def fptr(a):
