@@ -106,6 +106,9 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
     kbj::model_lds_fill(mc, ctx->model_h);
     KBJ_TRY(hipMalloc(&ctx->mc_d, sizeof(mc)));
     KBJ_TRY(hipMemcpy(ctx->mc_d, &mc, sizeof(mc), hipMemcpyHostToDevice));
+    const kbj::PhysConst pc = kbj::phys_const(ctx->cfg_h, ctx->model_h);
+    KBJ_TRY(hipMalloc(&ctx->pc_d, sizeof(pc)));
+    KBJ_TRY(hipMemcpy(ctx->pc_d, &pc, sizeof(pc), hipMemcpyHostToDevice));
   }
   KBJ_TRY(hipMalloc(&ctx->ep_d, N * KBJ_EP_SIZE * sizeof(float)));
   KBJ_TRY(hipMalloc(&ctx->es_d, N * KBJ_ES_SIZE * sizeof(float)));
@@ -157,6 +160,7 @@ int kbj_destroy(kbj_ctx* ctx) {
   if (ctx->model_d) hipFree(ctx->model_d);
   if (ctx->cfg_d) hipFree(ctx->cfg_d);
   if (ctx->mc_d) hipFree(ctx->mc_d);
+  if (ctx->pc_d) hipFree(ctx->pc_d);
   if (ctx->ep_d) hipFree(ctx->ep_d);
   if (ctx->es_d) hipFree(ctx->es_d);
   if (ctx->rcarry_d) hipFree(ctx->rcarry_d);

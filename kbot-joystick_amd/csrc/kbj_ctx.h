@@ -28,6 +28,7 @@ struct kbj_ctx {
   kbj_config cfg_h;
   kbj_model* model_d = nullptr;
   kbj_config* cfg_d = nullptr;
+  void* pc_d = nullptr;         // kbj::PhysConst (kbj_env_core.h): solver / impedance / terrain constants derived from the config, computed at create
   float* mc_d = nullptr;        // KbjModelLds image (kbj_env_core.h): the model constants every env workgroup copies into LDS
   float* ep_d = nullptr;        // [N][KBJ_EP_SIZE]
   float* es_d = nullptr;        // [N][KBJ_ES_SIZE]

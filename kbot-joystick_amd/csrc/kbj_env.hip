@@ -11,16 +11,17 @@ namespace {
 
 
 // grid = N workgroups of one wavefront; env state rows are read/written lane-contiguously (coalesced)
-__global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, uint32_t seed,
+__global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, const PhysConst* __restrict__ pcp, uint32_t seed,
                                                        float* __restrict__ ep, float* __restrict__ es, float* actor0, float* critic0, float* aux0) {
   __shared__ KbjShared S;
   const int env = blockIdx.x;
   PFOR(k, (int)(sizeof(KbjModelLds) / sizeof(float))) reinterpret_cast<float*>(&S.mc)[k] = mc[k];
+  PFOR(k, (int)(sizeof(PhysConst) / sizeof(float))) reinterpret_cast<float*>(&S.pc)[k] = reinterpret_cast<const float*>(pcp)[k];
   PFOR(k, KBJ_ES_SIZE) S.es[k] = 0;
   PFOR(k, 12) S.zrow[k] = 0;
   KBJ_SYNC();
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
-  PhysConst pc = phys_const(*c, *m);
+  const PhysConst& pc = S.pc;
   task_reset(S, *m, *c, pc, rng);
   task_write_obs(S, *m, *c, rng, actor0 + (size_t)env * KBJ_LD_ACTOR, critic0 + (size_t)env * KBJ_LD_CRITIC, aux0 + (size_t)env * KBJ_AUX_SIZE);
   PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
@@ -31,19 +32,20 @@ __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restri
 // task_reset / task_write_obs on the env's state row: the episode counter advances, the randomisers, reset distributions and the first
 // command are drawn from the env's streams) and rewrite their next observation rows; other envs are untouched. For terminations decided
 // OUTSIDE the kernel (user-written Termination terms on the host, train.py:817 protocol).
-__global__ __launch_bounds__(64) void env_reset_where_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, uint32_t seed,
+__global__ __launch_bounds__(64) void env_reset_where_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, const PhysConst* __restrict__ pcp, uint32_t seed,
                                                              float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ mask, float* actor_next,
                                                              float* critic_next, float* aux_next) {
   __shared__ KbjShared S;
   const int env = blockIdx.x;
   if (mask[env] == 0.0f) return;     // uniform over the workgroup
   PFOR(k, (int)(sizeof(KbjModelLds) / sizeof(float))) reinterpret_cast<float*>(&S.mc)[k] = mc[k];
+  PFOR(k, (int)(sizeof(PhysConst) / sizeof(float))) reinterpret_cast<float*>(&S.pc)[k] = reinterpret_cast<const float*>(pcp)[k];
   PFOR(k, KBJ_EP_SIZE) S.ep[k] = ep[(size_t)env * KBJ_EP_SIZE + k];
   PFOR(k, KBJ_ES_SIZE) S.es[k] = es[(size_t)env * KBJ_ES_SIZE + k];
   PFOR(k, 12) S.zrow[k] = 0;
   KBJ_SYNC();
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
-  PhysConst pc = phys_const(*c, *m);
+  const PhysConst& pc = S.pc;
   task_reset(S, *m, *c, pc, rng);
   task_write_obs(S, *m, *c, rng, actor_next + (size_t)env * KBJ_LD_ACTOR, critic_next + (size_t)env * KBJ_LD_CRITIC, aux_next + (size_t)env * KBJ_AUX_SIZE);
   PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
@@ -78,18 +80,19 @@ __global__ __launch_bounds__(256) void env_set_command_kernel(int N, float* __re
 #ifndef KBJ_ENV_NUM_VGPR
 #define KBJ_ENV_NUM_VGPR 84
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR))) void env_step_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, uint32_t seed,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR))) void env_step_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, const PhysConst* __restrict__ pcp, uint32_t seed,
                                                       float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ action,
                                                       float* aux_t, float* actor_next, float* critic_next, float* aux_next, int env0) {
   __shared__ KbjShared S;
   const int env = env0 + blockIdx.x;   // a launch covers the env range [env0, env0 + gridDim.x)
   PFOR(k, (int)(sizeof(KbjModelLds) / sizeof(float))) reinterpret_cast<float*>(&S.mc)[k] = mc[k];
+  PFOR(k, (int)(sizeof(PhysConst) / sizeof(float))) reinterpret_cast<float*>(&S.pc)[k] = reinterpret_cast<const float*>(pcp)[k];
   PFOR(k, KBJ_EP_SIZE) S.ep[k] = ep[(size_t)env * KBJ_EP_SIZE + k];
   PFOR(k, KBJ_ES_SIZE) S.es[k] = es[(size_t)env * KBJ_ES_SIZE + k];
   PFOR(k, 12) S.zrow[k] = 0;
   KBJ_SYNC();
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
-  PhysConst pc = phys_const(*c, *m);
+  const PhysConst& pc = S.pc;
   KBJ_STAMP(18);
   task_step(S, *m, *c, pc, rng, action + (size_t)env * KBJ_NU, aux_t + (size_t)env * KBJ_AUX_SIZE, actor_next + (size_t)env * KBJ_LD_ACTOR,
             critic_next + (size_t)env * KBJ_LD_CRITIC, aux_next + (size_t)env * KBJ_AUX_SIZE);
@@ -223,7 +226,7 @@ __global__ void init_reward_carry_kernel(float* carry, int N) {
 int kbj_env_step_range(kbj_ctx* ctx, hipStream_t s, int env0, int count, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d,
                        float* aux_next_d) {
   KbjKernelTimer timer(s, KBJ_KIND_ENV_STEP, 0.0);
-  hipLaunchKernelGGL(env_step_kernel, dim3(count), dim3(64), 0, s, ctx->model_d, ctx->cfg_d, ctx->mc_d, ctx->seed, ctx->ep_d, ctx->es_d, action_d, aux_t_d, actor_next_d,
+  hipLaunchKernelGGL(env_step_kernel, dim3(count), dim3(64), 0, s, ctx->model_d, ctx->cfg_d, ctx->mc_d, (const PhysConst*)ctx->pc_d, ctx->seed, ctx->ep_d, ctx->es_d, action_d, aux_t_d, actor_next_d,
                      critic_next_d, aux_next_d, env0);
   KBJ_CHECK_LAUNCH(ctx, "env_step_kernel");
   return 0;
@@ -239,7 +242,7 @@ int kbj_env_reset_all(kbj_ctx* ctx, uint32_t seed, float* actor0_d, float* criti
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   hipLaunchKernelGGL(init_reward_carry_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, ctx->rcarry_d, N);
   KBJ_CHECK_LAUNCH(ctx, "init_reward_carry_kernel");
-  hipLaunchKernelGGL(env_reset_kernel, dim3(N), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->mc_d, seed, ctx->ep_d, ctx->es_d, actor0_d,
+  hipLaunchKernelGGL(env_reset_kernel, dim3(N), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->mc_d, (const PhysConst*)ctx->pc_d, seed, ctx->ep_d, ctx->es_d, actor0_d,
                      critic0_d, aux0_d);
   KBJ_CHECK_LAUNCH(ctx, "env_reset_kernel");
   return 0;
@@ -255,7 +258,7 @@ int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* act
 int kbj_env_reset_where(kbj_ctx* ctx, const float* mask_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {
   if (!ctx || !mask_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_reset_where: null argument");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
-  hipLaunchKernelGGL(env_reset_where_kernel, dim3(ctx->cfg_h.num_envs), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->mc_d, ctx->seed, ctx->ep_d, ctx->es_d,
+  hipLaunchKernelGGL(env_reset_where_kernel, dim3(ctx->cfg_h.num_envs), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->mc_d, (const PhysConst*)ctx->pc_d, ctx->seed, ctx->ep_d, ctx->es_d,
                      mask_d, actor_next_d, critic_next_d, aux_next_d);
   KBJ_CHECK_LAUNCH(ctx, "env_reset_where_kernel");
   return 0;

@@ -32,6 +32,11 @@
 #define KBJ_SYNC() __syncthreads()
 #endif
 #define PFOR(i, n) for (int i = KBJ_LANE; i < (n); i += KBJ_NLANE)
+#ifdef KBJ_EMU
+#define KBJ_HD static inline
+#else
+#define KBJ_HD __host__ __device__ inline
+#endif
 
 namespace kbj {
 
@@ -71,12 +76,49 @@ static inline void model_lds_fill(KbjModelLds& o, const kbj_model& m) {   // hos
   o.meaninertia = m.meaninertia;
 }
 
+// solref / solimp of one constraint family, reduced ONCE PER CONTEXT (on the host, kbj_create) to what the rows need: stiffness k and damping b of the
+// reference acceleration, and the clamped impedance parameters (MuJoCo's mj_makeImpedance)
+struct ImpConst { float k, b, dmin, dmax, width, mid, power, iwidth, imid, i1mid; };   // + reciprocals of width, mid, 1 - mid (once per launch)
+KBJ_HD ImpConst imp_const(const float* solref, const float* solimp, float dt) {
+  ImpConst ic;
+  ic.dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f); ic.dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
+  ic.width = fmaxf(solimp[2], 1e-15f); ic.mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f); ic.power = fmaxf(solimp[4], 1.0f);
+  const float tc = fmaxf(solref[0], 2 * dt), dr = solref[1];
+  ic.k = 1 / (ic.dmax * ic.dmax * tc * tc * dr * dr);
+  ic.b = 2 / (ic.dmax * tc);
+  ic.iwidth = 1 / ic.width; ic.imid = 1 / ic.mid; ic.i1mid = 1 / (1 - ic.mid);
+  return ic;
+}
+struct PhysConst {  // constants derived from kbj_config and the model: computed on the host at kbj_create, copied into LDS by every env workgroup
+                     // (inside the kernel this was ~20 IEEE divisions and a cosf per launch, i.e. per control step)
+  float dt, tolerance;
+  float tol2;        // Newton exit: scale sqrt(|grad|^2) < tolerance with scale = 1 / (meaninertia nv)  <=>  |grad|^2 < (tolerance meaninertia nv)^2
+  float fric_ratio;  // (1 - imp) / imp of the friction-loss rows (impedance at distance 0)
+  float cos_max_tilt;
+  int iterations, ls_iterations;
+  float tamp, tkw;   // terrain z = tamp sin(tkw x) sin(tkw y); tamp = 0: the plane z = 0
+  ImpConst fric, lim, con;
+};
+KBJ_HD PhysConst phys_const(const kbj_config& c, const kbj_model& m) {
+  PhysConst pc;
+  pc.dt = c.dt; pc.tolerance = c.solver_tolerance; pc.iterations = c.solver_iterations; pc.ls_iterations = c.ls_iterations;
+  pc.tamp = c.terrain_amp;
+  pc.tkw = c.terrain_amp != 0 ? (float)(6.283185307179586 / c.terrain_wavelength) : 0.0f;
+  pc.fric = imp_const(m.fric_solref, m.fric_solimp, c.dt);
+  pc.lim = imp_const(m.limit_solref, m.limit_solimp, c.dt);
+  pc.con = imp_const(m.contact_solref, m.contact_solimp, c.dt);
+  pc.tol2 = (c.solver_tolerance * m.meaninertia * NV) * (c.solver_tolerance * m.meaninertia * NV);
+  pc.fric_ratio = (1 - pc.fric.dmin) / pc.fric.dmin;
+  pc.cos_max_tilt = cosf(c.max_tilt_rad);
+  return pc;
+}
 // Everything one env needs between phases, 12.4 KB so that 12 single-wavefront workgroups (3 waves per SIMD) share a CU.
 // Buffers whose lifetimes do not overlap share storage (union `u`): composite inertias (until the mass matrix exists),
 // RNE body forces (until the bias force exists), then the arrow-matrix blocks of the Newton solves. Rotation matrices
 // are recomputed from xquat where needed instead of being stored; the mass matrix is stored in its tree sparsity.
 struct KbjShared {
   KbjModelLds mc;
+  PhysConst pc;         // per-workgroup LDS copy like mc: in SGPRs these ~45 scalars were spilled to vector lanes (v_readlane per use)
   float ep[KBJ_EP_SIZE];
   float es[KBJ_ES_SIZE];
   float xpos[NB][3], xquat[NB][4], xipos[NB][3];

@@ -27,34 +27,6 @@ __shared__ unsigned long long kbj_env_stamp_last;
 
 namespace kbj {
 
-// solref / solimp of one constraint family, reduced once per launch to what the rows need: stiffness k and damping b of the
-// reference acceleration, and the clamped impedance parameters (MuJoCo's mj_makeImpedance)
-struct ImpConst { float k, b, dmin, dmax, width, mid, power; };
-KBJ_DEV ImpConst imp_const(const float* solref, const float* solimp, float dt) {
-  ImpConst ic;
-  ic.dmin = fminf(fmaxf(solimp[0], 0.0001f), 0.9999f); ic.dmax = fminf(fmaxf(solimp[1], 0.0001f), 0.9999f);
-  ic.width = fmaxf(solimp[2], 1e-15f); ic.mid = fminf(fmaxf(solimp[3], 0.0001f), 0.9999f); ic.power = fmaxf(solimp[4], 1.0f);
-  const float tc = fmaxf(solref[0], 2 * dt), dr = solref[1];
-  ic.k = 1 / (ic.dmax * ic.dmax * tc * tc * dr * dr);
-  ic.b = 2 / (ic.dmax * tc);
-  return ic;
-}
-struct PhysConst {  // per-launch constants derived from kbj_config and the model
-  float dt, tolerance;
-  int iterations, ls_iterations;
-  float tamp, tkw;   // terrain z = tamp sin(tkw x) sin(tkw y); tamp = 0: the plane z = 0
-  ImpConst fric, lim, con;
-};
-KBJ_DEV PhysConst phys_const(const kbj_config& c, const kbj_model& m) {
-  PhysConst pc;
-  pc.dt = c.dt; pc.tolerance = c.solver_tolerance; pc.iterations = c.solver_iterations; pc.ls_iterations = c.ls_iterations;
-  pc.tamp = c.terrain_amp;
-  pc.tkw = c.terrain_amp != 0 ? (float)(6.283185307179586 / c.terrain_wavelength) : 0.0f;
-  pc.fric = imp_const(m.fric_solref, m.fric_solimp, c.dt);
-  pc.lim = imp_const(m.limit_solref, m.limit_solimp, c.dt);
-  pc.con = imp_const(m.contact_solref, m.contact_solimp, c.dt);
-  return pc;
-}
 // terrain height and unit normal at (x, y)
 KBJ_DEV void terrain_eval(const PhysConst& pc, float x, float y, float& h, float n[3]) {
   float sx = sinf(pc.tkw * x), cx = cosf(pc.tkw * x), sy = sinf(pc.tkw * y), cy = cosf(pc.tkw * y);
@@ -72,8 +44,8 @@ KBJ_DEV void quat_rot(const float* q, const float* v, float* o) {
   o[1] = v[1] + q[0] * t[1] + (q[3] * t[0] - q[1] * t[2]);
   o[2] = v[2] + q[0] * t[2] + (q[1] * t[1] - q[2] * t[0]);
 }
-KBJ_DEV void quat_norm_fast(float* q) {   // one reciprocal square root instead of a square root and four divisions
-  float inv = 1.0f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+KBJ_DEV void quat_norm_fast(float* q) {   // one reciprocal square root (v_rsq_f32 + a Newton step) instead of a square root and four divisions
+  float inv = kbj_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   for (int k = 0; k < 4; ++k) q[k] *= inv;
 }
 
@@ -85,7 +57,8 @@ KBJ_DEV void phys_kinematics(KbjShared& S, const KbjModelLds& m) {
   const float* qpos = S.es + KBJ_ES_QPOS;
   PFOR(u, NU) {
     const int b = 3 + u;
-    const float ang = qpos[7 + u], sn = sinf(ang / 2), co = cosf(ang / 2);
+    float sn, co;
+    kbj_sincos(0.5f * qpos[7 + u], sn, co);
     const float jq[4] = {co, sn * m.jnt_axis[b][0], sn * m.jnt_axis[b][1], sn * m.jnt_axis[b][2]};
     float q[4];
     quat_mul(m.body_quat[b], jq, q);
@@ -143,8 +116,8 @@ KBJ_DEV void phys_com(KbjShared& S, const KbjModelLds& m) {
     const float m1 = m2 + mass[1];
     KBJ_SYNC();   // (emulation: the sums above read what the stores below overwrite nothing of; on the GPU a no-op for one wavefront)
     PFOR(w, 3) {
-      S.com2[w] = s2[w] / m2;
-      S.com[w] = (s2[w] + mass[1] * S.xipos[1][w]) / m1;
+      S.com2[w] = s2[w] * kbj_frcp(m2);
+      S.com[w] = (s2[w] + mass[1] * S.xipos[1][w]) * kbj_frcp(m1);
       if (w == 0) S.com[3] = m1;
     }
   }
@@ -455,12 +428,12 @@ KBJ_DEV float mul_M_row(const KbjShared& S, int i, const float* v) {
 
 // ---- constraint rows -------------------------------------------------------------------------------------------
 KBJ_DEV float impedance(float dist, const ImpConst& ic) {
-  float x = fabsf(dist) / ic.width;
+  float x = fabsf(dist) * ic.iwidth;
   if (x >= 1) return ic.dmax;
   if (x <= 0) return ic.dmin;
   float y;
   if (ic.power == 1.0f) y = x;
-  else if (ic.power == 2.0f) y = x <= ic.mid ? x * x / ic.mid : 1 - (1 - x) * (1 - x) / (1 - ic.mid);   // MuJoCo's default power, without pow()
+  else if (ic.power == 2.0f) y = x <= ic.mid ? x * x * ic.imid : 1 - (1 - x) * (1 - x) * ic.i1mid;   // MuJoCo's default power, without pow() or a division
   else if (x <= ic.mid) y = powf(x, ic.power) / powf(ic.mid, ic.power - 1);
   else y = 1 - powf(1 - x, ic.power) / powf(1 - ic.mid, ic.power - 1);
   return ic.dmin + y * (ic.dmax - ic.dmin);
@@ -473,8 +446,8 @@ KBJ_DEV void phys_make_constraints(KbjShared& S, const KbjModelLds& m, const Phy
     int dof = 6 + u;
     const float b = pc.fric.b, imp = pc.fric.dmin;   // impedance at distance 0
     float fl = S.ep[KBJ_EP_FRICLOSS + dof];
-    float Rr = fmaxf(1e-15f, (1 - imp) / imp * m.dof_invweight0[dof]);
-    S.Rf[u] = Rr; S.D[u] = fl > 0 ? 1 / Rr : 0.0f; S.aref[u] = -b * qvel[dof]; S.floss[u] = fl;
+    float Rr = fmaxf(1e-15f, pc.fric_ratio * m.dof_invweight0[dof]);
+    S.Rf[u] = Rr; S.D[u] = fl > 0 ? kbj_frcp(Rr) : 0.0f; S.aref[u] = -b * qvel[dof]; S.floss[u] = fl;
     float q = qpos[7 + u];
     float dlo = q - m.dof_range[dof][0], dhi = m.dof_range[dof][1] - q;
     float pos = fminf(dlo, dhi), sgn = dlo < dhi ? 1.0f : -1.0f;
@@ -482,8 +455,8 @@ KBJ_DEV void phys_make_constraints(KbjShared& S, const KbjModelLds& m, const Phy
     S.lsign[u] = sgn;
     if (pos < 0) {
       const float impl = impedance(pos, pc.lim);
-      float Rl = fmaxf(1e-15f, (1 - impl) / impl * m.dof_invweight0[dof]);
-      S.D[r] = 1 / Rl; S.aref[r] = -pc.lim.b * sgn * qvel[dof] - pc.lim.k * impl * pos;
+      float Rl = fmaxf(1e-15f, (1 - impl) * kbj_frcp(impl) * m.dof_invweight0[dof]);
+      S.D[r] = kbj_frcp(Rl); S.aref[r] = -pc.lim.b * sgn * qvel[dof] - pc.lim.k * impl * pos;
     } else { S.D[r] = 0; S.aref[r] = 0; }
   }
   // point Jacobian of every active contact in its contact frame, once per (contact, column) - the four pyramid rows of a contact
@@ -529,8 +502,8 @@ KBJ_DEV void phys_make_constraints(KbjShared& S, const KbjModelLds& m, const Phy
     const float k_ = pc.con.k, b_ = pc.con.b, imp = impedance(S.condist[ci], pc.con);
     float tran = m.body_invweight0[leg ? 12 : 7][0];
     float invw = (tran + mu * mu * tran) * 2 * mu * mu;
-    float Rc = fmaxf(1e-15f, (1 - imp) / imp * invw);
-    S.D[row] = 1 / Rc; S.aref[row] = -b_ * vel - k_ * imp * S.condist[ci];
+    float Rc = fmaxf(1e-15f, (1 - imp) * kbj_frcp(imp) * invw);
+    S.D[row] = kbj_frcp(Rc); S.aref[row] = -b_ * vel - k_ * imp * S.condist[ci];
   }
   KBJ_SYNC();
 }
@@ -851,8 +824,7 @@ KBJ_DEV void phys_solve(KbjShared& S, const KbjModelLds& mdl, const PhysConst& p
     WL(jar_f, l) = use_warm ? WL(jf_w, l) : WL(jf_s, l); WL(jar_l, l) = use_warm ? WL(jl_w, l) : WL(jl_s, l); WL(jar_c, l) = use_warm ? WL(jc_w, l) : WL(jc_s, l);
   }
   KBJ_STAMP(8);
-  const float scale = 1.0f / (mdl.meaninertia * NV);
-  const float tol2 = (pc.tolerance / scale) * (pc.tolerance / scale);   // scale sqrt(gg) < tolerance  <=>  gg < (tolerance / scale)^2
+  const float tol2 = pc.tol2;
   int iters = 0;
   WF ff, flm, fc, dnow, w_prev;
   WLANES(l) WL(w_prev, l) = 0.0f;     // weight (D in the quadratic zone, else 0) with which this lane's pyramid row currently sits in h
@@ -1034,13 +1006,19 @@ KBJ_DEV void phys_integrate(KbjShared& S, const PhysConst& pc) {
   PFOR(i, NV) {
     if (i < 3) qpos[i] += pc.dt * qvel[i];
     else if (i == 3) {
+      // base orientation: q <- normalise(q * [cos h, sin(h) w / |w|]), h = |w| dt / 2. In z = h^2: cos h = 1 - z/2 + ..., sin(h) / |w| =
+      // (dt / 2) (1 - z/6 + ...): no square root, no sin / cos (truncation < 1e-10 for |w| dt < 1; beyond that the closed form).
       float w[3] = {qvel[3], qvel[4], qvel[5]};
-      float nrm = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), ang = nrm * pc.dt;
-      if (ang > 0) {
-        float s = sinf(ang / 2) / nrm;
-        float dq[4] = {cosf(ang / 2), s * w[0], s * w[1], s * w[2]}, q[4];
+      const float hd = 0.5f * pc.dt, z = hd * hd * (w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      if (z > 0) {
+        float co, s;
+        if (z < 0.25f) {
+          co = fmaf(fmaf(fmaf(fmaf(fmaf(-1.0f / 3628800, z, 1.0f / 40320), z, -1.0f / 720), z, 1.0f / 24), z, -0.5f), z, 1.0f);
+          s = hd * fmaf(fmaf(fmaf(fmaf(1.0f / 362880, z, -1.0f / 5040), z, 1.0f / 120), z, -1.0f / 6), z, 1.0f);
+        } else { const float nrm = sqrtf(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]), ang = nrm * pc.dt; co = cosf(ang / 2); s = sinf(ang / 2) / nrm; }
+        float dq[4] = {co, s * w[0], s * w[1], s * w[2]}, q[4];
         quat_mul(qpos + 3, dq, q);
-        quat_norm(q);
+        quat_norm_fast(q);
         for (int k = 0; k < 4; ++k) qpos[3 + k] = q[k];
       }
     } else if (i >= 6) qpos[1 + i] += pc.dt * qvel[i];

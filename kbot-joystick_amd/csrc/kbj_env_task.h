@@ -198,23 +198,29 @@ KBJ_DEV void task_write_obs(KbjShared& S, const kbj_model& m, const kbj_config& 
     critic[KBJ_OBS_JPOS + u] = (q - m.joint_bias[u]) / range; critic[KBJ_OBS_JVEL + u] = v / KBJ_OBS_JVEL_DIV;
     critic[KBJ_OBS_ACTFRC + u] = S.qfrc_act[6 + u] / KBJ_OBS_ACTFRC_DIV;
   }
+  // The four one-lane jobs below are different code, so the wavefront runs them one after the other: keep each short. The six normal
+  // draws of the imu noise (Box-Muller: threefry + log + cos + sqrt, ~150 vector instructions each) run on six lanes at once.
+  float* nrm6 = S.u.cfrc[0];     // scratch: the RNE buffers are dead once the solver has run
+  PFOR(w, 6) nrm6[w] = noise ? rng_normal(rng, KBJ_RNG_OBS_NOISE, st, 40 + w) : 0.0f;    // 40..42 gyro, 43..45 projected gravity
+  KBJ_SYNC();
   PFOR(w, 4) {
     if (w == 0) {  // lagged / biased / noisy projected gravity for the actor, clean one for the critic
       float lag = S.ep[KBJ_EP_PGLAG], pgn[3], o[5];
       for (int k = 0; k < 3; ++k) {
         float pgl = lag * es[KBJ_ES_PGLAG + k] + (1 - lag) * S.pg[k];
         es[KBJ_ES_PGLAG + k] = pgl;
-        pgn[k] = pgl + S.ep[KBJ_EP_PGBIAS + k] + (noise ? c.pg_noise_std * rng_normal(rng, KBJ_RNG_OBS_NOISE, st, 43 + k) : 0.0f);
+        pgn[k] = pgl + S.ep[KBJ_EP_PGBIAS + k] + (noise ? c.pg_noise_std * nrm6[3 + k] : 0.0f);
       }
       encode_pg(pgn, o);
       for (int k = 0; k < 5; ++k) actor[KBJ_OBS_PG + k] = o[k];
-      encode_pg(S.pg, o);
-      for (int k = 0; k < 5; ++k) critic[KBJ_OBS_PG + k] = o[k];
       for (int k = 0; k < 3; ++k) {
-        actor[KBJ_OBS_GYRO + k] = S.gyro[k] + (noise ? c.gyro_noise_std * rng_normal(rng, KBJ_RNG_OBS_NOISE, st, 40 + k) : 0.0f);
+        actor[KBJ_OBS_GYRO + k] = S.gyro[k] + (noise ? c.gyro_noise_std * nrm6[k] : 0.0f);
         critic[KBJ_OBS_GYRO + k] = S.gyro[k];
       }
     } else if (w == 1) {
+      float o[5];
+      encode_pg(S.pg, o);
+      for (int k = 0; k < 5; ++k) critic[KBJ_OBS_PG + k] = o[k];
       actor[KBJ_OBS_ZEROCMD] = zc; critic[KBJ_OBS_ZEROCMD] = zc;
       for (int k = KBJ_NOBS_ACTOR; k < KBJ_LD_ACTOR; ++k) actor[k] = 0;
       for (int k = KBJ_NOBS_CRITIC; k < KBJ_LD_CRITIC; ++k) critic[k] = 0;
@@ -223,16 +229,19 @@ KBJ_DEV void task_write_obs(KbjShared& S, const kbj_model& m, const kbj_config& 
       for (int k = 0; k < 3; ++k) { critic[KBJ_OBS_BASEPOS + k] = es[KBJ_ES_QPOS + k]; critic[KBJ_OBS_LINVEL + k] = es[KBJ_ES_QVEL + k]; critic[KBJ_OBS_ANGVEL + k] = es[KBJ_ES_QVEL + 3 + k]; }
       for (int k = 0; k < 4; ++k) critic[KBJ_OBS_BASEQUAT + k] = es[KBJ_ES_QPOS + 3 + k];
       critic[KBJ_OBS_HEIGHT] = S.xpos[1][2];  // BaseHeightObservation (train.py:706-707)
-    } else if (w == 2) {  // FeetPositionObservation (train.py:682-699)
-      float e[3], yq[4];
-      quat_to_euler(S.xquat[1], e);
-      float ye[3] = {0, 0, e[2]};
-      euler_to_quat(ye, yq);
+    } else if (w == 2) {  // FeetPositionObservation (train.py:682-699): foot offsets in the base's yaw frame
+      // the reference goes quat -> euler -> (0, 0, yaw) -> quat -> rotate; the yaw rotation is cos / sin of atan2(sn, cs), i.e. (cs, sn)
+      // normalised - no trigonometry needed
+      const float* q = S.xquat[1];
+      const float sn = 2 * (q[0] * q[3] + q[1] * q[2]), cs = 1 - 2 * (q[2] * q[2] + q[3] * q[3]);
+      const float h2 = sn * sn + cs * cs, inv = h2 > 0 ? kbj_rsqrt(h2) : 0.0f;
+      const float cy = h2 > 0 ? cs * inv : 1.0f, sy = sn * inv;
       for (int f = 0; f < 2; ++f) {
         int fb = f ? 12 : 7;
-        float rel[3] = {S.xpos[fb][0] - S.xpos[1][0], S.xpos[fb][1] - S.xpos[1][1], S.xpos[fb][2] - S.xpos[1][2]}, o[3];
-        rotate_by_quat(rel, yq, true, o);
-        for (int k = 0; k < 3; ++k) critic[KBJ_OBS_FEETPOS + 3 * f + k] = o[k];
+        float rel[3] = {S.xpos[fb][0] - S.xpos[1][0], S.xpos[fb][1] - S.xpos[1][1], S.xpos[fb][2] - S.xpos[1][2]};
+        critic[KBJ_OBS_FEETPOS + 3 * f + 0] = cy * rel[0] + sy * rel[1];
+        critic[KBJ_OBS_FEETPOS + 3 * f + 1] = cy * rel[1] - sy * rel[0];
+        critic[KBJ_OBS_FEETPOS + 3 * f + 2] = rel[2];
       }
     } else aux[KBJ_AUX_COMDIST] = task_com_distance(S);
   }
@@ -286,7 +295,7 @@ KBJ_DEV void task_step(KbjShared& S, const kbj_model& m, const kbj_config& c, co
     float zz = 1 - 2 * (qx * qx + qy * qy);
     int done = 0;
     if (es[KBJ_ES_TIME] >= (float)c.max_episode_steps) done = 1;
-    if (height < c.unhealthy_z || zz < cosf(c.max_tilt_rad)) done = -1;
+    if (height < c.unhealthy_z || zz < pc.cos_max_tilt) done = -1;
     S.done = done;
     for (int k = 0; k < 6; ++k) aux_t[KBJ_AUX_QVEL + k] = es[KBJ_ES_QVEL + k];
     for (int k = 0; k < 4; ++k) { aux_t[KBJ_AUX_BQUAT + k] = S.xquat[1][k]; aux_t[KBJ_AUX_LFQUAT + k] = S.xquat[7][k]; aux_t[KBJ_AUX_RFQUAT + k] = S.xquat[12][k]; }

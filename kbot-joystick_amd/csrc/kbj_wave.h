@@ -138,6 +138,40 @@ KBJ_DEV void wsum2(float x1, float x2, float& s1, float& s2) {   // two wave sum
 template <class F> KBJ_DEV unsigned long long wballot(F f) { return __builtin_amdgcn_ballot_w64(f(KBJ_LANE)); }
 #endif
 
+// ---- scalar arithmetic that replaces IEEE division / square-root sequences (10-14 vector instructions each) -----------------------
+// hardware estimate + one Newton step: within an ulp of the rounded result. The emulation uses the exact operation.
+KBJ_DEV float kbj_frcp(float x) {    // 1 / x
+#ifdef KBJ_EMU
+  return 1.0f / x;
+#else
+  const float r = __builtin_amdgcn_rcpf(x);
+  return fmaf(fmaf(-x, r, 1.0f), r, r);
+#endif
+}
+KBJ_DEV float kbj_rsqrt(float x) {   // 1 / sqrt(x): y (1 + (1 - x y^2) / 2)
+#ifdef KBJ_EMU
+  return 1.0f / sqrtf(x);
+#else
+  const float y = __builtin_amdgcn_rsqf(x);
+  return fmaf(0.5f * y, fmaf(-x * y, y, 1.0f), y);
+#endif
+}
+// sin and cos of one argument (|x| up to a few thousand; the callers pass joint half-angles below 2): quadrant by round-to-nearest of
+// 2 x / pi, two-term Cody-Waite reduction, the single-precision minimax polynomials of the Cephes library on [-pi/4, pi/4]; ~1 ulp.
+// Plain arithmetic, identical on the GPU and in the emulation; ~23 instructions against ~80 for sinf() + cosf().
+KBJ_DEV void kbj_sincos(float x, float& s, float& c) {
+  const float k = rintf(x * 0.636619772f);
+  float r = fmaf(-k, 1.57079637f, x);
+  r = fmaf(-k, -4.37113883e-8f, r);
+  const float z = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z, fmaf(-0.5f, z, 1.0f));
+  const int q = (int)k;
+  const float ss = (q & 1) ? pc : ps, cc = (q & 1) ? ps : pc;
+  s = (q & 2) ? -ss : ss;
+  c = ((q + 1) & 2) ? -cc : cc;
+}
+
 // -x / (lane P of the row of x): the multiplier column of a pivot. One hardware reciprocal and one Newton step on the quotient
 // (q0 = -x r, e = x + q0 d ~ 0, q = q0 - e r): within an ulp of the rounded quotient for 5 instructions instead of the 10 of an IEEE
 // division. KBJ_SOLVER_RAW_RCP drops the correction (A/B builds).

@@ -20,8 +20,9 @@ void kbj_emu_reset_all(const kbj_model* m, const kbj_config* c, uint32_t seed, f
     std::unique_ptr<KbjShared> S(new KbjShared());
     std::memset(S.get(), 0, sizeof(KbjShared));
     model_lds_fill(S->mc, *m);
+    S->pc = pc;
     Rng rng{seed, (uint32_t)(c->env_id_offset + i)};
-    task_reset(*S, *m, *c, pc, rng);
+    task_reset(*S, *m, *c, S->pc, rng);
     task_write_obs(*S, *m, *c, rng, a0 + (size_t)i * KBJ_LD_ACTOR, c0 + (size_t)i * KBJ_LD_CRITIC, x0 + (size_t)i * KBJ_AUX_SIZE);
     std::memcpy(ep + (size_t)i * KBJ_EP_SIZE, S->ep, sizeof(S->ep));
     std::memcpy(es + (size_t)i * KBJ_ES_SIZE, S->es, sizeof(S->es));
@@ -36,10 +37,11 @@ void kbj_emu_env_step(const kbj_model* m, const kbj_config* c, uint32_t seed, fl
     std::unique_ptr<KbjShared> S(new KbjShared());
     std::memset(S.get(), 0, sizeof(KbjShared));
     model_lds_fill(S->mc, *m);
+    S->pc = pc;
     std::memcpy(S->ep, ep + (size_t)i * KBJ_EP_SIZE, sizeof(S->ep));
     std::memcpy(S->es, es + (size_t)i * KBJ_ES_SIZE, sizeof(S->es));
     Rng rng{seed, (uint32_t)(c->env_id_offset + i)};
-    task_step(*S, *m, *c, pc, rng, action + (size_t)i * KBJ_NU, aux_t + (size_t)i * KBJ_AUX_SIZE, an + (size_t)i * KBJ_LD_ACTOR,
+    task_step(*S, *m, *c, S->pc, rng, action + (size_t)i * KBJ_NU, aux_t + (size_t)i * KBJ_AUX_SIZE, an + (size_t)i * KBJ_LD_ACTOR,
               cn + (size_t)i * KBJ_LD_CRITIC, xn + (size_t)i * KBJ_AUX_SIZE);
     std::memcpy(ep + (size_t)i * KBJ_EP_SIZE, S->ep, sizeof(S->ep));
     std::memcpy(es + (size_t)i * KBJ_ES_SIZE, S->es, sizeof(S->es));
