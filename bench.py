@@ -40,11 +40,13 @@ def nn_flops_per_envstep(H: int, num_passes: int) -> float:
 
 
 def cpu_baseline(repeats: int = 3):
-    """The CPU oracle (C++ OpenMP env + torch actor-critic, a *port*: the JAX reference cannot run offline) on a bounded
-    sample of the same workload: a full iteration of configs[1] scaled down to 256 envs x 100 steps
-    (batch 256, 3 passes, hidden 256). The thread count is SWEPT (8 ... 256, capped by the cores this process may use) with one timed
-    iteration each after a warm-up, and the best setting is then timed as the median of `repeats`: the reported baseline is the best
-    the box does, and the sweep is part of the line. Plus the configs[0] plumbing line (4 envs x 64 steps, batch 4)."""
+    """The CPU oracle (C++ OpenMP env + torch actor-critic, a *port*: the JAX reference cannot run offline) on bounded samples of the
+    same workload, full iterations (rollout + GAE + 3 passes, hidden 256) of configs[1]:
+      * LARGE: 2048 envs x 100 steps, batch 512 - a problem big enough for the host's cores (the env part is one OpenMP task per env, the
+        minibatch matrices are 512 rows). Thread sweep (16 ... usable cores) on a 2048-env x 20-step probe, then ONE timed full iteration
+        at the best setting. This is the line's `value`: the best the host does on this path.
+      * SMALL: 256 envs x 100 steps, batch 256 (round 3's sample: small-problem overhead, best at 16 threads), median of `repeats`.
+    plus the configs[0] plumbing line (4 envs x 64 steps, batch 4). `cores` = the threads used for `value`."""
     import numpy as np
     import torch
     from kbot_joystick_amd.spec import compiler, layout as L
@@ -61,8 +63,8 @@ def cpu_baseline(repeats: int = 3):
         torch.set_num_threads(n)
         O.lib().kbj_cpu_set_num_threads(n)
 
-    def make(n_envs, T):
-        cfg = L.default_config(num_envs=n_envs, batch_size=n_envs, rollout_len=T, hidden_size=256, num_passes=3, command_mode=1)
+    def make(n_envs, T, batch=None):
+        cfg = L.default_config(num_envs=n_envs, batch_size=batch or n_envs, rollout_len=T, hidden_size=256, num_passes=3, command_mode=1)
         cfg.fixed_command[0] = 0.5
         rng = np.random.default_rng(0)
         params = (rng.uniform(-1, 1, ON.param_count(256)) / 16).astype(np.float32)
@@ -75,36 +77,52 @@ def cpu_baseline(repeats: int = 3):
         tr.train_iteration()
         return time.perf_counter() - t0
 
-    # thread sweep on a quarter-size probe (128 envs x 50 steps), smallest first; it stops at the first setting that is clearly slower
-    # than the best so far (oversubscribed OpenMP / intra-op pools on these small matrices get slower, and an unbounded sweep could sit
-    # silent for minutes); every point is printed as it is measured
-    probe = make(128, 50)
-    sweep = {}
-    for n in (8, 16, 32, 64, 128, 256):
-        if n > usable and sweep:
-            break
-        set_threads(n)
-        if not sweep:
-            probe.train_iteration()   # warm-up (allocator, thread pools)
-        sweep[n] = round(timed(probe), 3)
-        print(f"bench.py: cpu_baseline thread sweep: {n} threads -> {sweep[n]:.3f} s per probe iteration", file=sys.stderr, flush=True)
-        if sweep[n] > 1.3 * min(sweep.values()):
-            break
-    best = min(sweep, key=sweep.get)
-    set_threads(best)
+    def sweep_threads(probe, candidates, label, budget_s):
+        """smallest first; stops at the first setting clearly slower than the best so far (oversubscribed pools get slower) or when the
+        time budget is spent; every point is printed as it is measured (a silent sweep looks hung)"""
+        sweep, spent = {}, 0.0
+        for n in candidates:
+            if n > usable and sweep:
+                break
+            set_threads(n)
+            if not sweep:
+                probe.train_iteration()   # warm-up (allocator, thread pools)
+            sweep[n] = round(timed(probe), 3)
+            spent += sweep[n]
+            print(f"bench.py: cpu_baseline thread sweep ({label}): {n} threads -> {sweep[n]:.3f} s per probe iteration", file=sys.stderr, flush=True)
+            if sweep[n] > 1.3 * min(sweep.values()) or spent > budget_s:
+                break
+        return sweep
+
+    # ---- small sample (round 3's): 256 envs ----
+    sweep_s = sweep_threads(make(128, 50), (8, 16, 32, 64, 128, 256), "128 envs x 50 steps", 30.0)
+    best_s = min(sweep_s, key=sweep_s.get)
+    set_threads(best_s)
     tr = make(256, 100)
     tr.train_iteration()              # warm-up at the chosen setting
     ts1 = [timed(tr) for _ in range(repeats)]
     t1 = float(np.median(ts1))
+    del tr
+    # ---- large sample: 2048 envs, batch 512 ----
+    sweep_l = sweep_threads(make(2048, 20, 512), (16, 32, 64, 128, 256), "2048 envs x 20 steps, batch 512", 60.0)
+    best_l = min(sweep_l, key=sweep_l.get)
+    set_threads(best_l)
+    trl = make(2048, 100, 512)
+    t_large = timed(trl)              # one full iteration (its pools are warm from the probe at the same setting)
+    print(f"bench.py: cpu_baseline large sample: 2048 envs x 100 steps at {best_l} threads -> {t_large:.2f} s", file=sys.stderr, flush=True)
+    del trl
+    set_threads(best_s)
     tr0 = make(4, 64)
     tr0.train_iteration()
     t0 = float(np.median([timed(tr0) for _ in range(3)]))
-    return dict(value=256 * 100 / t1, unit="env-steps/s", cores=best, kind="port",
-                sample=f"oracle full iteration (rollout + GAE + 3 passes) on 256 envs x 100 steps, batch 256, hidden 256: median of {repeats} "
-                       f"= {t1:.2f} s (runs {', '.join('%.2f' % t for t in ts1)}) at the best of the thread sweep ({best} threads; this process may use "
-                       f"{usable} of the host's {os.cpu_count()} cores)",
-                thread_sweep_probe="128 envs x 50 steps, seconds per iteration by thread count (stops at the first setting > 1.3x the best)",
-                thread_sweep_seconds_per_iteration={str(k): v for k, v in sweep.items()},
+    return dict(value=2048 * 100 / t_large, unit="env-steps/s", cores=best_l, kind="port", host_cores=os.cpu_count(), usable_cores=usable,
+                sample=f"oracle full iteration (rollout + GAE + 3 passes) on 2048 envs x 100 steps, batch 512, hidden 256: one iteration = {t_large:.2f} s at the best "
+                       f"of the thread sweep ({best_l} threads; this process may use {usable} of the host's {os.cpu_count()} cores)",
+                thread_sweep_probe="2048 envs x 20 steps, batch 512: seconds per iteration by thread count (stops at the first setting > 1.3x the best or after 60 s)",
+                thread_sweep_seconds_per_iteration={str(k): v for k, v in sweep_l.items()},
+                small_sample=dict(value=256 * 100 / t1, unit="env-steps/s", cores=best_s,
+                                  sample=f"256 envs x 100 steps, batch 256: median of {repeats} = {t1:.2f} s (runs {', '.join('%.2f' % t for t in ts1)}) at {best_s} threads",
+                                  thread_sweep_seconds_per_iteration={str(k): v for k, v in sweep_s.items()}),
                 config0=dict(value=4 * 64 / t0, unit="env-steps/s", sample=f"configs[0]: 4 envs x 64 steps, batch 4, 3 passes, hidden 256: median of 3 = {t0:.2f} s"))
 
 
@@ -171,6 +189,11 @@ def main():
                          "sampler; 4 = full kbot on the sine terrain (extra measurements, not the headline line)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend of the gradient all-reduce (nccl = RCCL over xGMI)")
     ap.add_argument("--share-gpu", action="store_true", help="diagnostic: every rank on GPU 0 (rehearses the N-rank flow on a 1-GPU box; use with --backend gloo)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="--gpus 1 only: what the RCCL leg costs THIS schedule on one GPU. The same task is timed three times in one process: without a "
+                         "process group, then with backend nccl at world size 1 and the gradient all-reduce forced (RCCL's stream and kernels join the "
+                         "context's lanes), then with the overlapped actor-slice exchange; the line's value is the forced per-step run, the object "
+                         "`forced_collective` holds all three")
     ap.add_argument("--allreduce", default=os.environ.get("KBJ_ALLREDUCE", "per_step"), choices=["per_step", "per_pass"],
                     help="per_step (default): all-reduce before every optimizer step; per_pass: accumulate a pass, one all-reduce + one step per pass")
     args = ap.parse_args()
@@ -216,24 +239,45 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        task.train_iteration()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        task.train_iteration()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed_steps(warmup, steps):
+        for _ in range(warmup):
+            task.train_iteration()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            task.train_iteration()
+        barrier()
+        return time.perf_counter() - t0
+
+    from kbot_joystick_amd.host import dist as dist_util
+    forced = None
+    if args.force_collective:
+        if world != 1:
+            sys.exit("bench.py: --force-collective is the one-GPU measurement (--gpus 1)")
+        import torch.distributed as dist
+        plain = timed_steps(args.warmup, args.steps)                       # the schedule without a process group
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        dist_util.FORCE_COLLECTIVE = True                                  # world size 1 would skip the collective
+        forced = dict(ms_per_step_no_process_group=round(plain / args.steps * 1e3, 2))
+    elapsed = timed_steps(args.warmup, args.steps)
+    rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        ts = [torch.zeros(1, device="cuda", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(ts, torch.tensor([elapsed], device="cuda", dtype=torch.float64))
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in ts]
+        elapsed = max(float(t.item()) for t in ts)                          # MAX over ranks
+    # the rank count the line reports comes from the process group itself: its size and an all-reduce of ones through the backend
+    pg_ranks, pg_counted, pg_backend = 1, 1, None
+    if world > 1 or args.force_collective:
+        ones = torch.ones(1, device="cuda")
+        dist.all_reduce(ones)
+        pg_ranks, pg_counted, pg_backend = dist.get_world_size(), int(round(float(ones.item()))), dist.get_backend()
     env_steps = args.envs_per_gpu * world * task.T * args.steps
     value = env_steps / elapsed
 
     # ---- roofline leg: one extra iteration with HIP-event timing inside the library (rank 0) ----
     roofline = roofline2 = hbm = None
-    from kbot_joystick_amd.host import dist as dist_util
     if rank == 0:
         task.ctx.profile_begin()
         dist_util.TIMING = []          # events around every gradient all-reduce of the instrumented iteration
@@ -286,6 +330,14 @@ def main():
             meas = traffic_src["hbm_bytes_per_iteration"] / iter_s / 1e9
             hbm.update(measured=round(meas, 1), measured_frac=round(meas / PEAK_HBM_GBS, 4), measured_bytes_per_iteration=round(traffic_src["hbm_bytes_per_iteration"]))
 
+    if forced is not None:      # third leg: the actor's gradient slice all-reduced on a second stream under the critic's tail
+        forced.update(ms_per_step_forced_allreduce=round(elapsed / args.steps * 1e3, 2), allreduce_ms_per_iteration=round(allreduce_ms, 3),
+                      allreduce_calls_per_iteration=allreduce_calls)
+        task.config.overlap_allreduce = True
+        forced["ms_per_step_forced_allreduce_overlapped"] = round(timed_steps(1, args.steps) / args.steps * 1e3, 2)
+        task.config.overlap_allreduce = False
+        forced["note"] = ("one GPU, backend nccl, world size 1: the all-reduce moves no data between GPUs; what is measured is RCCL's kernel launch + its "
+                          "stream joining the schedule's lanes (DESIGN.md section 8)")
     if world > 1:
         dist.barrier()
     if rank != 0:
@@ -308,12 +360,13 @@ def main():
         "roofline": roofline, "roofline_secondary": roofline2, "cpu_baseline": cpu,
         # data-parallel exchange: ranks in the process group (1 = no collective runs), gradient all-reduce time of one iteration (HIP events
         # around every dist.all_reduce of the instrumented iteration, rank 0) and the whole-path HBM fraction
-        "rccl_ranks": world, "collective_backend": (args.backend if world > 1 else None),
+        "rccl_ranks": pg_ranks, "rccl_ranks_counted_by_allreduce": pg_counted, "collective_backend": pg_backend,
+        "rank_ms_per_step": {"min": round(min(rank_ms), 2), "max": round(max(rank_ms), 2)}, "forced_collective": forced,
         "allreduce_ms_per_iteration": round(allreduce_ms, 3), "allreduce_calls_per_iteration": allreduce_calls,
         "hbm_whole_path": hbm,
     }
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_collective:
         dist.destroy_process_group()
 
 

@@ -272,6 +272,26 @@ def test_bench_launches_its_own_ranks():
     assert bad.returncode != 0 and "does not match WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
+def test_bench_forced_collective_on_one_gpu():
+    """`bench.py --gpus 1 --force-collective`: the RCCL leg (backend nccl, world size 1, gradient all-reduce forced) timed beside the run
+    without a process group and the overlapped exchange, in one process; the rank count of the line comes from the process group and an
+    all-reduce of ones, not from the environment."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--envs-per-gpu", "1024", "--hidden", "64",
+                          "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    rec = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    fc = rec["forced_collective"]
+    assert rec["rccl_ranks"] == 1 and rec["rccl_ranks_counted_by_allreduce"] == 1 and rec["collective_backend"] == "nccl"
+    assert rec["allreduce_calls_per_iteration"] == 3 * (1024 // 512) and rec["allreduce_ms_per_iteration"] > 0
+    for k in ("ms_per_step_no_process_group", "ms_per_step_forced_allreduce", "ms_per_step_forced_allreduce_overlapped"):
+        assert fc[k] > 0
+    assert abs(rec["ms_per_step"] - fc["ms_per_step_forced_allreduce"]) < 1e-6
+    assert rec["rank_ms_per_step"]["min"] <= rec["rank_ms_per_step"]["max"]
+
+
 def test_python_termination_and_observation_terms():
     """f3: user-written Termination / Observation terms in the reference's protocol (train.py:817, 635-707) on the post-step StepView.
     The reference's own TerrainBadZTermination (train.py:817-823) restated in Python, with the kernel's built-in bad-z term switched off,
