@@ -12,7 +12,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "_build", "libkbj_oracle.so")
+_LIB_PATH = os.environ.get("KBJ_ORACLE_LIB") or os.path.join(_HERE, "_build", "libkbj_oracle.so")   # override: the sanitizer build (tests/test_sanitize.py)
 
 DBG = dict(XPOS=(0, 72), XQUAT=(72, 96), M=(168, 676), QACC=(844, 26), QACC_SMOOTH=(870, 26), BIAS=(896, 26),
            EFC_FORCE=(922, 72), TOUCH=(994, 2), GYRO=(996, 3), SUBCOM=(999, 72), CINERT=(1071, 240), CVEL=(1311, 144),
@@ -21,6 +21,8 @@ DBG = dict(XPOS=(0, 72), XQUAT=(72, 96), M=(168, 676), QACC=(844, 26), QACC_SMOO
 
 
 def build(force: bool = False) -> str:
+    if os.environ.get("KBJ_ORACLE_LIB"):
+        return _LIB_PATH
     srcs = [os.path.join(_HERE, f) for f in ("kbj_oracle.cpp", "kbj_oracle_physics.h", "kbj_oracle_task.h")]
     srcs.append(os.path.join(_HERE, "..", "include", "kbj_model.h"))
     if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
