@@ -5,6 +5,8 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include <algorithm>
+#include <utility>
 #include "kbj_gemm.h"
 
 thread_local kbj_ctx* kbj_prof_ctx = nullptr;
@@ -45,6 +47,181 @@ double run(const char* name, int M, int N, int K, int splitk, int force_big, flo
   return us;
 }
 
+
+// ---- PROTOTYPE (this tool only, not in libkbj.so): fp32 GEMM on the bf16 matrix cores through an EXACT three-way operand split ----
+// x = hi + mid + lo with hi = x truncated to its top 8 significand bits (a bf16), mid = (x - hi) truncated likewise, lo = x - hi - mid:
+// both subtractions are exact in fp32 and lo has at most 8 significant bits left, so the three bf16 pieces carry all 24 bits of x.
+// a b = sum of the 9 piece products, each exact in the MFMA's fp32 accumulation; the 6-product form drops mid*lo, lo*mid, lo*lo
+// (relative size <= 2^-23). `v_mfma_f32_32x32x16_bf16` runs at 16x the per-instruction rate of `v_mfma_f32_32x32x2_f32` and holds the
+// vector issue port for 8 of its 32 cycles, so 6 / 9 of them per 16 k cost 0.375 / 0.56 of the fp32 form's time and leave the port free
+// for the split itself. Operands are split ONCE per element, on the way into LDS (and + sub + pack: ~5.5 vector instructions per
+// element against 128 multiply-adds it takes part in). 128 x 128 x 32 tiles on 4 wavefronts (2 x 2, each 64 x 64 = 2 x 2 MFMA tiles);
+// LDS: [piece][row][40] bf16 per operand (16-byte fragments), one stage + register prefetch, two workgroups per CU.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int X3_LD = 40;                       // bf16 per LDS row (32 k + 8 pad: 80-byte rows keep ds_read_b128 of 32 rows conflict-free)
+constexpr int X3_PIECE = 128 * X3_LD;           // bf16 per piece of one operand tile
+__device__ __forceinline__ void split3(const f32x4& x, u32x2& hi, u32x2& mid, u32x2& lo) {   // four consecutive k of one row -> 3 x (4 bf16)
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const unsigned xb = __float_as_uint(x[e]);
+    h[e] = xb & 0xFFFF0000u;
+    const float r1 = x[e] - __uint_as_float(h[e]);
+    m[e] = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(m[e]);
+    l[e] = __float_as_uint(r2);                 // <= 8 significant bits: its upper half is exact
+  }
+  hi = {__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+  mid = {__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+  lo = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+}
+// one operand tile 128 rows x 32 k: every thread stages 16 elements as four (row, 4 consecutive k) groups
+template <bool KC> struct X3Stage {
+  f32x4 v[4];
+  // k-contiguous [rows][ld]: thread = (row rr + 32 i, k 4 kq); row-contiguous [k][ld]: thread = (rows 4 rq .. 4 rq + 3, k 4 kg .. 4 kg + 3), transposed in registers
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r0, int k0) {
+    const int t = threadIdx.x;
+    if (KC) { const int kq = t & 7, rr = t >> 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(P + (size_t)(r0 + rr + 32 * i) * ld + k0 + 4 * kq);
+    } else { const int rq = t & 31, kg = t >> 5;
+      f32x4 w[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = *reinterpret_cast<const f32x4*>(P + (size_t)(k0 + 4 * kg + j) * ld + r0 + 4 * rq);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = {w[0][i], w[1][i], w[2][i], w[3][i]};      // row 4 rq + i, k 4 kg .. + 3
+    }
+  }
+  __device__ __forceinline__ void store(short* lds) const {    // lds: [3][128][X3_LD]
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = KC ? (t >> 3) + 32 * i : 4 * (t & 31) + i, k = KC ? 4 * (t & 7) : 4 * (t >> 5);
+      u32x2 hi, mid, lo;
+      split3(v[i], hi, mid, lo);
+      short* p = lds + row * X3_LD + k;
+      *reinterpret_cast<u32x2*>(p) = hi; *reinterpret_cast<u32x2*>(p + X3_PIECE) = mid; *reinterpret_cast<u32x2*>(p + 2 * X3_PIECE) = lo;
+    }
+  }
+};
+template <int NPROD, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
+                                                             int lda, int ldb, int ldc, int splitk) {
+  extern __shared__ __attribute__((aligned(16))) short x3lds[];   // A: 3 pieces, then B: 3 pieces
+  short* As = x3lds; short* Bs = x3lds + 3 * X3_PIECE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int tiles_n = N / 128, tiles_m = M / 128;
+  const int per = splitk > 1 ? ((K + splitk - 1) / splitk + 31) / 32 * 32 : K;
+  const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);     // XCD-contiguous hand-out as in kbj_gemm.h
+  if (item >= tiles_n * tiles_m * (splitk > 1 ? splitk : 1)) return;
+  const int tn = item % tiles_n, tm = (item / tiles_n) % tiles_m, ks = item / (tiles_n * tiles_m);
+  const int m0 = tm * 128, n0 = tn * 128, kbeg = ks * per, kend = min(K, kbeg + per);
+  if (kbeg >= kend) return;
+  X3Stage<A_KC> sa; X3Stage<B_KC> sb;
+  sa.load(A, lda, m0, kbeg); sb.load(B, ldb, n0, kbeg);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  for (int k0 = kbeg; k0 < kend; k0 += 32) {
+    __syncthreads();                       // every wavefront has read the previous tile
+    sa.store(As); sb.store(Bs);
+    __syncthreads();
+    if (k0 + 32 < kend) { sa.load(A, lda, m0, k0 + 32); sb.load(B, ldb, n0, k0 + 32); }     // in flight behind the MFMAs
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[3][2], b[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[p][i] = *reinterpret_cast<const bf16x8*>(As + p * X3_PIECE + (wr * 64 + 32 * i + lr) * X3_LD + 16 * kk + 8 * lh);
+          b[p][i] = *reinterpret_cast<const bf16x8*>(Bs + p * X3_PIECE + (wc * 64 + 32 * i + lr) * X3_LD + 16 * kk + 8 * lh);
+        }
+      // smallest products first; pa / pb = piece of A / B (0 hi, 1 mid, 2 lo)
+      constexpr int PA[9] = {2, 1, 2, 1, 2, 0, 1, 0, 0}, PB[9] = {2, 2, 1, 1, 0, 2, 0, 1, 0};   // lo*lo, mid*lo, lo*mid | mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
+#pragma unroll
+      for (int q = 9 - NPROD; q < 9; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wc * 64 + 32 * j + lr;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float* c = C + (size_t)m * ldc + n;
+        if (splitk > 1) atomicAdd(c, acc[i][j][r]); else *c = acc[i][j][r];
+      }
+    }
+}
+template <int NPROD, bool A_KC, bool B_KC> void launch_x3(const float* A, const float* B, float* C, int M, int N, int K, int splitk) {
+  constexpr size_t bytes = 6 * X3_PIECE * sizeof(short);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<NPROD, A_KC, B_KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  (void)attr;
+  int wgs = (M / 128) * (N / 128) * (splitk > 1 ? splitk : 1);
+  wgs = (wgs + 7) / 8 * 8;
+  hipLaunchKernelGGL((gemm_bf16x3_kernel<NPROD, A_KC, B_KC>), dim3(wgs), dim3(256), bytes, 0, A, B, C, M, N, K, A_KC ? K : M, B_KC ? K : N, N, splitk);
+}
+// error study: n sampled outputs against an fp64 dot product of the SAME fp32 operands; relative to 1 + |exact| (the existing column) and to
+// sum |a||b| (the scale rounding errors of a dot product live on)
+struct ErrStat { double max1 = 0, p999_1 = 0, maxs = 0, p999_s = 0, med_s = 0; };
+template <bool A_KC, bool B_KC> ErrStat err_study(const std::vector<float>& hA, const std::vector<float>& hB, const float* C, int M, int N, int K, int n) {
+  std::vector<float> hC((size_t)M * N);
+  CK(hipMemcpy(hC.data(), C, hC.size() * 4, hipMemcpyDeviceToHost));
+  std::vector<double> e1(n), es(n);
+  srand(12345);
+  for (int t = 0; t < n; ++t) {
+    const int m = rand() % M, c = rand() % N;
+    double s = 0, sa = 0;
+    for (int k = 0; k < K; ++k) {
+      const double a = A_KC ? hA[(size_t)m * K + k] : hA[(size_t)k * M + m], b = B_KC ? hB[(size_t)c * K + k] : hB[(size_t)k * N + c];
+      s += a * b; sa += std::fabs(a * b);
+    }
+    const double d = std::fabs(s - hC[(size_t)m * N + c]);
+    e1[t] = d / (1 + std::fabs(s)); es[t] = d / sa;
+  }
+  std::sort(e1.begin(), e1.end()); std::sort(es.begin(), es.end());
+  ErrStat r; r.max1 = e1.back(); r.p999_1 = e1[(size_t)(0.999 * (n - 1))]; r.maxs = es.back(); r.p999_s = es[(size_t)(0.999 * (n - 1))]; r.med_s = es[n / 2];
+  return r;
+}
+template <bool A_KC, bool B_KC> void compare_x3(const char* name, int M, int N, int K, int splitk, float* A, float* B, float* C, int samples) {
+  std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
+  CK(hipMemcpy(hA.data(), A, hA.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hB.data(), B, hB.size() * 4, hipMemcpyDeviceToHost));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto timeit = [&](auto&& fn) {
+    if (splitk > 1) CK(hipMemset(C, 0, (size_t)M * N * 4));
+    fn(); CK(hipDeviceSynchronize());
+    ErrStat st = err_study<A_KC, B_KC>(hA, hB, C, M, N, K, samples);
+    const int reps = 10;
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) fn();
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return std::make_pair(ms * 1e3 / reps, st);
+  };
+  GemmArgs g{A, B, C, nullptr, M, N, K, A_KC ? K : M, B_KC ? K : N, N, splitk > 1 ? 1 : 0, splitk, nullptr};
+  auto ex = timeit([&] { gemm_launch<A_KC, B_KC>(0, g, 1); });
+  auto x6 = timeit([&] { launch_x3<6, A_KC, B_KC>(A, B, C, M, N, K, splitk); });
+  auto x9 = timeit([&] { launch_x3<9, A_KC, B_KC>(A, B, C, M, N, K, splitk); });
+  auto row = [&](const char* what, std::pair<double, ErrStat>& r) {
+    printf("  %-34s %8.1f us %6.1f TF   err/(1+|c|): max %.2e p99.9 %.2e   err/sum|ab|: max %.2e p99.9 %.2e median %.2e\n", what, r.first,
+           2.0 * M * N * K / (r.first * 1e-6) / 1e12, r.second.max1, r.second.p999_1, r.second.maxs, r.second.p999_s, r.second.med_s);
+  };
+  printf("%s  M=%d N=%d K=%d split-K %d  (%d sampled outputs against fp64)\n", name, M, N, K, splitk, samples);
+  row("exact fp32 MFMA (kbj_gemm.h)", ex); row("bf16 x3 split, 6 products", x6); row("bf16 x3 split, 9 products", x9);
+}
+
 int main(int argc, char** argv) {
   const int only = argc > 1 ? atoi(argv[1]) : 0;   // 1..4: that shape alone, without the checks (for counter passes)
   size_t big = (size_t)51200 * 1024;
@@ -53,6 +230,13 @@ int main(int argc, char** argv) {
   std::vector<float> h(big);
   for (size_t i = 0; i < big; ++i) h[i] = (float)((rand() & 0xFFFF) - 32768) / 32768.0f;
   CK(hipMemcpy(A, h.data(), big * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(B, h.data() + 777, (big - 777) * 4, hipMemcpyHostToDevice));
+  if (only == 9) {   // the bf16-split prototype beside the exact kernel on the update's shapes: TF and error against fp64
+    compare_x3<true, true>("forward  [x|h] W^T", 51200, 1024, 256, 1, A, B, C, 20000);
+    compare_x3<true, false>("input gradient dG W", 51200, 256, 1024, 1, A, B, C, 20000);
+    compare_x3<false, false>("weight gradient dG^T [h|x] (paired)", 1024, 512, 51200, 24, A, B, C, 4000);
+    compare_x3<true, true>("square", 4096, 4096, 4096, 1, A, B, C, 8000);
+    return 0;
+  }
   if (only) {
     if (only == 1) run<true, true>("fwd ih (R x 4H x H)", 51200, 1024, 256, 1, -1, A, B, C, false);
     if (only == 2) run<true, false>("dx (R x H x 4H)", 51200, 256, 1024, 1, -1, A, B, C, false);
