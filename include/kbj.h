@@ -180,6 +180,12 @@ int kbj_ppo_forward(kbj_ctx* ctx, const float* params_d, const kbj_traj* traj, c
  * a millisecond before the call's own stream sees the whole gradient - so a host may all-reduce that slice on a second stream under the
  * critic's tail and the rest on the call's stream (host/task.py `overlap_allreduce`). */
 int kbj_stream_wait_actor_grad(kbj_ctx* ctx, void* hip_stream);
+/* Data-parallel variant of the advantage normalisation (ksim normalises the advantages of the batch it is given and
+ * the reference has no multi-device call site to compare with): the following kbj_ppo_grad calls normalise with the statistics the caller
+ * supplies - three doubles on the device, (sum adv, sum adv^2, sample count), e.g. the minibatch's sums all-reduced over the ranks so that
+ * every rank normalises with the mean / variance of the GLOBAL minibatch - instead of their own minibatch's. NULL restores the default.
+ * The pointer is read when kbj_ppo_grad runs (stream-ordered): fill it on the context's stream before the call. */
+int kbj_set_advantage_sums(kbj_ctx* ctx, const double* sums_d);
 /* replaces: optax.adamw + global-norm clip (train.py:1059-1077). step is 1-based. grad_scale multiplies the
  * gradient first (1/world_size after an all-reduce sum). */
 int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const float* grad_d, int64_t step, float grad_scale);

@@ -86,7 +86,8 @@ struct NnWs {
   // W_eff = W_ih0 W_in [4H][68 (65 used)], b_eff = W_ih0 b_in + b_0; Zeff[n] = dG0^T obs of actor-type net n (n = 0, 2)
   float *Weff = nullptr, *beff = nullptr, *Zeff[4] = {nullptr, nullptr, nullptr, nullptr};
   float* WinP[2] = {nullptr, nullptr};   // input-projection weights re-pitched to the observation rows' 16-byte aligned stride (per call: the parameters change)
-  double* stats = nullptr;  // [0..1] adv stats, [2..9] metric accumulators, [10] grad sumsq
+  double* stats = nullptr;  // [0..1] adv stats, [2..9] metric accumulators, [10] grad sumsq, [11] sample count of caller-supplied adv sums (0: own minibatch)
+  const double* ext_adv_sums = nullptr;   // kbj_set_advantage_sums: (sum adv, sum adv^2, count) on the device, used instead of the minibatch's own statistics
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
   unsigned* bwd_progress = nullptr;  // [layer][net][MAX_BWD_CHUNKS] chunk completion counts of the backward recurrences (cleared with the hand-off counters)
@@ -960,8 +961,13 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R * (KBJ_NU + 4)), dim3(256), 0, sm, gs, idx, T, N, B, 0, KBJ_NU + 4);
     if (grad) {
       KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), sm));
-      hipLaunchKernelGGL(adv_stats_kernel, dim3(32), dim3(256), 0, sm, w.adv, R, w.stats, sc.deterministic ? w.detd : (double*)nullptr);
-      if (sc.deterministic) hipLaunchKernelGGL(reduce_double_kernel, dim3(1), dim3(64), 0, sm, w.detd, 32, 2, w.stats);
+      if (w.ext_adv_sums) {   // global-batch statistics from the caller (all-reduced over the data-parallel ranks)
+        KBJ_HIP(ctx, hipMemcpyAsync(w.stats, w.ext_adv_sums, 2 * sizeof(double), hipMemcpyDeviceToDevice, sm));
+        KBJ_HIP(ctx, hipMemcpyAsync(w.stats + 11, w.ext_adv_sums + 2, sizeof(double), hipMemcpyDeviceToDevice, sm));
+      } else {
+        hipLaunchKernelGGL(adv_stats_kernel, dim3(32), dim3(256), 0, sm, w.adv, R, w.stats, sc.deterministic ? w.detd : (double*)nullptr);
+        if (sc.deterministic) hipLaunchKernelGGL(reduce_double_kernel, dim3(1), dim3(64), 0, sm, w.detd, 32, 2, w.stats);
+      }
       KBJ_HIP(ctx, hipMemsetAsync(grad_d, 0, w.nparams * sizeof(float), sm));
       if (sc.fold_actor)
         for (int n = 0; n < w.nnets; ++n)
@@ -1292,6 +1298,12 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d + w.nactor);
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_grad");
   if (sc.debug_sync) return kbj_synchronize(ctx);   // KBJ_DEBUG=1: surface a hand-off timeout at the call that caused it
+  return 0;
+}
+
+int kbj_set_advantage_sums(kbj_ctx* ctx, const double* sums_d) {
+  if (!ctx || !ctx->nn_ws) return kbj_fail(ctx, "kbj_set_advantage_sums: null ctx");
+  ws_of(ctx)->ext_adv_sums = sums_d;
   return 0;
 }
 

@@ -308,8 +308,11 @@ __global__ void ppo_loss_kernel(const float* __restrict__ logp, const float* __r
   double m[6] = {0, 0, 0, 0, 0, 0};
   const float inv = 1.0f / R;
   if (r < R && (part & 1)) {
-    float mean = (float)(stats[0] / R);
-    float var = fmaxf((float)(stats[1] / R) - mean * mean, 0.0f);
+    // stats[11]: the number of samples behind the two sums when the caller supplied them (kbj_set_advantage_sums: the global minibatch of a
+    // data-parallel job), else 0 = this minibatch's own R samples
+    const double cnt = stats[11] > 0 ? stats[11] : (double)R;
+    float mean = (float)(stats[0] / cnt);
+    float var = fmaxf((float)(stats[1] / cnt) - mean * mean, 0.0f);
     float a = (adv[r] - mean) / (sqrtf(var) + pp.adv_eps);
     float d = logp[r] - logp_old[r];
     float dcl = fminf(fmaxf(d, -pp.lrclip), pp.lrclip);
@@ -373,7 +376,8 @@ __global__ void critic_head_kernel(const float* __restrict__ h, const float* __r
 // metrics[10] = loss, policy, value, entropy, clipfrac, kl, adv_mean, adv_std, action_mirror_loss, value_mirror_loss
 __global__ void ppo_metrics_kernel(const double* __restrict__ macc, const double* __restrict__ stats, PpoParams pp, int R, float* __restrict__ metrics) {
   double pol = macc[0] / R, vl = macc[1] / R, en = macc[2] / R, ma = macc[5] / R, mc = macc[6] / R;
-  double mean = stats[0] / R, var = stats[1] / R - mean * mean;
+  const double cnt = stats[11] > 0 ? stats[11] : (double)R;
+  double mean = stats[0] / cnt, var = stats[1] / cnt - mean * mean;
   metrics[0] = (float)(pol + pp.vcoef * vl - pp.ecoef * en + ma + mc);
   metrics[8] = (float)ma; metrics[9] = (float)mc;
   metrics[1] = (float)pol; metrics[2] = (float)vl; metrics[3] = (float)en; metrics[4] = (float)(macc[3] / R); metrics[5] = (float)(macc[4] / R);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "kbj_destroy": (_i, [_vp]),
     "kbj_last_error": (C.c_char_p, [_vp]),
     "kbj_check_config": (_i, [_vp, _vp, _sz]),
+    "kbj_set_advantage_sums": (_i, [_vp, _vp]),
     "kbj_sizeof_model": (_i, []),
     "kbj_sizeof_config": (_i, []),
     "kbj_sizeof_traj": (_i, []),
@@ -254,6 +255,10 @@ class Context:
         """kbj_ppo_forward: the on-policy pass (no gradients) for the B envs `env_idx` names; outputs are [T][B](x20) in env_idx order."""
         out = PpoVars(_ptr(logp), _ptr(value), _ptr(entropy), _ptr(action_std), _ptr(action_mean))
         self.call("kbj_ppo_forward", _ptr(params), C.byref(traj), _ptr(env_idx), B, C.byref(out))
+
+    def set_advantage_sums(self, sums):
+        """kbj_set_advantage_sums: a float64 [3] device tensor (sum adv, sum adv^2, count) or None (default: each minibatch's own)."""
+        self.call("kbj_set_advantage_sums", _ptr(sums))
 
     def stream_wait_actor_grad(self, hip_stream: int):
         self.call("kbj_stream_wait_actor_grad", hip_stream)

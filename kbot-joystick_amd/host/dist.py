@@ -45,3 +45,15 @@ def allreduce_grad_(grad: torch.Tensor, world_size: int) -> float:
         else:
             dist.all_reduce(grad, op=dist.ReduceOp.SUM)
     return 1.0 / world_size
+
+
+def global_advantage_sums(adv_minibatch: torch.Tensor, world_size: int) -> torch.Tensor:
+    """(sum adv, sum adv^2, count) of the GLOBAL minibatch as three float64 on the tensor's device: this rank's sums all-reduced over the
+    data-parallel ranks. Fed to kbj_set_advantage_sums (product) / ppo_loss(adv_sums=...) (oracle): every rank then
+    normalises its advantages with the same mean and variance, and the averaged gradient equals the single-process gradient of the union."""
+    a = adv_minibatch.to(torch.float64)
+    sums = torch.stack([a.sum(), (a * a).sum(), torch.tensor(float(a.numel()), dtype=torch.float64, device=a.device)])
+    if world_size > 1 or FORCE_COLLECTIVE:
+        import torch.distributed as dist
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+    return sums

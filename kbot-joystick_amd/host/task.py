@@ -89,6 +89,10 @@ class HumanoidWalkingTaskConfig:
     # bit-reproducible update: fixed-order reductions instead of fp32 / fp64 atomics in the gradient (kbj_config.deterministic); the
     # reference's XLA program is deterministic by default, here it costs a few percent and is off unless asked for
     deterministic: bool = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_DETERMINISTIC", "0") not in ("0", ""))
+    # data-parallel variant: normalise a minibatch's advantages with the mean / variance of the GLOBAL minibatch (all
+    # ranks' minibatches of that step: three scalars all-reduced per step) instead of each rank's own. With it the averaged gradient equals the
+    # single-process gradient over the union of the ranks' minibatches. Off by default (what ksim does across devices is not visible).
+    global_advantage_stats: bool = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_GLOBAL_ADV_STATS", "0") not in ("0", ""))
     # use_lr_decay with adam_weight_decay == 0 is train.py:1074-1075 AS WRITTEN: optax.chain(scale_by_adam(), scale_by_schedule(cosine)) has
     # no sign flip, i.e. gradient ASCENT. Served only with this explicit opt-in (recorded in the checkpoint's config member); without it
     # that combination is an error.
@@ -347,6 +351,9 @@ class HumanoidWalkingTask:
                 self.grad_acc.zero_()
             for mb in range(nmb):
                 idx = perm[mb * self.B:(mb + 1) * self.B].contiguous()
+                if self.config.global_advantage_stats:
+                    self._adv_sums = dist_util.global_advantage_sums(self.traj.adv.index_select(1, idx.long()), self.world_size)   # kept alive until the call has run
+                    self.ctx.set_advantage_sums(self._adv_sums)
                 self.ctx.ppo_grad(self.params, self.traj.c, idx, self.B, self.traj.adv, self.traj.target, self.grad, self.metrics)
                 if per_pass:
                     self.grad_acc.add_(self.grad)          # kbj_ppo_grad overwrites `grad`; the pass total lives in grad_acc

@@ -125,9 +125,15 @@ def gae(values, rewards, done, gamma, lam):
     return adv, adv + values
 
 
-def ppo_loss(cfg, logp, value, entropy, logp_old, value_old, adv, target):
-    """Clipped PPO objective over one minibatch (all tensors [T,B]); returns (loss, metrics dict)."""
-    a = (adv - adv.mean()) / (adv.std(unbiased=False) + cfg.adv_eps)
+def ppo_loss(cfg, logp, value, entropy, logp_old, value_old, adv, target, adv_sums=None):
+    """Clipped PPO objective over one minibatch (all tensors [T,B]); returns (loss, metrics dict). adv_sums = (sum adv, sum adv^2, count)
+    of the batch to normalise with (the global minibatch of a data-parallel job, kbj_set_advantage_sums); None = this minibatch's own."""
+    if adv_sums is None:
+        mean, std = adv.mean(), adv.std(unbiased=False)
+    else:
+        mean = adv_sums[0] / adv_sums[2]
+        std = torch.sqrt(torch.clamp(adv_sums[1] / adv_sums[2] - mean * mean, min=0.0))
+    a = (adv - mean) / (std + cfg.adv_eps)
     lr = torch.clamp(logp - logp_old, -cfg.log_ratio_clip, cfg.log_ratio_clip)
     ratio = torch.exp(lr)
     surr = torch.minimum(ratio * a, torch.clamp(ratio, 1 - cfg.clip_param, 1 + cfg.clip_param) * a)
@@ -138,7 +144,7 @@ def ppo_loss(cfg, logp, value, entropy, logp_old, value_old, adv, target):
     loss = pol + cfg.value_loss_coef * vl - cfg.entropy_coef * ent
     clipfrac = ((ratio - 1).abs() > cfg.clip_param).to(value.dtype).mean()
     kl = (logp_old - logp).mean()
-    return loss, dict(loss=loss, policy=pol, value=vl, entropy=ent, clipfrac=clipfrac, kl=kl, adv_mean=adv.mean(), adv_std=adv.std(unbiased=False))
+    return loss, dict(loss=loss, policy=pol, value=vl, entropy=ent, clipfrac=clipfrac, kl=kl, adv_mean=mean, adv_std=std)
 
 
 def adamw_step(cfg, p, m, v, g, step, grad_scale=1.0):

@@ -76,7 +76,7 @@ class OracleTrainer:
         self.traj = dict(actor_obs=a_obs, critic_obs=c_obs, aux=aux, action=act, logp=logp, value=value, reward=reward, comps=comps)
         return self.traj
 
-    def minibatch_grad(self, idx: np.ndarray, adv: torch.Tensor, target: torch.Tensor):
+    def minibatch_grad(self, idx: np.ndarray, adv: torch.Tensor, target: torch.Tensor, adv_sums=None):
         L, T = self.L, self.T
         tr = self.traj
         pf = self.params.clone().requires_grad_(True)
@@ -88,7 +88,7 @@ class OracleTrainer:
         cc = [[x[ii] for x in l] for l in self.carry0[1]]
         lp, v, en, *_ = ON.ppo_variables(p, self.cfg, self.jb, tt(tr["actor_obs"][:T])[:, ii], tt(tr["critic_obs"][:T])[:, ii],
                                          tt(tr["action"])[:, ii], done[:, ii], ca, cc, self.carry0[2][ii], self.D)
-        loss, metrics = ON.ppo_loss(self.cfg, lp, v, en, tt(tr["logp"])[:, ii], tt(tr["value"])[:, ii], adv[:, ii], target[:, ii])
+        loss, metrics = ON.ppo_loss(self.cfg, lp, v, en, tt(tr["logp"])[:, ii], tt(tr["value"])[:, ii], adv[:, ii], target[:, ii], adv_sums=adv_sums)
         loss.backward()
         return pf.grad.detach(), {k: float(x.detach()) for k, x in metrics.items()}
 

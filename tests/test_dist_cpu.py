@@ -127,3 +127,58 @@ def test_env_shard_helper():
         D.env_shard(10, 0, 4)
     g = torch.ones(4)
     assert D.allreduce_grad_(g, 1) == 1.0 and torch.equal(g, torch.ones(4))
+
+
+def _worker_global_adv(rank, world, port, out):
+    import torch.distributed as dist
+    from kbot_joystick_amd.host import dist as D
+    from oracle.trainer import OracleTrainer
+    from oracle import nn as ON
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    model = compiler.load_model("kbot-headless")
+    n_local, off = D.env_shard(8, rank, world)
+    cfg = L.default_config(num_envs=n_local, env_id_offset=off, batch_size=n_local, rollout_len=4, hidden_size=16, num_passes=1)
+    params = (np.random.default_rng(0).uniform(-1, 1, ON.param_count(16)) / 4).astype(np.float32)
+    tr = OracleTrainer(model, cfg, seed=3, params=params, precision="f64")
+    tr.rollout()
+    adv, tgt = ON.gae(torch.tensor(tr.traj["value"], dtype=torch.float64), torch.tensor(tr.traj["reward"], dtype=torch.float64),
+                      torch.tensor(tr.traj["aux"][:4, :, L.AUX["DONE"]], dtype=torch.float64), cfg.gamma, cfg.lam)
+    idx = np.arange(n_local)
+    sums = D.global_advantage_sums(adv[:, idx], world)                   # the exchange of the variant: three scalars
+    g, met = tr.minibatch_grad(idx, adv, tgt, adv_sums=sums)
+    g_own, _ = tr.minibatch_grad(idx, adv, tgt)                           # default: this rank's own statistics
+    scale = D.allreduce_grad_(g, world)
+    out[rank] = dict(sums=sums.numpy(), g_avg=(g * scale).numpy(), g_own=g_own.numpy(), adv=adv.numpy(), adv_mean=met["adv_mean"], adv_std=met["adv_std"])
+    dist.destroy_process_group()
+
+
+def test_global_advantage_statistics_equal_the_union():
+    """SURVEY section 8e's optional exchange: all-reduce (sum adv, sum adv^2, count) per minibatch. Two gloo ranks with 4 envs each: the sums
+    every rank ends up with are those of the union of the two minibatches, and the AVERAGED gradient under that normalisation equals the
+    single-process gradient of the 8-env minibatch - which the default (per-rank statistics) does not."""
+    from oracle import oracle as O
+    from oracle import nn as ON
+    from oracle.trainer import OracleTrainer
+    O.build()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker_global_adv, args=(2, 29523, out), nprocs=2, join=True)
+    r0, r1 = out[0], out[1]
+    union = np.concatenate([r0["adv"], r1["adv"]], axis=1)
+    assert np.array_equal(r0["sums"], r1["sums"]) and r0["sums"][2] == union.size
+    assert np.allclose(r0["sums"][:2], [union.sum(), (union ** 2).sum()], rtol=1e-12)
+    assert abs(r0["adv_mean"] - union.mean()) < 1e-12 and abs(r0["adv_std"] - union.std()) < 1e-12
+    model = compiler.load_model("kbot-headless")
+    cfg = L.default_config(num_envs=8, batch_size=8, rollout_len=4, hidden_size=16, num_passes=1)
+    params = (np.random.default_rng(0).uniform(-1, 1, ON.param_count(16)) / 4).astype(np.float32)
+    single = OracleTrainer(model, cfg, seed=3, params=params, precision="f64")
+    single.rollout()
+    adv, tgt = ON.gae(torch.tensor(single.traj["value"], dtype=torch.float64), torch.tensor(single.traj["reward"], dtype=torch.float64),
+                      torch.tensor(single.traj["aux"][:4, :, L.AUX["DONE"]], dtype=torch.float64), cfg.gamma, cfg.lam)
+    g_single, _ = single.minibatch_grad(np.arange(8), adv, tgt)
+    g_single = g_single.numpy()
+    scale = np.abs(g_single).max()
+    assert np.abs(r0["g_avg"] - g_single).max() < 1e-6 * scale              # (qpos / qvel differ by batch-size dependent BLAS rounding, 1e-6)
+    assert np.abs(0.5 * (r0["g_own"] + r1["g_own"]) - g_single).max() > 1e-4 * scale   # the default is a different (per-rank) normalisation

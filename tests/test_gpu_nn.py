@@ -140,6 +140,29 @@ def test_ppo_grad_matches_autograd(H, N, B, T):
         assert err < 2e-3, (name, float(err), float(b.abs().max()))
         off += n
     assert (gg - go).norm() / go.norm() < 1e-4
+    # caller-supplied advantage statistics (kbj_set_advantage_sums, the data-parallel variant of SURVEY 8e): the sums of ANOTHER set - here
+    # the whole rollout's advantages, as if seven more ranks had contributed - must give the oracle's gradient under that normalisation,
+    # and NULL must restore the minibatch's own
+    if T < 100:
+        from kbot_joystick_amd.host import dist as D
+        sums = D.global_advantage_sums(tr.adv, 1)
+        ctx.set_advantage_sums(sums)
+        g2, m2 = torch.zeros(P, device="cuda:0"), torch.zeros(10, device="cuda:0")
+        ctx.ppo_grad(params, tr.c, idx.cuda(), B, tr.adv, tr.target, g2, m2)
+        ctx.synchronize()
+        pf2 = p64.clone().requires_grad_(True)
+        lp2, v2, en2, *_ = ON.ppo_variables(ON.unflatten(pf2, H), cfg, jb, ao[:, ii], co[:, ii], act[:, ii], done[:, ii], ca, cc, tr.carry0_lpf.cpu().double()[ii])
+        loss2, mt2 = ON.ppo_loss(cfg, lp2, v2, en2, tr.logp.cpu().double()[:, ii], tr.value.cpu().double()[:, ii], adv_o[:, ii], tgt_o[:, ii],
+                                 adv_sums=torch.stack([adv_o.sum(), (adv_o ** 2).sum(), torch.tensor(float(adv_o.numel()), dtype=torch.float64)]))
+        loss2.backward()
+        assert (g2.cpu().double() - pf2.grad).norm() / pf2.grad.norm() < 1e-4
+        assert abs(float(m2[6]) - float(adv_o.mean())) < 1e-5 and abs(float(m2[7]) - float(adv_o.std(unbiased=False))) < 1e-5
+        assert (g2.cpu().double() - gg).norm() / gg.norm() > 1e-3           # it IS a different normalisation
+        ctx.set_advantage_sums(None)
+        g3 = torch.zeros(P, device="cuda:0")
+        ctx.ppo_grad(params, tr.c, idx.cuda(), B, tr.adv, tr.target, g3, m2)
+        ctx.synchronize()
+        assert (g3.cpu().double() - gg).norm() / gg.norm() < 1e-5
     # AdamW + global-norm clip
     mom, var = torch.zeros(P, device="cuda:0"), torch.zeros(P, device="cuda:0")
     p_o, m_o, v_o = params.cpu().double().clone(), torch.zeros(P, dtype=torch.float64), torch.zeros(P, dtype=torch.float64)
