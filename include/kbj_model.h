@@ -38,6 +38,13 @@ extern "C" {
 #define KBJ_LD_ACTOR     68
 #define KBJ_MAX_DEPTH    4   /* LSTM layers per net the library's workspaces are laid out for */
 #define KBJ_LD_CRITIC    476
+/* User observations INTO the network rows (kbj_config.extra_obs_actor / extra_obs_critic, the f3 row of SURVEY.md section 8): the reference's
+ * user appends terms to the lists run_actor / run_critic concatenate (train.py:1351-1433); here up to KBJ_MAX_EXTRA_OBS floats are appended
+ * BEHIND the reference's 65 / 475 (every KBJ_OBS_* offset stays put). Row widths and strides of a context:
+ *   nobs = KBJ_NOBS_x + extra_obs_x,  ld = KBJ_LD_OF(nobs)  (rows stay 16-byte aligned; the pad columns are zero)
+ * The env kernels write the reference's columns and zero [KBJ_NOBS_x, ld); the host writes its terms' outputs behind them. */
+#define KBJ_MAX_EXTRA_OBS 64
+#define KBJ_LD_OF(nobs)  (((nobs) + 3) & ~3)
 
 /* Offsets of the pieces of a packed observation row, in the order run_actor / run_critic concatenate them (train.py:1367-1374,
  * 1410-1430); the first 65 entries are common to both rows, the critic's privileged pieces follow. Divisors as train.py:1336, 1427.
@@ -133,7 +140,9 @@ typedef struct kbj_config {
   int32_t solver_newton;     /* 1 = Newton direction (default), 0 = Polak-Ribiere CG */
   int32_t deterministic;     /* 1 = the PPO update reduces in a fixed order (split-K slabs, per-block partials) instead of with fp32 / fp64 atomics:
                                 two updates from the same state give bit-identical parameters, as the reference's XLA program does; default 0 */
-  int32_t reserved_i[3];
+  int32_t extra_obs_actor;   /* floats the host appends to every actor / critic observation row (0..KBJ_MAX_EXTRA_OBS, default 0): the input */
+  int32_t extra_obs_critic;  /* projections are [H][65 + extra] / [H][475 + extra], the parameter vector grows accordingly */
+  int32_t reserved_i[1];
   float dt;                  /* 0.004 */
   float ctrl_dt;             /* 0.02  */
   float solver_tolerance;    /* 1e-8 */

@@ -59,10 +59,13 @@ int kbj_check_config(const kbj_config* cfg, char* why, size_t why_bytes) {
   if (cfg->solver_newton != 1) return fail("only the Newton solver is implemented on the GPU (solver_newton = 1)");
   if (cfg->hidden_size < 1 || cfg->hidden_size > 256 || cfg->depth < 1 || cfg->depth > KBJ_MAX_DEPTH)
     return fail("hidden_size must be in 1..256 (multiples of 64 run unpadded) and depth in 1..4 (train.py:78-85 defaults 128 / 2, launch 256 / 2)");
+  if (cfg->extra_obs_actor < 0 || cfg->extra_obs_actor > KBJ_MAX_EXTRA_OBS || cfg->extra_obs_critic < 0 || cfg->extra_obs_critic > KBJ_MAX_EXTRA_OBS)
+    return fail("extra_obs_actor / extra_obs_critic must be in 0.." + std::to_string(KBJ_MAX_EXTRA_OBS));
   const unsigned long long lim = 1ull << 31;
   const unsigned long long Hp = (unsigned long long)((cfg->hidden_size + 63) / 64 * 64), T = (unsigned long long)cfg->rollout_len;
   const unsigned long long B = (unsigned long long)(cfg->batch_size > 0 ? cfg->batch_size : cfg->num_envs), N = (unsigned long long)cfg->num_envs;
-  const unsigned long long wide = 4 * Hp > KBJ_LD_CRITIC ? 4 * Hp : KBJ_LD_CRITIC;
+  const unsigned long long ldc = (unsigned long long)KBJ_LD_OF(KBJ_NOBS_CRITIC + cfg->extra_obs_critic);
+  const unsigned long long wide = 4 * Hp > ldc ? 4 * Hp : ldc;
   if (T * B * wide * sizeof(float) >= lim)
     return fail("rollout_len x batch_size x max(4 hidden_size, 476) x 4 bytes reaches 2 GiB: the minibatch's stash arrays are addressed with 32-bit "
                 "byte offsets (buffer loads) - use a smaller batch_size (" + std::to_string(T * B * wide * sizeof(float)) + " bytes)");

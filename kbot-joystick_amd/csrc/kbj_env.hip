@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64) void env_reset_kernel(const kbj_model* __restri
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
   const PhysConst& pc = S.pc;
   task_reset(S, *m, *c, pc, rng);
-  task_write_obs(S, *m, *c, rng, actor0 + (size_t)env * KBJ_LD_ACTOR, critic0 + (size_t)env * KBJ_LD_CRITIC, aux0 + (size_t)env * KBJ_AUX_SIZE);
+  task_write_obs(S, *m, *c, rng, actor0 + (size_t)env * KBJ_LD_OF(KBJ_NOBS_ACTOR + c->extra_obs_actor), critic0 + (size_t)env * KBJ_LD_OF(KBJ_NOBS_CRITIC + c->extra_obs_critic), aux0 + (size_t)env * KBJ_AUX_SIZE);
   PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
   PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
 }
@@ -47,7 +47,7 @@ __global__ __launch_bounds__(64) void env_reset_where_kernel(const kbj_model* __
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
   const PhysConst& pc = S.pc;
   task_reset(S, *m, *c, pc, rng);
-  task_write_obs(S, *m, *c, rng, actor_next + (size_t)env * KBJ_LD_ACTOR, critic_next + (size_t)env * KBJ_LD_CRITIC, aux_next + (size_t)env * KBJ_AUX_SIZE);
+  task_write_obs(S, *m, *c, rng, actor_next + (size_t)env * KBJ_LD_OF(KBJ_NOBS_ACTOR + c->extra_obs_actor), critic_next + (size_t)env * KBJ_LD_OF(KBJ_NOBS_CRITIC + c->extra_obs_critic), aux_next + (size_t)env * KBJ_AUX_SIZE);
   PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
   PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
 }
@@ -55,20 +55,20 @@ __global__ __launch_bounds__(64) void env_reset_where_kernel(const kbj_model* __
 // overwrite the joystick command of the envs whose mask entry is non-zero (mask == nullptr: all envs): the env's state row (the next step's
 // rewards and its command-switch draw start from it) and the command columns of the NEXT observation rows + aux record, zero-command flag
 // included — what task_write_obs wrote there from the kernel's own command. One thread per (env, command slot).
-__global__ __launch_bounds__(256) void env_set_command_kernel(int N, float* __restrict__ es, const float* __restrict__ mask, const float* __restrict__ cmd, float* actor_next,
+__global__ __launch_bounds__(256) void env_set_command_kernel(int N, int lda, int ldc, float* __restrict__ es, const float* __restrict__ mask, const float* __restrict__ cmd, float* actor_next,
                                                               float* critic_next, float* aux_next) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x, env = i / KBJ_NCMD, k = i % KBJ_NCMD;
   if (env >= N || (mask && mask[env] == 0.0f)) return;
   const float* c = cmd + (size_t)env * KBJ_NCMD;
   const float v = c[k];
   es[(size_t)env * KBJ_ES_SIZE + KBJ_ES_CMD + k] = v;
-  actor_next[(size_t)env * KBJ_LD_ACTOR + KBJ_OBS_CMD + k] = v;
-  critic_next[(size_t)env * KBJ_LD_CRITIC + KBJ_OBS_CMD + k] = v;
+  actor_next[(size_t)env * lda + KBJ_OBS_CMD + k] = v;
+  critic_next[(size_t)env * ldc + KBJ_OBS_CMD + k] = v;
   aux_next[(size_t)env * KBJ_AUX_SIZE + KBJ_AUX_CMD + k] = v;
   if (k == 0) {
     const float zc = sqrtf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]) < 1e-3f ? 1.0f : 0.0f;
-    actor_next[(size_t)env * KBJ_LD_ACTOR + KBJ_OBS_ZEROCMD] = zc;
-    critic_next[(size_t)env * KBJ_LD_CRITIC + KBJ_OBS_ZEROCMD] = zc;
+    actor_next[(size_t)env * lda + KBJ_OBS_ZEROCMD] = zc;
+    critic_next[(size_t)env * ldc + KBJ_OBS_ZEROCMD] = zc;
   }
 }
 
@@ -94,8 +94,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR
   Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
   const PhysConst& pc = S.pc;
   KBJ_STAMP(18);
-  task_step(S, *m, *c, pc, rng, action + (size_t)env * KBJ_NU, aux_t + (size_t)env * KBJ_AUX_SIZE, actor_next + (size_t)env * KBJ_LD_ACTOR,
-            critic_next + (size_t)env * KBJ_LD_CRITIC, aux_next + (size_t)env * KBJ_AUX_SIZE);
+  task_step(S, *m, *c, pc, rng, action + (size_t)env * KBJ_NU, aux_t + (size_t)env * KBJ_AUX_SIZE, actor_next + (size_t)env * KBJ_LD_OF(KBJ_NOBS_ACTOR + c->extra_obs_actor),
+            critic_next + (size_t)env * KBJ_LD_OF(KBJ_NOBS_CRITIC + c->extra_obs_critic), aux_next + (size_t)env * KBJ_AUX_SIZE);
   if (S.done) PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
   PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
   KBJ_STAMP(19);
@@ -268,7 +268,8 @@ int kbj_env_set_command(kbj_ctx* ctx, const float* mask_d, const float* cmd_d, f
   if (!ctx || !cmd_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_set_command: null argument");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   const int N = ctx->cfg_h.num_envs, n = N * KBJ_NCMD;
-  hipLaunchKernelGGL(env_set_command_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, N, ctx->es_d, mask_d, cmd_d, actor_next_d, critic_next_d, aux_next_d);
+  hipLaunchKernelGGL(env_set_command_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, N, KBJ_LD_OF(KBJ_NOBS_ACTOR + ctx->cfg_h.extra_obs_actor),
+                     KBJ_LD_OF(KBJ_NOBS_CRITIC + ctx->cfg_h.extra_obs_critic), ctx->es_d, mask_d, cmd_d, actor_next_d, critic_next_d, aux_next_d);
   KBJ_CHECK_LAUNCH(ctx, "env_set_command_kernel");
   return 0;
 }

@@ -222,8 +222,9 @@ KBJ_DEV void task_write_obs(KbjShared& S, const kbj_model& m, const kbj_config& 
       encode_pg(S.pg, o);
       for (int k = 0; k < 5; ++k) critic[KBJ_OBS_PG + k] = o[k];
       actor[KBJ_OBS_ZEROCMD] = zc; critic[KBJ_OBS_ZEROCMD] = zc;
-      for (int k = KBJ_NOBS_ACTOR; k < KBJ_LD_ACTOR; ++k) actor[k] = 0;
-      for (int k = KBJ_NOBS_CRITIC; k < KBJ_LD_CRITIC; ++k) critic[k] = 0;
+      // behind the reference's columns: user observation slots (the host fills them after the step) and the pad to the 16-byte row stride
+      for (int k = KBJ_NOBS_ACTOR; k < KBJ_LD_OF(KBJ_NOBS_ACTOR + c.extra_obs_actor); ++k) actor[k] = 0;
+      for (int k = KBJ_NOBS_CRITIC; k < KBJ_LD_OF(KBJ_NOBS_CRITIC + c.extra_obs_critic); ++k) critic[k] = 0;
       critic[KBJ_OBS_TOUCH] = S.touch[0]; critic[KBJ_OBS_TOUCH + 1] = S.touch[1];
       aux[KBJ_AUX_TOUCH] = S.touch[0]; aux[KBJ_AUX_TOUCH + 1] = S.touch[1];
       for (int k = 0; k < 3; ++k) { critic[KBJ_OBS_BASEPOS + k] = es[KBJ_ES_QPOS + k]; critic[KBJ_OBS_LINVEL + k] = es[KBJ_ES_QVEL + k]; critic[KBJ_OBS_ANGVEL + k] = es[KBJ_ES_QVEL + 3 + k]; }

@@ -98,13 +98,13 @@ struct NnWs {
 
 NnWs* ws_of(kbj_ctx* ctx) { return reinterpret_cast<NnWs*>(ctx->nn_ws); }
 
-void layout_params(NnWs& w, int H, int D) {
+void layout_params(NnWs& w, int H, int D, int extra_actor = 0, int extra_critic = 0) {
   w.D = D;
   size_t off = 0;
   for (int n = 0; n < 2; ++n) {
     NetOff& o = w.net[n];
-    o.nin = n == 0 ? KBJ_NOBS_ACTOR : KBJ_NOBS_CRITIC;
-    o.ld_obs = n == 0 ? KBJ_LD_ACTOR : KBJ_LD_CRITIC;
+    o.nin = n == 0 ? KBJ_NOBS_ACTOR + extra_actor : KBJ_NOBS_CRITIC + extra_critic;     // user observation columns behind the reference's (kbj_model.h)
+    o.ld_obs = KBJ_LD_OF(o.nin);
     o.nout = n == 0 ? 2 * KBJ_NU : 1;
     o.w_in = off; off += (size_t)H * o.nin;
     o.b_in = off; off += H;
@@ -123,7 +123,9 @@ void layout_params(NnWs& w, int H, int D) {
 // Mirror of the packed observation rows as (source index, multiplier, offset) per element (mirror_rows_kernel).
 // Follows the index/sign lists of the reference's mirror_obs functions (train.py:1574-1756); element order = the obs packing
 // of kbj_env_task.h write_obs (kbj_model.h KBJ_NOBS_*).
-void build_mirror_tables(const kbj_model& m, std::vector<MirrorEntry>& ta, std::vector<MirrorEntry>& tc) {
+// extra_actor / extra_critic user columns behind the reference's are carried over unchanged (identity entries): a user term that is not
+// mirror-invariant has to be mirrored by the user's own mirror-loss code, as in the reference (train.py:1574-1756 names every key).
+void build_mirror_tables(const kbj_model& m, std::vector<MirrorEntry>& ta, std::vector<MirrorEntry>& tc, int extra_actor = 0, int extra_critic = 0) {
   auto swp = [](int i) { return i < 5 ? i + 5 : (i < 10 ? i - 5 : i); };  // left leg <-> right leg, arms stay (train.py:1574-1582)
   tc.assign(KBJ_LD_CRITIC, MirrorEntry{0, 0.0f, 0.0f});
   for (int k = 0; k < KBJ_LD_CRITIC; ++k) tc[k].src = k;
@@ -158,6 +160,12 @@ void build_mirror_tables(const kbj_model& m, std::vector<MirrorEntry>& ta, std::
   keep(KBJ_OBS_ANGVEL, -1); keep(KBJ_OBS_ANGVEL + 1, 1); keep(KBJ_OBS_ANGVEL + 2, -1);    // base angular velocity
   keep(KBJ_OBS_HEIGHT, 1);                                                                 // base height
   for (int k = KBJ_NOBS_CRITIC; k < KBJ_LD_CRITIC; ++k) tc[k] = MirrorEntry{k, 0.0f, 0.0f};
+  auto widen = [](std::vector<MirrorEntry>& t, int nobs, int extra) {
+    t.resize(KBJ_LD_OF(nobs + extra));
+    for (int k = nobs; k < (int)t.size(); ++k) t[k] = MirrorEntry{k, k < nobs + extra ? 1.0f : 0.0f, 0.0f};
+  };
+  if (extra_actor > 0) widen(ta, KBJ_NOBS_ACTOR, extra_actor);
+  if (extra_critic > 0) widen(tc, KBJ_NOBS_CRITIC, extra_critic);
 }
 
 template <class T> int dalloc(kbj_ctx* ctx, NnWs& w, T** p, size_t count) {
@@ -384,12 +392,12 @@ int kbj_nn_create(kbj_ctx* ctx) {
   const kbj_config& c = ctx->cfg_h;
   w->Hu = c.hidden_size; w->H = (c.hidden_size + 63) / 64 * 64; w->N = c.num_envs; w->B = c.batch_size; w->T = c.rollout_len;
   if (w->B <= 0 || w->B > w->N) return kbj_fail(ctx, "kbj_create: batch_size must be in [1, num_envs]");
-  layout_params(*w, w->H, ctx->cfg_h.depth);
+  layout_params(*w, w->H, ctx->cfg_h.depth, ctx->cfg_h.extra_obs_actor, ctx->cfg_h.extra_obs_critic);
   size_t N = w->N, H = w->H, B = w->B, T = w->T;
   w->unparams = w->nparams; w->unactor = w->nactor;
   if (w->padded()) {
     NnWs u;
-    layout_params(u, w->Hu, c.depth);
+    layout_params(u, w->Hu, c.depth, c.extra_obs_actor, c.extra_obs_critic);
     w->unparams = u.nparams; w->unactor = u.nactor;
     std::vector<PadDesc> pd;
     const int Hu = w->Hu, Hi = w->H;
@@ -426,11 +434,11 @@ int kbj_nn_create(kbj_ctx* ctx) {
   size_t R = T * B;
   if (w->mirror) {
     std::vector<MirrorEntry> ta, tc;
-    build_mirror_tables(ctx->model_h, ta, tc);
+    build_mirror_tables(ctx->model_h, ta, tc, ctx->cfg_h.extra_obs_actor, ctx->cfg_h.extra_obs_critic);
     if (dalloc(ctx, *w, &w->mtab[0], ta.size()) || dalloc(ctx, *w, &w->mtab[1], tc.size())) return -1;
     if (hipMemcpy(w->mtab[0], ta.data(), ta.size() * sizeof(MirrorEntry), hipMemcpyHostToDevice) != hipSuccess ||
         hipMemcpy(w->mtab[1], tc.data(), tc.size() * sizeof(MirrorEntry), hipMemcpyHostToDevice) != hipSuccess) return kbj_fail(ctx, "hipMemcpy mirror tables");
-    if (dalloc(ctx, *w, &w->rObsM[0], N * KBJ_LD_ACTOR) || dalloc(ctx, *w, &w->rObsM[1], N * KBJ_LD_CRITIC)) return -1;
+    if (dalloc(ctx, *w, &w->rObsM[0], N * w->net[0].ld_obs) || dalloc(ctx, *w, &w->rObsM[1], N * w->net[1].ld_obs)) return -1;
     float** rs[] = {&w->value_m, &w->dvalue_m, &w->zeroR};
     for (float** p : rs) if (dalloc(ctx, *w, p, R)) return -1;
     float** r20[] = {&w->y_m, &w->sd_m, &w->dy, &w->dy_m};
@@ -462,10 +470,10 @@ int kbj_nn_create(kbj_ctx* ctx) {
   if (dalloc(ctx, *w, &w->sd, R * KBJ_NU)) return -1;
   if (dalloc(ctx, *w, &w->lpf0, B * KBJ_NU)) return -1;
   if (dalloc(ctx, *w, &w->stats, 16)) return -1;
-  if (dalloc(ctx, *w, &w->Weff, 4 * H * KBJ_LD_ACTOR) || dalloc(ctx, *w, &w->beff, 4 * H)) return -1;
+  if (dalloc(ctx, *w, &w->Weff, (size_t)4 * H * w->net[0].ld_obs) || dalloc(ctx, *w, &w->beff, 4 * H)) return -1;
   for (int n = 0; n < w->nnets; ++n) if (dalloc(ctx, *w, &w->Zeff[n], 4 * H * w->net[n & 1].ld_obs)) return -1;
   for (int k = 0; k < 2; ++k) if (dalloc(ctx, *w, &w->WinP[k], H * w->net[k].ld_obs)) return -1;
-  if (hipMemset(w->Weff, 0, 4 * H * KBJ_LD_ACTOR * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset Weff");
+  if (hipMemset(w->Weff, 0, (size_t)4 * H * w->net[0].ld_obs * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset Weff");
   if (dalloc(ctx, *w, &w->seq_counters, 2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS)) return -1;
   w->bwd_progress = w->seq_counters + 2 * MAXD * 4 * SEQ_COUNTER_WORDS;   // same allocation: one clear covers both   // [phase: forward layer l = l, backward layer l = D + l][net][row group x unit group]
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
@@ -566,7 +574,7 @@ const float* fold_actor_weights(kbj_ctx* ctx, hipStream_t s, const float* params
   const int H = w.H;
   if (!w.sched.rollout_step || w.net[0].ld_obs != KBJ_LD_ACTOR || !w.sched.fold_actor) return nullptr;
   const NetOff& oa = w.net[0];
-  GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, KBJ_LD_ACTOR, 0, 1, nullptr};
+  GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, oa.ld_obs, 0, 1, nullptr};
   gemm_launch<true, false>(s, g);
   hipLaunchKernelGGL(matvec_kernel, dim3((4 * H + 3) / 4), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
   return w.Weff;
@@ -581,7 +589,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
   const bool fused_any = w.sched.rollout_step;
   const float* obs_base[2] = {actor_obs_d, critic_obs_d};
   float* hc[4] = {carry->actor_hc_d, carry->critic_hc_d, carry->actor_mirror_hc_d, carry->critic_mirror_hc_d};
-  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
+  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha, w.net[0].ld_obs};
   for (int n = net_lo; n < net_hi; ++n) {
     const int k = n & 1;
     const NetOff& o = w.net[k];
@@ -605,7 +613,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
         const float* h_in = h_plane(w, hc[n], n, l, n0, parity != 0);
         float* h_out = h_plane(w, hc[n], n, l, n0, parity == 0);
         StepArgs sa{x, H, 0, params_d + o.w_ih[l], H, params_d + o.w_hh[l], params_d + o.b[l], h_in, h_out, cc, cnt};
-        if (l == 0 && folded) { sa.X = obs; sa.ldx = o.ld_obs; sa.kx = o.nin; sa.Wih = weff; sa.ldw = KBJ_LD_ACTOR; sa.bias = w.beff; }
+        if (l == 0 && folded) { sa.X = obs; sa.ldx = o.ld_obs; sa.kx = o.nin; sa.Wih = weff; sa.ldw = o.ld_obs; sa.bias = w.beff; }
         if (lstm_step(ctx, s, H, sa)) return -1;
         x = h_out;
         continue;
@@ -634,7 +642,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
     }
     // n == 2: the mirrored actor only advances its low-pass state (no sample)
     linear_fwd(s, x, H, params_d + o.w_out, H, params_d + o.b_out, Out, 40, cnt, o.nout, H, 0);
-    hipLaunchKernelGGL(actor_head_lpf_kernel, g1((size_t)cnt * KBJ_NU), dim3(256), 0, s, Out, obs, carry->lpf_mirror_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, c.lpf_alpha, cnt);
+    hipLaunchKernelGGL(actor_head_lpf_kernel, g1((size_t)cnt * KBJ_NU), dim3(256), 0, s, Out, obs, carry->lpf_mirror_d + (size_t)n0 * KBJ_NU, w.joint_bias_d, c.lpf_alpha, cnt, w.net[0].ld_obs);
   }
   return 0;
 }
@@ -722,15 +730,15 @@ int kbj_mirror_table(const void* model_blob, size_t model_bytes, int critic, int
   return (int)t.size();
 }
 
-size_t kbj_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size, cfg->depth); return w.nparams; }
-size_t kbj_actor_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size, cfg->depth); return w.nactor; }
+size_t kbj_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size, cfg->depth, cfg->extra_obs_actor, cfg->extra_obs_critic); return w.nparams; }
+size_t kbj_actor_param_count(const kbj_config* cfg) { NnWs w; layout_params(w, cfg->hidden_size, cfg->depth, cfg->extra_obs_actor, cfg->extra_obs_critic); return w.nactor; }
 
 int kbj_init_params(kbj_ctx* ctx, uint32_t seed, float* params_d) {
   if (!ctx || !params_d) return kbj_fail(ctx, "kbj_init_params: null argument");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   NnWs& w = *ws_of(ctx);
   NnWs u;                                // the caller's layout: fan-ins and offsets follow its hidden_size, not the kernels' padded one
-  layout_params(u, w.Hu, w.D);
+  layout_params(u, w.Hu, w.D, ctx->cfg_h.extra_obs_actor, ctx->cfg_h.extra_obs_critic);
   int H = w.Hu;
   uint32_t leaf = 0;
   auto fill = [&](size_t off, size_t n, int fan_in) {
@@ -813,7 +821,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
     return rc;
   }
   hipStream_t s = ctx->stream;
-  size_t la = KBJ_LD_ACTOR, lc = KBJ_LD_CRITIC, lx = KBJ_AUX_SIZE;
+  size_t la = w.net[0].ld_obs, lc = w.net[1].ld_obs, lx = KBJ_AUX_SIZE;
   // observation row T of the previous rollout is row 0 of this one
   KBJ_HIP(ctx, hipMemcpyAsync(tr->actor_obs_d, tr->actor_obs_d + (size_t)T * N * la, N * la * sizeof(float), hipMemcpyDeviceToDevice, s));
   KBJ_HIP(ctx, hipMemcpyAsync(tr->critic_obs_d, tr->critic_obs_d + (size_t)T * N * lc, N * lc * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -917,7 +925,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     // (W_ih0 b_in + b_0): a 65-deep contraction instead of 65 -> H -> 4H (6.8 instead of 28.5 GFLOP per minibatch forward, and
     // 6.8 instead of 55 GFLOP backward). Same function, different rounding order (inside the parity tolerances).
     const NetOff& oa = w.net[0];
-    GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, KBJ_LD_ACTOR, 0, 1, nullptr};
+    GemmArgs g{params_d + oa.w_ih[0], params_d + oa.w_in, w.Weff, nullptr, 4 * H, oa.nin, H, H, oa.nin, oa.ld_obs, 0, 1, nullptr};
     gemm_launch<true, false>(s, g);
     hipLaunchKernelGGL(matvec_kernel, dim3((4 * H + 3) / 4), dim3(256), 0, s, params_d + oa.w_ih[0], params_d + oa.b_in, params_d + oa.b[0], 4 * H, H, w.beff);
   }
@@ -932,8 +940,8 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
   // gathered copy, which the backward pass and the mirror branch want, is made on the critic's side lane, off the chain that starts the
   // critic's first recurrence. (One stream, mirror branches or an unfolded actor: gathered in front of the projection as before.)
   const bool gather_late = !sc.one_stream && !w.mirror && sc.fold_actor;
-  if (!gather_late) gather(ns[1], tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);
-  gather(s, tr->actor_obs_d, KBJ_LD_ACTOR, KBJ_LD_ACTOR, w.tb[0].obs, KBJ_LD_ACTOR);
+  if (!gather_late) gather(ns[1], tr->critic_obs_d, w.net[1].ld_obs, w.net[1].ld_obs, w.tb[1].obs, w.net[1].ld_obs);
+  gather(s, tr->actor_obs_d, w.net[0].ld_obs, w.net[0].ld_obs, w.tb[0].obs, w.net[0].ld_obs);
   GatherSmallArgs gs{tr->action_d, grad ? tr->logp_d : nullptr, grad ? tr->value_d : nullptr, adv_d, target_d, tr->aux_d, w.act, w.logp_old, w.val_old, w.adv, w.target, w.keep};
   hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R), dim3(256), 0, s, gs, idx, T, N, B, KBJ_NU + 4, KBJ_NU + 5);   // keep flags: all the recurrences need of these
   const float* carry0[4] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d, tr->carry0_actor_mirror_hc_d, tr->carry0_critic_mirror_hc_d};
@@ -1007,7 +1015,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
       // the copy behind the projection, under the recurrences (beside it the two would share HBM: 175 instead of 144 us for the GEMM)
       KBJ_HIP(ctx, hipEventRecord(ctx->ev_obs, ns[1]));
       KBJ_HIP(ctx, hipStreamWaitEvent(ctx->side[1], ctx->ev_obs, 0));
-      if (grad) gather(ctx->side[1], tr->critic_obs_d, KBJ_LD_CRITIC, KBJ_LD_CRITIC, w.tb[1].obs, KBJ_LD_CRITIC);   // the forward-only pass never reads the copy
+      if (grad) gather(ctx->side[1], tr->critic_obs_d, w.net[1].ld_obs, w.net[1].ld_obs, w.tb[1].obs, w.net[1].ld_obs);   // the forward-only pass never reads the copy
       KBJ_HIP(ctx, hipEventRecord(ctx->ev_obs, ctx->side[1]));
       continue;
     }
@@ -1018,7 +1026,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
-      if (sc.fold_actor && (n & 1) == 0 && l == 0) { if (!fuse_obs) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, KBJ_LD_ACTOR, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0); }
+      if (sc.fold_actor && (n & 1) == 0 && l == 0) { if (!fuse_obs) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, o.ld_obs, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0); }
       else if (!fuse_ih) linear_fwd(ns[n & 1], l == 0 ? t.X0 : t.Hout[l - 1], H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
     }
     for (int n = 0; n < w.nnets; ++n) {
@@ -1026,7 +1034,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
       TrainBufs& t = w.tb[n];
       SeqFwdArgs fa{t.G[l], params_d + o.w_hh[l], t.Hm[l], t.Cm[l], t.Hout[l], t.TanhC[l], w.keep, w.seq_counters + SEQ_COUNTER_WORDS * (4 * l + n), w.seq_err, T, B, (n == stamp_net && l == stamp_layer) ? w.seq_stamps : nullptr};
       if (sc.fold_actor && (n & 1) == 0 && l == 0) {
-        if (fuse_obs) { fa.X = t.obs; fa.ldx = o.ld_obs; fa.Wih = w.Weff; fa.ldw = KBJ_LD_ACTOR; fa.bias = w.beff; fa.kx = o.nin; }   // gates_0 = obs Weff^T + beff inside the recurrence
+        if (fuse_obs) { fa.X = t.obs; fa.ldx = o.ld_obs; fa.Wih = w.Weff; fa.ldw = o.ld_obs; fa.bias = w.beff; fa.kx = o.nin; }   // gates_0 = obs Weff^T + beff inside the recurrence
       } else if (fuse_ih) {   // K = H input projections ride inside the recurrence (kbj_lstm_seq.h FUSE)
         fa.X = l == 0 ? t.X0 : t.Hout[l - 1]; fa.Wih = params_d + o.w_ih[l]; fa.bias = params_d + o.b[l];
       }
@@ -1063,7 +1071,7 @@ int kbj_ppo_forward(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, con
     const NetOff& o = w.net[n];
     linear_fwd(ns[n], w.tb[n].Hout[D - 1], H, params_d + o.w_out, H, params_d + o.b_out, w.tb[n].Out, 40, R, o.nout, H, 0);
   }
-  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
+  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha, w.net[0].ld_obs};
   hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.tb[0].obs, w.joint_bias_d, hp, R, w.y, w.sd);
   hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0, hp, T, B, w.y);
   hipLaunchKernelGGL(gaussian_logp_kernel, g1(R), dim3(256), 0, s, w.y, w.sd, w.act, R, out->logp_d, out->entropy_d ? out->entropy_d : w.ent);
@@ -1119,7 +1127,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // heads and losses: the policy terms need the actor only, the value terms the critic only (the mirror terms likewise), so each lane
   // computes its own and the two chains stay independent through the whole call: the shorter actor chain runs ahead, and its
   // recurrences meet the critic's GEMM phases instead of the critic's recurrences
-  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha};
+  HeadParams hp{c.min_std, c.max_std, c.var_scale, c.lpf_alpha, w.net[0].ld_obs};
   PpoParams pp{c.clip_param, c.value_clip, c.value_loss_coef, c.entropy_coef, c.log_ratio_clip, c.adv_eps};
   hipLaunchKernelGGL(actor_head_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.tb[0].obs, w.joint_bias_d, hp, R, w.y, w.sd);
   hipLaunchKernelGGL(actor_head_train_fwd_kernel, g1((size_t)B * KBJ_NU, 64), dim3(64), 0, s, w.keep, w.lpf0, hp, T, B, w.y);

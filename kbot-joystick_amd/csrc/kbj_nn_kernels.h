@@ -55,7 +55,7 @@ __device__ __forceinline__ void nn_threefry(uint32_t k0, uint32_t k1, uint32_t c
 }
 
 // ---- actor head at rollout time (train.py:924-941, 1545-1572): 32 lanes per env, one per joint (20 active) --------------
-struct HeadParams { float min_std, max_std, var_scale, alpha; };
+struct HeadParams { float min_std, max_std, var_scale, alpha; int ld_obs; };   // ld_obs: stride of the actor observation rows (68 + user columns)
 // The rollout's actor head as ONE launch on the env -> actor -> env chain: output projection (H -> 40), low-pass, Gaussian sample and
 // log-prob. (As a 64x64-tile GEMM the 40-column projection was 45 us of mostly latency at 8192 envs, the sampling kernel 22 us more.)
 // It runs beside the critic's GEMMs of the same step, which hold most of every CU's LDS and registers, so it is built to fit in the
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(64 * HEAD_WAVES) void actor_head_fused_kernel(const
       float lp = 0;
       if (n < N) {
         const float om = outs[wv][e][j] + bout[j], os = outs[wv][e][KBJ_NU + j] + bout[KBJ_NU + j];
-        float mean = om + joint_bias[j] + (j >= 10 ? obs[(size_t)n * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
+        float mean = om + joint_bias[j] + (j >= 10 ? obs[(size_t)n * hp.ld_obs + KBJ_OBS_CMD + 6 + (j - 10)] : 0.0f);
         float sd = fminf((softplusf_(os) + hp.min_std) * hp.var_scale, hp.max_std);
         float y0 = lpf[n * KBJ_NU + j];
         float y = y0 + hp.alpha * (mean - y0);
@@ -230,7 +230,7 @@ __global__ void actor_head_pre_kernel(const float* __restrict__ out, const float
   if (i >= (size_t)R * KBJ_NU) return;
   size_t r = i / KBJ_NU;
   int j = (int)(i - r * KBJ_NU);
-  y[i] = out[r * 40 + j] + joint_bias[j] + (j >= 10 ? obs[r * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
+  y[i] = out[r * 40 + j] + joint_bias[j] + (j >= 10 ? obs[r * hp.ld_obs + KBJ_OBS_CMD + 6 + (j - 10)] : 0.0f);
   sd[i] = fminf((softplusf_(out[r * 40 + KBJ_NU + j]) + hp.min_std) * hp.var_scale, hp.max_std);
 }
 // stage 2 (one thread per (b, j), serial in t): one-pole low-pass over the means in place, state reset where done
@@ -398,11 +398,11 @@ __global__ void mirror_rows_kernel(const float* __restrict__ in, float* __restri
 }
 // mirror branch of the actor head at rollout time: only the low-pass state advances (no sampling)
 __global__ void actor_head_lpf_kernel(const float* __restrict__ out, const float* __restrict__ obs, float* __restrict__ lpf,
-                                      const float* __restrict__ joint_bias, float alpha, int N) {
+                                      const float* __restrict__ joint_bias, float alpha, int N, int ld_obs) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N * KBJ_NU) return;
   int n = i / KBJ_NU, j = i % KBJ_NU;
-  float mean = out[n * 40 + j] + joint_bias[j] + (j >= 10 ? obs[(size_t)n * KBJ_LD_ACTOR + KBJ_NOBS_ACTOR - 20 + j] : 0.0f);
+  float mean = out[n * 40 + j] + joint_bias[j] + (j >= 10 ? obs[(size_t)n * ld_obs + KBJ_OBS_CMD + 6 + (j - 10)] : 0.0f);
   float y0 = lpf[i];
   lpf[i] = y0 + alpha * (mean - y0);
 }

@@ -34,11 +34,13 @@ class CarryBuffers:
 class TrajBuffers:
     """One rollout's worth of trajectory arrays ([T(+1)][N][dim], time-major)."""
 
-    def __init__(self, T: int, N: int, H: int, depth: int, device, mirror: bool = False, reward_comps: bool = False):
+    def __init__(self, T: int, N: int, H: int, depth: int, device, mirror: bool = False, reward_comps: bool = False,
+                 ld_actor: int = L.LD_ACTOR, ld_critic: int = L.LD_CRITIC):
+        """ld_actor / ld_critic: row strides of the context's observation rows (layout.obs_widths(kbj_config): 68 / 476 plus user columns)."""
         self.T, self.N = T, N
         z = lambda *s: torch.zeros(*s, device=device)
-        self.actor_obs = z(T + 1, N, L.LD_ACTOR)
-        self.critic_obs = z(T + 1, N, L.LD_CRITIC)
+        self.actor_obs = z(T + 1, N, ld_actor)
+        self.critic_obs = z(T + 1, N, ld_critic)
         self.aux = z(T + 1, N, L.AUX["SIZE"])
         self.action = z(T, N, L.NU)
         self.logp = z(T, N)

@@ -44,10 +44,10 @@ def _read_blobs(data: bytes, count: Optional[int] = None):
     return out
 
 
-def split_leaves(flat: np.ndarray, hidden_size: int, depth: int = 2):
-    """Flat fp32 parameter vector -> list of (name, array) in equinox leaf order."""
+def split_leaves(flat: np.ndarray, hidden_size: int, depth: int = 2, extra_obs=(0, 0)):
+    """Flat fp32 parameter vector -> list of (name, array) in equinox leaf order. extra_obs: user observation columns (actor, critic)."""
     out, off = [], 0
-    for name, shape in L.param_leaves(hidden_size, depth):
+    for name, shape in L.param_leaves(hidden_size, depth, extra_obs):
         n = int(np.prod(shape))
         out.append((name, np.asarray(flat[off:off + n], np.float32).reshape(shape)))
         off += n
@@ -56,8 +56,8 @@ def split_leaves(flat: np.ndarray, hidden_size: int, depth: int = 2):
     return out
 
 
-def join_leaves(leaves, hidden_size: int, depth: int = 2) -> np.ndarray:
-    want = L.param_leaves(hidden_size, depth)
+def join_leaves(leaves, hidden_size: int, depth: int = 2, extra_obs=(0, 0)) -> np.ndarray:
+    want = L.param_leaves(hidden_size, depth, extra_obs)
     if len(leaves) != len(want):
         raise ValueError(f"model_0 holds {len(leaves)} leaves, the layout for hidden_size {hidden_size} has {len(want)}")
     for a, (name, shape) in zip(leaves, want):
@@ -81,13 +81,13 @@ def _add(tar: tarfile.TarFile, name: str, data: bytes):
 
 
 def save_ckpt(path: str, params: np.ndarray, opt_m: np.ndarray, opt_v: np.ndarray, opt_count: int, hidden_size: int, depth: int,
-              state: dict, config: dict, extras: Optional[Dict[str, np.ndarray]] = None, schedule_count: Optional[int] = None) -> None:
+              state: dict, config: dict, extras: Optional[Dict[str, np.ndarray]] = None, schedule_count: Optional[int] = None, extra_obs=(0, 0)) -> None:
     """Write `ckpt.bin`. `extras` (name -> array) are this build's resume payload (kbj_* members). `schedule_count`: with a learning-rate
     schedule (train.py:1067-1077, either branch) optax's state tree ends in a ScaleByScheduleState(count) leaf - (count, mu.., nu.., count);
     pass the optimizer-step count to write that trailing leaf so that the reference's optimizer tree has as many leaves as the file."""
-    model = [a for _, a in split_leaves(np.asarray(params), hidden_size, depth)]
-    mu = [a for _, a in split_leaves(np.asarray(opt_m), hidden_size, depth)]
-    nu = [a for _, a in split_leaves(np.asarray(opt_v), hidden_size, depth)]
+    model = [a for _, a in split_leaves(np.asarray(params), hidden_size, depth, extra_obs)]
+    mu = [a for _, a in split_leaves(np.asarray(opt_m), hidden_size, depth, extra_obs)]
+    nu = [a for _, a in split_leaves(np.asarray(opt_v), hidden_size, depth, extra_obs)]
     import os
     tmp = path + ".tmp"        # never leave a truncated ckpt.bin behind: write beside it, flush to disk, then rename over it
     with open(tmp, "wb") as fh, tarfile.open(fileobj=fh, mode="w:gz") as tar:
@@ -124,10 +124,12 @@ def load_ckpt(path: str, part: str = "all", hidden_size: Optional[int] = None, d
         depth = int((config or {}).get("depth", depth))
     if hidden_size is None:
         raise ValueError("hidden_size is neither given nor stored in the checkpoint's config")
-    nleaf = len(L.param_leaves(hidden_size, depth))
+    # user observation columns (widened input projections): stored in the config member by the task that wrote the file
+    extra_obs = (int((config or {}).get("extra_actor_obs", 0) or 0), int((config or {}).get("extra_critic_obs", 0) or 0))
+    nleaf = len(L.param_leaves(hidden_size, depth, extra_obs))
 
     def model():
-        return join_leaves(_read_blobs(members["model_0"]), hidden_size, depth)
+        return join_leaves(_read_blobs(members["model_0"]), hidden_size, depth, extra_obs)
 
     def opt_state():
         """optax state leaves: adam / adamw = ScaleByAdamState(count, mu, nu) [+ ...]; with a schedule (train.py:1067-1077) optax adds a
@@ -142,7 +144,7 @@ def load_ckpt(path: str, part: str = "all", hidden_size: Optional[int] = None, d
         if len(arrays) != 2 * nleaf:
             return None
         try:
-            return dict(count=counts[0] if counts else 0, counts=counts, mu=join_leaves(arrays[:nleaf], hidden_size, depth), nu=join_leaves(arrays[nleaf:], hidden_size, depth))
+            return dict(count=counts[0] if counts else 0, counts=counts, mu=join_leaves(arrays[:nleaf], hidden_size, depth, extra_obs), nu=join_leaves(arrays[nleaf:], hidden_size, depth, extra_obs))
         except ValueError:
             return None
 

@@ -89,6 +89,12 @@ class HumanoidWalkingTaskConfig:
     # bit-reproducible update: fixed-order reductions instead of fp32 / fp64 atomics in the gradient (kbj_config.deterministic); the
     # reference's XLA program is deterministic by default, here it costs a few percent and is off unless asked for
     deterministic: bool = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_DETERMINISTIC", "0") not in ("0", ""))
+    # user observations INTO the network rows (the reference's user appends terms to the lists run_actor / run_critic
+    # concatenate, train.py:1351-1433): that many floats are appended behind the reference's 65 / 475 columns of every observation row, the input
+    # projections and the parameter vector grow accordingly (kbj_config.extra_obs_*). Which terms fill them: HumanoidWalkingTask(
+    # extra_observations={name: (term, "actor" | "critic" | "both")}); the widths must add up. 0..64 each.
+    extra_actor_obs: int = 0
+    extra_critic_obs: int = 0
     # data-parallel variant: normalise a minibatch's advantages with the mean / variance of the GLOBAL minibatch (all
     # ranks' minibatches of that step: three scalars all-reduced per step) instead of each rank's own. With it the averaged gradient equals the
     # single-process gradient over the union of the ranks' minibatches. Off by default (what ksim does across devices is not visible).
@@ -118,7 +124,10 @@ class HumanoidWalkingTaskConfig:
                   drop_action_prob=self.drop_action_prob, var_scale=self.var_scale, entropy_coef=self.entropy_coef, gamma=self.gamma,
                   lam=self.lam, learning_rate=self.learning_rate, weight_decay=self.adam_weight_decay, switch_prob=self.ctrl_dt / 5,
                   actor_mirror_loss_scale=self.actor_mirror_loss_scale, critic_mirror_loss_scale=self.critic_mirror_loss_scale,
-                  lpf_alpha=self.ctrl_dt / (self.ctrl_dt + 1.0 / (2.0 * math.pi * self.cutoff_frequency)), deterministic=int(bool(self.deterministic)))
+                  lpf_alpha=self.ctrl_dt / (self.ctrl_dt + 1.0 / (2.0 * math.pi * self.cutoff_frequency)), deterministic=int(bool(self.deterministic)),
+                  extra_obs_actor=int(self.extra_actor_obs), extra_obs_critic=int(self.extra_critic_obs))
+        if not (0 <= self.extra_actor_obs <= L.MAX_EXTRA_OBS and 0 <= self.extra_critic_obs <= L.MAX_EXTRA_OBS):
+            raise ValueError(f"extra_actor_obs / extra_critic_obs must be in 0..{L.MAX_EXTRA_OBS}")
         if self.allreduce not in ("per_step", "per_pass"):
             raise ValueError(f"unknown allreduce mode {self.allreduce!r} (per_step | per_pass)")
         if self.terrain not in ("flat", "sine"):
@@ -191,7 +200,18 @@ class HumanoidWalkingTask:
         kbj_rollout fuses, bit-identical when no user term fires) instead of as one kbj_rollout call."""
         self.extra_rewards = dict(extra_rewards or {})
         self.extra_terminations = dict(extra_terminations or {})
-        self.extra_observations = dict(extra_observations or {})
+        # an observation term may be given as (term, into) with into in {"actor", "critic", "both"}: its output is then ALSO written into the
+        # networks' input rows, behind the reference's columns (config.extra_actor_obs / extra_critic_obs floats, in dictionary order)
+        self.extra_observations, self.extra_obs_into = {}, {}
+        for name, term in (extra_observations or {}).items():
+            into = None
+            if isinstance(term, tuple):
+                term, into = term
+            into = into if into is not None else getattr(term, "into", None)
+            if into not in (None, "actor", "critic", "both"):
+                raise ValueError(f"observation {name!r}: into must be 'actor', 'critic', 'both' or None, not {into!r}")
+            self.extra_observations[name], self.extra_obs_into[name] = term, into
+        self._obs_started = False
         self.command_term = command
         self._command_started = False
         self.extra_obs_buffers: dict = {}
@@ -223,7 +243,13 @@ class HumanoidWalkingTask:
         self.metrics = torch.zeros(10, device=self.device)
         self.mirror = config.actor_mirror_loss_scale != 0.0 or config.critic_mirror_loss_scale != 0.0
         self.carry = self.get_initial_model_carry()
-        self.traj = TrajBuffers(self.T, self.N, self.H, self.kcfg.depth, self.device, mirror=self.mirror, reward_comps=config.log_reward_components)
+        self.nobs_actor, self.nobs_critic, self.ld_actor, self.ld_critic = L.obs_widths(self.kcfg)
+        self.extra_obs = (int(self.kcfg.extra_obs_actor), int(self.kcfg.extra_obs_critic))
+        if any(self.extra_obs) and not any(v for v in self.extra_obs_into.values()):
+            raise ValueError("config.extra_actor_obs / extra_critic_obs reserve network inputs, but no observation term is routed into them "
+                             "(extra_observations={name: (term, 'actor' | 'critic' | 'both')})")
+        self.traj = TrajBuffers(self.T, self.N, self.H, self.kcfg.depth, self.device, mirror=self.mirror, reward_comps=config.log_reward_components,
+                                ld_actor=self.ld_actor, ld_critic=self.ld_critic)
         self.opt_step = 0
         self.iteration = 0
         self._perm_gen = torch.Generator(device="cpu")
@@ -278,6 +304,30 @@ class HumanoidWalkingTask:
             new = torch.where(fresh[:, None], new, term(prev, view, 1.0, g).reshape(n, L.NCMD).to(torch.float32))
         ctx.env_set_command(None, new.contiguous(), tr.actor_obs[row], tr.critic_obs[row], tr.aux[row])
 
+    def _observe_into_rows(self, tr, row: int, view) -> dict:
+        """Evaluate the user's Observation terms (train.py:635, 682, 706 protocol) on `view` and write those routed into the networks behind the
+        reference's columns of observation row `row` (actor: from column 65, critic: from 475, dictionary order). Returns {name: [N, d]}."""
+        off = {"actor": L.NOBS_ACTOR, "critic": L.NOBS_CRITIC}
+        rows = {"actor": tr.actor_obs[row], "critic": tr.critic_obs[row]}
+        lim = {"actor": self.nobs_actor, "critic": self.nobs_critic}
+        out = {}
+        for name, term in self.extra_observations.items():
+            v = term.observe(view, 1.0, None) if hasattr(term, "observe") else term(view)
+            v = v.reshape(view.N, -1).to(torch.float32)
+            out[name] = v
+            into = self.extra_obs_into.get(name)
+            for net in (("actor", "critic") if into == "both" else (into,) if into else ()):
+                if off[net] + v.shape[1] > lim[net]:
+                    raise B.KbjError(f"observation {name!r} ({v.shape[1]} floats) does not fit the {net} row: config.extra_{net}_obs reserves "
+                                     f"{lim[net] - (L.NOBS_ACTOR if net == 'actor' else L.NOBS_CRITIC)} floats")
+                rows[net][:, off[net]:off[net] + v.shape[1]] = v
+                off[net] += v.shape[1]
+        for net in ("actor", "critic"):
+            if any(i in (net, "both") for i in self.extra_obs_into.values()) and off[net] != lim[net]:
+                raise B.KbjError(f"the observation terms routed into the {net} fill {off[net] - (L.NOBS_ACTOR if net == 'actor' else L.NOBS_CRITIC)} "
+                                 f"floats, config.extra_{net}_obs says {lim[net] - (L.NOBS_ACTOR if net == 'actor' else L.NOBS_CRITIC)}")
+        return out
+
     def _rollout_stepwise(self):
         """kbj_rollout's steps as separate ABI calls with the user's Termination / Observation terms between the env step and the carry
         reset (train.py:817, 635 protocols on host/traj_view.StepView)."""
@@ -292,9 +342,8 @@ class HumanoidWalkingTask:
         first = self.iteration * T
 
         def observe(row: int, view):
-            for name, term in self.extra_observations.items():
-                v = term.observe(view, 1.0, None) if hasattr(term, "observe") else term(view)
-                v = v.reshape(self.N, -1).to(torch.float32)
+            vals = self._observe_into_rows(tr, row, view)
+            for name, v in vals.items():
                 if name not in self.extra_obs_buffers:
                     self.extra_obs_buffers[name] = torch.zeros(T + 1, self.N, v.shape[1], device=self.device)
                 self.extra_obs_buffers[name][row].copy_(v)
@@ -308,6 +357,9 @@ class HumanoidWalkingTask:
             self._command_started = True
         for name, buf in self.extra_obs_buffers.items():
             buf[0].copy_(buf[T])
+        if self.extra_observations and not self._obs_started:                 # the rows env_reset_all wrote carry zeros in the user columns
+            observe(0, StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob))
+            self._obs_started = True
         for t in range(T):
             c.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], self.carry.c, self.config.seed, first + t, False, tr.action[t], tr.logp[t], tr.value[t])
             c.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
@@ -487,7 +539,7 @@ class HumanoidWalkingTask:
         state = dict(num_steps=self.iteration, opt_step=self.opt_step, num_samples=self.iteration * self.N * self.T * self.world_size,
                      rank=self.rank, world_size=self.world_size)
         ckpt_io.save_ckpt(path, self.params.cpu().numpy(), self.opt_m.cpu().numpy(), self.opt_v.cpu().numpy(), self.opt_step, self.H, self.kcfg.depth,
-                          state, cfg, extras, schedule_count=self.opt_step if self.config.use_lr_decay else None)
+                          state, cfg, extras, schedule_count=self.opt_step if self.config.use_lr_decay else None, extra_obs=self.extra_obs)
 
     def load_checkpoint(self, path: str):
         """Resume from save_checkpoint(): the next train_iteration() is bit-identical to the one the saved run would have made."""
@@ -509,6 +561,7 @@ class HumanoidWalkingTask:
                 warnings.warn(f"{path}: opt_state_0 is present but does not map onto (count, mu, nu) of this model - "
                               "resuming with FRESH Adam moments and optimizer step 0 (parameters were loaded)")
         self.iteration = int(st.get("num_steps", 0))
+        self._obs_started = self.iteration > 0          # a resumed run's row 0 already carries the user observation columns
         self._command_started = self.iteration > 0      # a resumed run's row 0 already carries the user command term's commands
         x = z["extras"]
         if "es" not in x:
@@ -552,7 +605,7 @@ class HumanoidWalkingTask:
         the requested part; for "model" a ModelView with `.actor` (named leaves) as convert.py:44-46 reads it."""
         if part == "model":
             flat = ckpt_io.load_ckpt(path, "model", hidden_size=self.H, depth=self.kcfg.depth)
-            return [ModelView(flat, self.H, self.kcfg.depth)]
+            return [ModelView(flat, self.H, self.kcfg.depth, self.extra_obs)]
         return [ckpt_io.load_ckpt(path, part, hidden_size=self.H, depth=self.kcfg.depth)]
 
     # ---- validation (train.py:1564 argmax=True; valid_every_n_steps train.py:1789) ----
@@ -569,7 +622,8 @@ class HumanoidWalkingTask:
                 vcfg.command_mode = 1
             vctx = B.Context(self.model_blob, vcfg, self.device.index or 0, torch.cuda.current_stream().cuda_stream)
             self._valid = (key, vctx, CarryBuffers(num_envs, self.H, self.kcfg.depth, self.device, mirror=self.mirror),
-                           TrajBuffers(T, num_envs, self.H, self.kcfg.depth, self.device, mirror=self.mirror, reward_comps=True))
+                           TrajBuffers(T, num_envs, self.H, self.kcfg.depth, self.device, mirror=self.mirror, reward_comps=True,
+                                       ld_actor=self.ld_actor, ld_critic=self.ld_critic))
         _, vctx, carry, tr = self._valid
         seed = self.config.seed + seed_offset
         carry.zero_()
@@ -578,9 +632,15 @@ class HumanoidWalkingTask:
             from .traj_view import StepView
             self._apply_command(vctx, tr, 0, StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob),
                                 torch.ones(num_envs, dtype=torch.bool, device=self.device), seed_offset, all_fresh=True)
+        feeds = any(self.extra_obs)            # user observation terms that are network inputs drive the validation policy too
+        if feeds:
+            from .traj_view import StepView
+            self._observe_into_rows(tr, 0, StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob))
         for t in range(T):
             vctx.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], carry.c, seed, t, True, tr.action[t], tr.logp[t], tr.value[t])
             vctx.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
+            if feeds:
+                self._observe_into_rows(tr, t + 1, StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob))
             if self.command_term is not None:
                 self._apply_command(vctx, tr, t + 1, StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob),
                                     tr.aux[t][:, L.AUX["DONE"]] != 0, seed_offset + t + 1)
@@ -616,7 +676,7 @@ class HumanoidWalkingTask:
         from . import export
         c = self.kcfg
         export.export_actor(path, self.params.cpu().numpy(), self.H, c.depth, c.ctrl_dt, self.config.cutoff_frequency, c.min_std, c.max_std,
-                            c.var_scale, list(self.model_blob.joint_bias))
+                            c.var_scale, list(self.model_blob.joint_bias), extra_obs=self.extra_obs)
 
     def reward_components(self):
         """Mean of every unscaled reward term over the last rollout (train.py:1224-1256 order, spec/constants.REWARD_NAMES);
@@ -676,9 +736,9 @@ class ModelView:
             self.rnns = tuple(_Leaf(weight_ih=g(f"rnns.{l}.weight_ih"), weight_hh=g(f"rnns.{l}.weight_hh"), bias=g(f"rnns.{l}.bias")) for l in range(depth))
             self.output_proj = _Leaf(weight=g("output_proj.weight"), bias=g("output_proj.bias"))
 
-    def __init__(self, flat, hidden_size: int, depth: int = 2):
+    def __init__(self, flat, hidden_size: int, depth: int = 2, extra_obs=(0, 0)):
         self.hidden_size, self.depth = hidden_size, depth
-        leaves = dict(ckpt_io.split_leaves(flat, hidden_size, depth))
+        leaves = dict(ckpt_io.split_leaves(flat, hidden_size, depth, extra_obs))
         self.leaves = leaves
         self.actor = ModelView._Net(leaves, "actor", depth)
         self.critic = ModelView._Net(leaves, "critic", depth)

@@ -9,7 +9,21 @@ import ctypes as C
 import math
 
 NBODY, NQ, NV, NU, NCAP, NCON, NCMD, NREW = 24, 27, 26, 20, 4, 8, 16, 12
-NOBS_ACTOR, NOBS_CRITIC, LD_ACTOR, LD_CRITIC = 65, 475, 68, 476
+NOBS_ACTOR, NOBS_CRITIC, LD_ACTOR, LD_CRITIC = 65, 475, 68, 476     # the reference's rows (train.py:1281-1312) and their 16-byte aligned strides
+MAX_EXTRA_OBS = 64                                                  # kbj_model.h KBJ_MAX_EXTRA_OBS: user columns behind the reference's
+
+
+def ld_of(nobs: int) -> int:
+    """KBJ_LD_OF: row stride (floats) of an observation row of `nobs` used columns."""
+    return (nobs + 3) & ~3
+
+
+def obs_widths(cfg) -> tuple[int, int, int, int]:
+    """(nobs_actor, nobs_critic, ld_actor, ld_critic) of a kbj_config: the reference's 65 / 475 columns plus the user columns
+    (extra_obs_actor / extra_obs_critic) appended behind them."""
+    na, nc = NOBS_ACTOR + int(cfg.extra_obs_actor), NOBS_CRITIC + int(cfg.extra_obs_critic)
+    return na, nc, ld_of(na), ld_of(nc)
+
 MAGIC, VERSION = 0x4D4A424B, 3
 
 f32, i32, u32 = C.c_float, C.c_int32, C.c_uint32
@@ -45,7 +59,7 @@ class Config(C.Structure):
         ("num_envs", i32), ("env_id_offset", i32), ("rollout_len", i32), ("substeps", i32),
         ("solver_iterations", i32), ("ls_iterations", i32), ("hidden_size", i32), ("depth", i32),
         ("batch_size", i32), ("num_passes", i32), ("command_mode", i32), ("enable_randomizers", i32),
-        ("enable_pushes", i32), ("enable_noise", i32), ("max_episode_steps", i32), ("solver_newton", i32), ("deterministic", i32), ("reserved_i", i32 * 3),
+        ("enable_pushes", i32), ("enable_noise", i32), ("max_episode_steps", i32), ("solver_newton", i32), ("deterministic", i32), ("extra_obs_actor", i32), ("extra_obs_critic", i32), ("reserved_i", i32 * 1),
         ("dt", f32), ("ctrl_dt", f32), ("solver_tolerance", f32), ("latency_lo", f32), ("latency_hi", f32),
         ("drop_action_prob", f32), ("fixed_command", f32 * NCMD),
         ("vx_lo", f32), ("vx_hi", f32), ("vy_lo", f32), ("vy_hi", f32), ("wz_lo", f32), ("wz_hi", f32),
@@ -154,19 +168,20 @@ def default_config(**overrides) -> Config:
     return c
 
 
-def param_count(hidden: int, depth: int = 2) -> tuple[int, int]:
-    """(actor, critic) parameter counts (train.py:878-903, 964-989)."""
+def param_count(hidden: int, depth: int = 2, extra_obs: tuple[int, int] = (0, 0)) -> tuple[int, int]:
+    """(actor, critic) parameter counts (train.py:878-903, 964-989); extra_obs = (actor, critic) user columns."""
     lstm = depth * (4 * hidden * 2 * hidden + 4 * hidden)
-    actor = NOBS_ACTOR * hidden + hidden + lstm + hidden * 2 * NU + 2 * NU
-    critic = NOBS_CRITIC * hidden + hidden + lstm + hidden + 1
+    actor = (NOBS_ACTOR + extra_obs[0]) * hidden + hidden + lstm + hidden * 2 * NU + 2 * NU
+    critic = (NOBS_CRITIC + extra_obs[1]) * hidden + hidden + lstm + hidden + 1
     return actor, critic
 
 
-def param_leaves(hidden_size: int, depth: int = 2):
+def param_leaves(hidden_size: int, depth: int = 2, extra_obs: tuple[int, int] = (0, 0)):
     """(name, shape) of every leaf of the flat parameter vector, in equinox leaf order of Model(actor, critic)
-    (include/kbj.h; train.py:847-1046; convert.py:44-46 takes `model.actor`)."""
+    (include/kbj.h; train.py:847-1046; convert.py:44-46 takes `model.actor`). extra_obs = (actor, critic) user columns: they widen the
+    input projections, as appending a term to run_actor / run_critic's concatenation does in the reference (train.py:1351-1433)."""
     H, leaves = hidden_size, []
-    for net, nin, nout in (("actor", NOBS_ACTOR, 2 * NU), ("critic", NOBS_CRITIC, 1)):
+    for net, nin, nout in (("actor", NOBS_ACTOR + extra_obs[0], 2 * NU), ("critic", NOBS_CRITIC + extra_obs[1], 1)):
         leaves.append((f"{net}.input_proj.weight", (H, nin)))
         leaves.append((f"{net}.input_proj.bias", (H,)))
         for l in range(depth):

@@ -23,10 +23,11 @@ NOBS_ACTOR, NOBS_CRITIC = 65, 475
 LOG_2PI = math.log(2.0 * math.pi)
 
 
-def param_shapes(H: int, depth: int = 2):
-    """Flat parameter layout = equinox leaf order of Model(actor, critic) (kbj.h)."""
+def param_shapes(H: int, depth: int = 2, extra_obs=(0, 0)):
+    """Flat parameter layout = equinox leaf order of Model(actor, critic) (kbj.h). extra_obs = (actor, critic) user observation columns
+    appended behind the reference's 65 / 475 (kbj_config.extra_obs_*): they widen the input projections."""
     shapes = []
-    for net, nin, nout in (("actor", NOBS_ACTOR, 2 * NU), ("critic", NOBS_CRITIC, 1)):
+    for net, nin, nout in (("actor", NOBS_ACTOR + extra_obs[0], 2 * NU), ("critic", NOBS_CRITIC + extra_obs[1], 1)):
         shapes.append((f"{net}.input_proj.weight", (H, nin)))
         shapes.append((f"{net}.input_proj.bias", (H,)))
         for l in range(depth):
@@ -38,9 +39,9 @@ def param_shapes(H: int, depth: int = 2):
     return shapes
 
 
-def unflatten(flat: torch.Tensor, H: int, depth: int = 2) -> dict:
+def unflatten(flat: torch.Tensor, H: int, depth: int = 2, extra_obs=(0, 0)) -> dict:
     out, off = {}, 0
-    for name, shp in param_shapes(H, depth):
+    for name, shp in param_shapes(H, depth, extra_obs):
         n = int(np.prod(shp))
         out[name] = flat[off:off + n].view(shp)
         off += n
@@ -48,8 +49,8 @@ def unflatten(flat: torch.Tensor, H: int, depth: int = 2) -> dict:
     return out
 
 
-def param_count(H: int, depth: int = 2) -> int:
-    return sum(int(np.prod(s)) for _, s in param_shapes(H, depth))
+def param_count(H: int, depth: int = 2, extra_obs=(0, 0)) -> int:
+    return sum(int(np.prod(s)) for _, s in param_shapes(H, depth, extra_obs))
 
 
 def lstm_cell(x, h, c, w_ih, w_hh, b):
@@ -62,7 +63,8 @@ def lstm_cell(x, h, c, w_ih, w_hh, b):
 
 
 def net_forward(p: dict, net: str, obs, hc, depth: int = 2):
-    """obs [B, nin]; hc [depth][2][B,H] -> (out [B,nout], new hc)"""
+    """obs [B, >= nin] (columns beyond the input projection's width - the row's pad - are ignored); hc [depth][2][B,H] -> (out [B,nout], new hc)"""
+    obs = obs[..., :p[f"{net}.input_proj.weight"].shape[1]]
     x = obs @ p[f"{net}.input_proj.weight"].T + p[f"{net}.input_proj.bias"]
     new = []
     for l in range(depth):
@@ -98,11 +100,11 @@ def ppo_variables(p, cfg, joint_bias, actor_obs, critic_obs, actions, done, carr
     T = actor_obs.shape[0]
     logps, values, ents = [], [], []
     for t in range(T):
-        out_a, carry_a = net_forward(p, "actor", actor_obs[t][..., :NOBS_ACTOR], carry_a, depth)
+        out_a, carry_a = net_forward(p, "actor", actor_obs[t], carry_a, depth)
         mean, std, lpf = actor_head(out_a, actor_obs[t], lpf, joint_bias, cfg)
         logps.append(gaussian_logp(actions[t], mean, std))
         ents.append(gaussian_entropy(std))
-        out_c, carry_c = net_forward(p, "critic", critic_obs[t][..., :NOBS_CRITIC], carry_c, depth)
+        out_c, carry_c = net_forward(p, "critic", critic_obs[t], carry_c, depth)
         values.append(out_c[..., 0])
         keep = (done[t] == 0).to(mean.dtype)[:, None]                 # carry <- initial carry where done (train.py:1502-1506)
         carry_a = [[h * keep, c * keep] for h, c in carry_a]
@@ -233,16 +235,16 @@ def ppo_variables_mirror(p, cfg, model, joint_bias, actor_obs, critic_obs, actio
     T = actor_obs.shape[0]
     logps, values, ents, la, lc = [], [], [], [], []
     for t in range(T):
-        out_a, carry_a = net_forward(p, "actor", actor_obs[t][..., :NOBS_ACTOR], carry_a, depth)
+        out_a, carry_a = net_forward(p, "actor", actor_obs[t], carry_a, depth)
         mean, std, lpf = actor_head(out_a, actor_obs[t], lpf, joint_bias, cfg)
         logps.append(gaussian_logp(actions[t], mean, std)); ents.append(gaussian_entropy(std))
-        out_c, carry_c = net_forward(p, "critic", critic_obs[t][..., :NOBS_CRITIC], carry_c, depth)
+        out_c, carry_c = net_forward(p, "critic", critic_obs[t], carry_c, depth)
         values.append(out_c[..., 0])
         ao_m, co_m = mirror_actor_obs(actor_obs[t], model), mirror_critic_obs(critic_obs[t], model)
-        out_am, carry_am = net_forward(p, "actor", ao_m[..., :NOBS_ACTOR], carry_am, depth)
+        out_am, carry_am = net_forward(p, "actor", ao_m, carry_am, depth)
         mean_m, _, lpf_m = actor_head(out_am, ao_m, lpf_m, joint_bias, cfg)
         la.append(((mean - mirror_joints(mean_m)) ** 2).mean(-1) * cfg.actor_mirror_loss_scale)       # train.py:1470-1473
-        out_cm, carry_cm = net_forward(p, "critic", co_m[..., :NOBS_CRITIC], carry_cm, depth)
+        out_cm, carry_cm = net_forward(p, "critic", co_m, carry_cm, depth)
         lc.append((out_c[..., 0] - out_cm[..., 0]) ** 2 * cfg.critic_mirror_loss_scale)               # train.py:1481
         keep = (done[t] == 0).to(mean.dtype)[:, None]
         carry_a = [[h * keep, c * keep] for h, c in carry_a]; carry_c = [[h * keep, c * keep] for h, c in carry_c]

@@ -23,7 +23,7 @@ void kbj_emu_reset_all(const kbj_model* m, const kbj_config* c, uint32_t seed, f
     S->pc = pc;
     Rng rng{seed, (uint32_t)(c->env_id_offset + i)};
     task_reset(*S, *m, *c, S->pc, rng);
-    task_write_obs(*S, *m, *c, rng, a0 + (size_t)i * KBJ_LD_ACTOR, c0 + (size_t)i * KBJ_LD_CRITIC, x0 + (size_t)i * KBJ_AUX_SIZE);
+    task_write_obs(*S, *m, *c, rng, a0 + (size_t)i * KBJ_LD_OF(KBJ_NOBS_ACTOR + c->extra_obs_actor), c0 + (size_t)i * KBJ_LD_OF(KBJ_NOBS_CRITIC + c->extra_obs_critic), x0 + (size_t)i * KBJ_AUX_SIZE);
     std::memcpy(ep + (size_t)i * KBJ_EP_SIZE, S->ep, sizeof(S->ep));
     std::memcpy(es + (size_t)i * KBJ_ES_SIZE, S->es, sizeof(S->es));
   }
@@ -41,8 +41,8 @@ void kbj_emu_env_step(const kbj_model* m, const kbj_config* c, uint32_t seed, fl
     std::memcpy(S->ep, ep + (size_t)i * KBJ_EP_SIZE, sizeof(S->ep));
     std::memcpy(S->es, es + (size_t)i * KBJ_ES_SIZE, sizeof(S->es));
     Rng rng{seed, (uint32_t)(c->env_id_offset + i)};
-    task_step(*S, *m, *c, S->pc, rng, action + (size_t)i * KBJ_NU, aux_t + (size_t)i * KBJ_AUX_SIZE, an + (size_t)i * KBJ_LD_ACTOR,
-              cn + (size_t)i * KBJ_LD_CRITIC, xn + (size_t)i * KBJ_AUX_SIZE);
+    task_step(*S, *m, *c, S->pc, rng, action + (size_t)i * KBJ_NU, aux_t + (size_t)i * KBJ_AUX_SIZE, an + (size_t)i * KBJ_LD_OF(KBJ_NOBS_ACTOR + c->extra_obs_actor),
+              cn + (size_t)i * KBJ_LD_OF(KBJ_NOBS_CRITIC + c->extra_obs_critic), xn + (size_t)i * KBJ_AUX_SIZE);
     std::memcpy(ep + (size_t)i * KBJ_EP_SIZE, S->ep, sizeof(S->ep));
     std::memcpy(es + (size_t)i * KBJ_ES_SIZE, S->es, sizeof(S->es));
   }

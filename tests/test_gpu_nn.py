@@ -378,3 +378,90 @@ def test_full_size_minibatch_gradient_is_permutation_invariant():
     assert (g0 - g1).norm() / g0.norm() < 1e-4
     assert (m0 - m1).abs().max() < 1e-4 * (1 + m0.abs().max())
     ctx.close()
+
+
+@pytest.mark.parametrize("ea,ec,H", [(3, 3, 256), (7, 5, 128), (35, 64, 64)])
+def test_user_observation_columns_match_oracle(ea, ec, H):
+    """f3 widening: `ea` / `ec` user floats appended behind the reference's 65 / 475 columns of the actor / critic rows
+    (kbj_config.extra_obs_*), as a user of the reference appends a term to the lists run_actor / run_critic concatenate (train.py:1351-1433).
+    The input projections are [H][65 + ea] / [H][475 + ec]; the policy step and the minibatch gradient follow oracle/nn.py at the widened
+    sizes. (3, 3): the actor row keeps its 68-float stride and stays on the fused observation kernels; the others take the general path."""
+    N, B, T = 40, 32, 6
+    m, cfg, ctx, torch, buffers = _setup(N, B, T, H, extra_obs_actor=ea, extra_obs_critic=ec)
+    from oracle import nn as ON
+    na, nc, lda, ldc = L.obs_widths(cfg)
+    assert (na, nc) == (65 + ea, 475 + ec) and lda % 4 == 0 and ldc % 4 == 0
+    P = ctx.param_count()
+    assert P == ON.param_count(H, 2, (ea, ec)) and ctx.actor_param_count() == L.param_count(H, 2, (ea, ec))[0]
+    params = torch.zeros(P, device="cuda:0")
+    ctx.init_params(3, params)
+    p64 = params.detach().cpu().double()
+    p = ON.unflatten(p64, H, 2, (ea, ec))
+    assert p["actor.input_proj.weight"].shape == (H, na) and p["critic.input_proj.weight"].shape == (H, nc)
+    assert float(p["actor.input_proj.weight"][:, 65:].abs().max()) > 0            # the user columns have live weights
+    jb = torch.tensor(list(m.joint_bias), dtype=torch.float64)
+    g = torch.Generator(device="cpu").manual_seed(1)
+    # ---- policy step ----
+    aobs = torch.zeros(N, lda); aobs[:, :na] = torch.randn(N, na, generator=g)
+    cobs = torch.zeros(N, ldc); cobs[:, :nc] = torch.randn(N, nc, generator=g)
+    carry = buffers.CarryBuffers(N, H, 2, "cuda:0")
+    carry.actor_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.5); carry.critic_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.5)
+    hc_a0, hc_c0 = carry.actor_hc.cpu().double(), carry.critic_hc.cpu().double()
+    action, logp, value = torch.zeros(N, 20, device="cuda:0"), torch.zeros(N, device="cuda:0"), torch.zeros(N, device="cuda:0")
+    ctx.policy_step(params, aobs.cuda(), cobs.cuda(), carry.c, 7, 5, True, action, logp, value)
+    ctx.synchronize()
+    out_a, _ = ON.net_forward(p, "actor", aobs.double(), [[hc_a0[l, 0], hc_a0[l, 1]] for l in range(2)])
+    mean, std, _ = ON.actor_head(out_a, aobs.double(), torch.zeros(N, 20, dtype=torch.float64), jb, cfg)
+    out_c, _ = ON.net_forward(p, "critic", cobs.double(), [[hc_c0[l, 0], hc_c0[l, 1]] for l in range(2)])
+    assert (action.cpu().double() - mean).abs().max() < 2e-5 and (value.cpu().double() - out_c[:, 0]).abs().max() < 2e-5
+    # the user columns matter: zeroing them changes the outputs
+    a0 = aobs.clone(); a0[:, 65:] = 0
+    act0 = torch.zeros_like(action)
+    ctx.policy_step(params, a0.cuda(), cobs.cuda(), buffers.CarryBuffers(N, H, 2, "cuda:0").c, 7, 5, True, act0, logp, value)
+    ctx.synchronize()
+    # ---- minibatch gradient ----
+    tr = buffers.TrajBuffers(T, N, H, 2, "cuda:0", ld_actor=lda, ld_critic=ldc)
+    tr.actor_obs[:, :, :na] = (torch.randn(T + 1, N, na, generator=g) * 0.5).cuda()
+    tr.critic_obs[:, :, :nc] = (torch.randn(T + 1, N, nc, generator=g) * 0.5).cuda()
+    tr.action.copy_(torch.randn(T, N, 20, generator=g) * 0.3)
+    done = (torch.rand(T, N, generator=g) < 0.15).float() * torch.where(torch.rand(T, N, generator=g) < 0.5, -1.0, 1.0)
+    tr.aux[:T, :, L.AUX["DONE"]] = done.cuda()
+    tr.reward.copy_(torch.rand(T, N, generator=g))
+    tr.carry0_actor_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3); tr.carry0_critic_hc.copy_(torch.randn(2, 2, N, H, generator=g) * 0.3)
+    tr.carry0_lpf.copy_(torch.randn(N, 20, generator=g) * 0.2)
+    idx = torch.randperm(N, generator=g)[:B].int()
+    ii = idx.long()
+    ao, co = tr.actor_obs[:T].cpu().double(), tr.critic_obs[:T].cpu().double()
+    act, dn = tr.action.cpu().double(), tr.done.cpu().double()
+    with torch.no_grad():
+        ca = [[tr.carry0_actor_hc[l, k].cpu().double() for k in range(2)] for l in range(2)]
+        cc = [[tr.carry0_critic_hc[l, k].cpu().double() for k in range(2)] for l in range(2)]
+        lp, v, en, *_ = ON.ppo_variables(p, cfg, jb, ao, co, act, dn, ca, cc, tr.carry0_lpf.cpu().double())
+    tr.logp.copy_((lp + 0.3 * torch.randn(T, N, generator=g).double()).float())
+    tr.value.copy_((v + 0.3 * torch.randn(T, N, generator=g).double()).float())
+    ctx.gae(tr.c, tr.adv, tr.target)
+    grad, metrics = torch.zeros(P, device="cuda:0"), torch.zeros(10, device="cuda:0")
+    ctx.ppo_grad(params, tr.c, idx.cuda(), B, tr.adv, tr.target, grad, metrics)
+    ctx.synchronize()
+    pf = p64.clone().requires_grad_(True)
+    pg = ON.unflatten(pf, H, 2, (ea, ec))
+    ca = [[tr.carry0_actor_hc[l, k].cpu().double()[ii] for k in range(2)] for l in range(2)]
+    cc = [[tr.carry0_critic_hc[l, k].cpu().double()[ii] for k in range(2)] for l in range(2)]
+    lp, v, en, *_ = ON.ppo_variables(pg, cfg, jb, ao[:, ii], co[:, ii], act[:, ii], dn[:, ii], ca, cc, tr.carry0_lpf.cpu().double()[ii])
+    loss, mt = ON.ppo_loss(cfg, lp, v, en, tr.logp.cpu().double()[:, ii], tr.value.cpu().double()[:, ii], tr.adv.cpu().double()[:, ii], tr.target.cpu().double()[:, ii])
+    loss.backward()
+    gg, go = grad.cpu().double(), pf.grad
+    assert abs(float(metrics[0]) - float(loss.detach())) < 2e-4 * (1 + abs(float(loss.detach())))
+    off = 0
+    for name, shp in ON.param_shapes(H, 2, (ea, ec)):
+        n = int(np.prod(shp))
+        err = (gg[off:off + n] - go[off:off + n]).abs().max() / (go[off:off + n].abs().max() + 1e-12)
+        assert err < 2e-3, (name, float(err))
+        if name.endswith("input_proj.weight"):      # the user columns' own gradient block
+            k0 = 65 if name.startswith("actor") else 475
+            blk_g, blk_o = gg[off:off + n].view(shp)[:, k0:], go[off:off + n].view(shp)[:, k0:]
+            assert float(blk_o.abs().max()) > 0 and (blk_g - blk_o).abs().max() / blk_o.abs().max() < 2e-3
+        off += n
+    assert (gg - go).norm() / go.norm() < 1e-4
+    assert not torch.equal(act0, action)
+    ctx.close()
