@@ -172,6 +172,28 @@ template <int W> KBJ_DEV float subtree_sum(const float (*q)[W], int b, int k) {
   return s;
 }
 
+// the stored entries of the tree-sparse mass matrix: (dof i, ancestor-or-self dof j, byte offset of the entry from S.Mb)
+struct MPair { unsigned char i, j; unsigned short off; };
+constexpr int MPAIR_N = 21 + 20 * 6 + 4 * 15;
+struct MPairTab { MPair e[MPAIR_N]; };
+constexpr MPairTab make_mpair_tab() {
+  MPairTab t{};
+  int n = 0;
+  for (int i = 0; i < 6; ++i) for (int j = 0; j <= i; ++j) t.e[n++] = MPair{(unsigned char)i, (unsigned char)j, (unsigned short)(4 * (i * 6 + j))};
+  for (int c = 0; c < 4; ++c)
+    for (int a = 0; a < 5; ++a) {
+      const int i = 6 + 5 * c + a, row = 36 + (c * 5 + a) * 11;
+      for (int j = 0; j < 6; ++j) t.e[n++] = MPair{(unsigned char)i, (unsigned char)j, (unsigned short)(4 * (row + j))};
+      for (int a2 = 0; a2 <= a; ++a2) t.e[n++] = MPair{(unsigned char)i, (unsigned char)(6 + 5 * c + a2), (unsigned short)(4 * (row + 6 + a2))};
+    }
+  return t;
+}
+#ifdef KBJ_EMU
+static const MPairTab MPAIR = make_mpair_tab();
+#else
+__device__ const MPairTab MPAIR = make_mpair_tab();
+#endif
+
 KBJ_DEV void phys_crb_mass(KbjShared& S) {
   // composite inertias: suffix sums from the tip of each limb towards the torso (one lane per limb and component), then torso and base
   PFOR(w, 50) {
@@ -187,19 +209,27 @@ KBJ_DEV void phys_crb_mass(KbjShared& S) {
     S.u.crb[2][k] = t; S.u.crb[1][k] = t + S.cinert[1][k]; S.u.crb[0][k] = 0;
   }
   KBJ_SYNC();
-  // M[i][j] = cdof_j . (crb[body_i] cdof_i) for j = i and its ancestors: the six base dofs, then the limb's dofs up to i
+  // M[i][j] = cdof_j . (crb[body_i] cdof_i) for j = i and its ancestors (the six base dofs, then the limb's dofs up to i): first the 26
+  // spatial forces crb cdof_i (one lane per dof), then one lane per STORED entry (201 of them: 4 rounds of 64 instead of one lane per row
+  // walking up to 11 dot products, with the base and the limb rows diverging). The forces sit in the constraint-row arrays D / aref / force,
+  // which are dead from the end of a solve (and its sensors) to the next phys_make_constraints.
+  float* fbuf = S.D;
+  static_assert(sizeof(S.D) + sizeof(S.aref) + sizeof(S.force) >= NV * 6 * sizeof(float) && offsetof(KbjShared, aref) == offsetof(KbjShared, D) + sizeof(S.D) &&
+                offsetof(KbjShared, force) == offsetof(KbjShared, aref) + sizeof(S.aref), "D, aref, force are used as one scratch array here");
   PFOR(i, NV) {
     float buf[6];
     inert_mul(S.u.crb[dof_body(i)], S.cdof[i], buf);
-    auto dot = [&](int j) { float x = 0; for (int k = 0; k < 6; ++k) x += S.cdof[j][k] * buf[k]; return x; };
-    const float arm = S.ep[KBJ_EP_ARMATURE + i];
-    if (i < 6) {
-      for (int j = 0; j <= i; ++j) S.Mb[i][j] = dot(j) + (j == i ? arm : 0.0f);
-    } else {
-      const int c = (i - 6) / 5, a = (i - 6) % 5;
-      for (int j = 0; j < 6; ++j) S.Mc[c][a][j] = dot(j);
-      for (int a2 = 0; a2 <= a; ++a2) S.Mc[c][a][6 + a2] = dot(6 + 5 * c + a2) + (a2 == a ? arm : 0.0f);
-    }
+    for (int k = 0; k < 6; ++k) fbuf[6 * i + k] = buf[k];
+  }
+  KBJ_SYNC();
+  PFOR(w, MPAIR_N) {
+    const MPair e = MPAIR.e[w];
+    const float* cj = S.cdof[e.j];
+    const float* bi = fbuf + 6 * e.i;
+    float x = 0;
+    for (int k = 0; k < 6; ++k) x += cj[k] * bi[k];
+    if (e.i == e.j) x += S.ep[KBJ_EP_ARMATURE + e.i];
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(&S.Mb[0][0]) + e.off) = x;
   }
   KBJ_SYNC();
 }
@@ -231,12 +261,14 @@ KBJ_DEV void phys_collide_vel(KbjShared& S, const KbjModelLds& m, const PhysCons
       S.conact[ci] = dist < 0;
     }
   }
-  // RNE forward pass in two steps: five walkers (four limbs + imu) carry the spatial velocity and the bias acceleration outwards
-  // (a cross product and two axpys per body), then the body forces I a + v x* (I v) for all bodies in parallel
-  PFOR(c, 5) {
+  // RNE forward pass: spatial velocity and bias acceleration of every body. The base part (three translations, then three rotations that
+  // share the pre-rotation velocity) is computed by every lane; then one lane per hinge dof builds its body's velocity from the base's by
+  // adding the limb's dofs up to its own IN THE WALKER'S ORDER (base .. tip: same sums, bit for bit, as walking the limb), and the
+  // velocity-product axis cdof_dot = v_parent x cdof; a last phase adds the limb's cdof_dot qvel terms per (body, component). The serial
+  // walk per limb (five bodies x ~35 instructions on 5 lanes) becomes two short data-parallel phases.
+  {
     float v[6] = {0, 0, 0, 0, 0, 0}, a[6] = {0, 0, 0, -m.gravity[0], -m.gravity[1], -m.gravity[2]};
     float cdd[6];
-    // base body: 3 translations (cdof_dot = 0) then 3 rotations sharing the pre-rotation velocity
     for (int i = 0; i < 3; ++i) for (int k = 0; k < 6; ++k) v[k] += S.cdof[i][k] * qvel[i];
     float vb[6];
     for (int k = 0; k < 6; ++k) vb[k] = v[k];
@@ -244,19 +276,27 @@ KBJ_DEV void phys_collide_vel(KbjShared& S, const KbjModelLds& m, const PhysCons
       cross_motion(vb, S.cdof[i], cdd);
       for (int k = 0; k < 6; ++k) { v[k] += S.cdof[i][k] * qvel[i]; a[k] += cdd[k] * qvel[i]; }
     }
-    if (c == 4) {   // base and torso move together; world body at rest
-      for (int k = 0; k < 6; ++k) { S.cvel[0][k] = 0; S.u.cfrc_acc[0][k] = 0; S.cvel[1][k] = v[k]; S.u.cfrc_acc[1][k] = a[k]; S.cvel[2][k] = v[k]; S.u.cfrc_acc[2][k] = a[k]; }
-    }
-    const int nb = c < 4 ? 5 : 1;
-    for (int k5 = 0; k5 < nb; ++k5) {
-      const int b = c < 4 ? 3 + 5 * c + k5 : 23;
-      if (c < 4) {
-        const int d = b + 3;
-        cross_motion(v, S.cdof[d], cdd);
-        for (int k = 0; k < 6; ++k) { v[k] += S.cdof[d][k] * qvel[d]; a[k] += cdd[k] * qvel[d]; }
+    PFOR(w, 1) {   // world body at rest; base, torso and imu move together
+      for (int k = 0; k < 6; ++k) {
+        S.cvel[0][k] = 0; S.u.cfrc_acc[0][k] = 0;
+        S.cvel[1][k] = v[k]; S.u.cfrc_acc[1][k] = a[k]; S.cvel[2][k] = v[k]; S.u.cfrc_acc[2][k] = a[k]; S.cvel[23][k] = v[k]; S.u.cfrc_acc[23][k] = a[k];
       }
-      for (int k = 0; k < 6; ++k) { S.cvel[b][k] = v[k]; S.u.cfrc_acc[b][k] = a[k]; }   // cfrc_acc doubles as the acceleration buffer
     }
+    PFOR(u, NU) {
+      const int c = u / 5, pos = u % 5, d = 6 + u, b = 3 + u;
+      float vl[6], cd[6];
+      for (int k = 0; k < 6; ++k) vl[k] = v[k];
+      for (int e = 0; e < pos; ++e) { const int de = 6 + 5 * c + e; for (int k = 0; k < 6; ++k) vl[k] += S.cdof[de][k] * qvel[de]; }
+      cross_motion(vl, S.cdof[d], cd);
+      for (int k = 0; k < 6; ++k) { S.u.cfrc[b][k] = cd[k]; vl[k] += S.cdof[d][k] * qvel[d]; S.cvel[b][k] = vl[k]; }   // cfrc: cdof_dot until the body forces overwrite it
+    }
+  }
+  KBJ_SYNC();
+  PFOR(w, NU * 6) {
+    const int u = w / 6, k = w % 6, c = u / 5, pos = u % 5;
+    float a = S.u.cfrc_acc[1][k];
+    for (int e = 0; e <= pos; ++e) { const int de = 6 + 5 * c + e; a += S.u.cfrc[3 + 5 * c + e][k] * qvel[de]; }
+    S.u.cfrc_acc[3 + u][k] = a;
   }
   KBJ_SYNC();
   PFOR(b, NB) {

@@ -48,7 +48,15 @@ template <int J> KBJ_DEV WF wmul_bcast(const WF& src, const WF& mul) { WF o; for
 template <int J, int ROWMASK> KBJ_DEV void wset_rhs(WF& dst, const WF& g) {   // lanes 12..15 of the rows in ROWMASK <- lane J of their row
   for (int l = 0; l < 64; ++l) if ((l & 15) >= 12 && ((ROWMASK >> (l >> 4)) & 1)) dst.v[l] = g.v[(l & ~15) | J];
 }
+#ifdef KBJ_EMU_RCP_1ULP   // model of v_rcp_f32 (1 ulp): the rounded reciprocal moved by -1 / 0 / +1 ulp, pseudo-randomly from the argument's bits
+KBJ_DEV float wrcp_scalar(float x) {
+  union { float f; unsigned u; } a, r; a.f = x; r.f = 1.0f / x;
+  r.u += ((a.u >> 3) & 1u) - ((a.u >> 5) & 1u);
+  return r.f;
+}
+#else
 KBJ_DEV float wrcp_scalar(float x) { return 1.0f / x; }
+#endif
 KBJ_DEV float wclamp(float x, float t) { return fminf(fmaxf(x, -t), t); }
 KBJ_DEV float wmin0(float x) { return fminf(x, 0.0f); }
 KBJ_DEV void wopaque(WF&) {}
@@ -172,21 +180,29 @@ KBJ_DEV void kbj_sincos(float x, float& s, float& c) {
   c = ((q + 1) & 2) ? -cc : cc;
 }
 
-// -x / (lane P of the row of x): the multiplier column of a pivot. One hardware reciprocal and one Newton step on the quotient
-// (q0 = -x r, e = x + q0 d ~ 0, q = q0 - e r): within an ulp of the rounded quotient for 5 instructions instead of the 10 of an IEEE
-// division. KBJ_SOLVER_RAW_RCP drops the correction (A/B builds).
+// -x / (lane P of the row of x): the multiplier column of a pivot. ONE hardware reciprocal read through DPP (v_rcp_f32: 1 ulp) and one
+// multiply. The emulation with a reciprocal that is off by -1 / 0 / +1 ulp (KBJ_EMU_RCP_1ULP) gives the same error quantiles against the
+// fp64 oracle as the exact division (tools/emu_parity.py, 49 k env-steps: qpos p99.9 1.71e-6 vs 1.83e-6, qacc 5.1e-5 vs 4.7e-5, the oracle's
+// own fp32 1.6e-6 / 4.7e-5): an LDL^T pivot's reciprocal is one rounding among the eleven a row already takes. KBJ_SOLVER_NR adds a
+// Newton step on the quotient (A/B builds; 3 more instructions per pivot, 33 per solve).
 template <int P> KBJ_DEV WF wneg_div_bcast(const WF& x) {
-  const WF d = wbcast<P>(x);
   WF q;
+#if defined(KBJ_EMU) || defined(KBJ_SOLVER_NR)
+  const WF d = wbcast<P>(x);
   WLANES(l) {
     const float r = wrcp_scalar(WL(d, l)), q0 = -WL(x, l) * r;
-#ifdef KBJ_SOLVER_RAW_RCP
-    WL(q, l) = q0;
-#else
+#ifdef KBJ_SOLVER_NR
     const float e = fmaf(q0, WL(d, l), WL(x, l));
     WL(q, l) = fmaf(-e, r, q0);
+#else
+    WL(q, l) = q0;
 #endif
   }
+#else
+  float r;
+  asm("s_nop 1\n\tv_rcp_f32_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(x), "n"(P));
+  q = -x * r;
+#endif
   return q;
 }
 

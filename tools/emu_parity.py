@@ -27,11 +27,13 @@ def main():
     model = compiler.load_model(robot)
     cfg = L.default_config(num_envs=N, batch_size=min(512, N), **(dict(terrain_amp=0.05, terrain_wavelength=2.0) if terrain else {}))
     libs = {k: H.emu_lib(k) for k in ("reg", "lds")}
+    if os.environ.get("KBJ_EMU_ALT_LIB"):      # an experimental build of the emulation beside the two standard ones (e.g. -DKBJ_SOLVER_RAW_RCP -DKBJ_EMU_RCP_1ULP)
+        libs["alt"] = C.CDLL(os.environ["KBJ_EMU_ALT_LIB"])
     o32, o64 = (O.Oracle(model, cfg, seed=11, precision=p) for p in ("f32", "f64"))
     _, _, x0 = o32.reset_all()
     a1, c1, x1 = o32.new_obs()
     rng = np.random.default_rng(0)
-    E = {k: {n: [] for n in ("qpos", "qvel", "qacc")} for k in ("reg", "lds", "o32")}
+    E = {k: {n: [] for n in ("qpos", "qvel", "qacc")} for k in list(libs) + ["o32"]}
     done_mismatch = {k: 0 for k in libs}
     for t in range(steps):
         act = H.random_actions(model, rng, N)
