@@ -175,6 +175,13 @@ typedef struct kbj_ppo_vars {
   float* action_mean_d;  /* [T][B][20] or NULL: the filtered mean (the distribution's mode, train.py:936-939) */
 } kbj_ppo_vars;
 int kbj_ppo_forward(kbj_ctx* ctx, const float* params_d, const kbj_traj* traj, const int32_t* env_idx_d, int B, kbj_ppo_vars* out);
+/* Next-minibatch hint (no reference counterpart: XLA schedules its whole update as one program): the NEXT kbj_ppo_grad / kbj_ppo_forward of
+ * this context will be called with this trajectory and these indices (the same pointers). What that call gathers before its first
+ * recurrence and that does not depend on the parameters - the actor's observation rows, the keep flags, the start carries - is queued now,
+ * on a side lane behind everything enqueued on the context's stream so far, so it runs under the optimizer step between the two calls.
+ * Purely a scheduling hint: results are identical with and without it; a call with other arguments simply ignores the prefetch. Call it
+ * right after kbj_ppo_grad(k) with minibatch k + 1's indices. */
+int kbj_ppo_prefetch(kbj_ctx* ctx, const kbj_traj* traj, const int32_t* env_idx_d);
 /* Data-parallel overlap (no reference counterpart: the reference has no collective call site). After kbj_ppo_grad, work enqueued on
  * `hip_stream` behind this call starts once the ACTOR's slice of the gradient, grad_d[0, kbj_actor_param_count()), is final - about half
  * a millisecond before the call's own stream sees the whole gradient - so a host may all-reduce that slice on a second stream under the

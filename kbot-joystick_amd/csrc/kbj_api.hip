@@ -147,6 +147,7 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   for (int k = 0; k < 32; ++k) KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_pool[k], hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_actor_grad, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_small, hipEventDisableTiming));
+  KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_prefetch, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_obs, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -172,6 +173,7 @@ int kbj_destroy(kbj_ctx* ctx) {
   for (int k = 0; k < 32; ++k) if (ctx->ev_pool[k]) hipEventDestroy(ctx->ev_pool[k]);
   if (ctx->ev_actor_grad) hipEventDestroy(ctx->ev_actor_grad);
   if (ctx->ev_small) hipEventDestroy(ctx->ev_small);
+  if (ctx->ev_prefetch) hipEventDestroy(ctx->ev_prefetch);
   if (ctx->ev_obs) hipEventDestroy(ctx->ev_obs);
   if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) hipEventDestroy(ctx->ev_join);

@@ -20,6 +20,7 @@ struct kbj_ctx {
   hipEvent_t ev_dx[2] = {nullptr, nullptr};
   hipEvent_t ev_side[2] = {nullptr, nullptr};
   hipEvent_t ev_obs = nullptr;                // the critic's gathered observation rows are in place (side lane, ppo_forward_nets)
+  hipEvent_t ev_prefetch = nullptr;           // kbj_ppo_prefetch: the next minibatch's head gathers are done
   hipEvent_t ev_small = nullptr;              // the minibatch's small gathers / clears on the actor's side lane are done (ppo_forward_nets)
   hipEvent_t ev_actor_grad = nullptr;         // recorded by kbj_ppo_grad once the ACTOR's slice of the gradient is final (kbj_stream_wait_actor_grad)
   hipEvent_t ev_pool[32] = {};                // lane-alignment events of kbj_ppo_grad

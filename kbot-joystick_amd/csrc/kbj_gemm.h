@@ -337,7 +337,8 @@ inline void gemm_launch(hipStream_t s, const GemmArgs& g_in, int force_big = -1)
   GemmArgs g = g_in;
   int sk = g.splitk > 1 ? g.splitk : 1;
   long big_items = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * sk;
-  bool big = force_big >= 0 ? force_big != 0 : big_items >= 192;
+  // a narrow output (the actor's 40-column head) wastes 2/3 of a 128-wide tile's MFMAs and operand traffic: 64-wide tiles there
+  bool big = force_big >= 0 ? force_big != 0 : (big_items >= 192 && g.N > 64);
   long items = big ? big_items : (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * sk;
   // one work item per workgroup (walking several items per workgroup was slower at every setting for this path's shapes)
   int wgs = (int)items;

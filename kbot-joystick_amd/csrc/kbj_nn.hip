@@ -87,6 +87,8 @@ struct NnWs {
   float *Weff = nullptr, *beff = nullptr, *Zeff[4] = {nullptr, nullptr, nullptr, nullptr};
   float* WinP[2] = {nullptr, nullptr};   // input-projection weights re-pitched to the observation rows' 16-byte aligned stride (per call: the parameters change)
   double* stats = nullptr;  // [0..1] adv stats, [2..9] metric accumulators, [10] grad sumsq, [11] sample count of caller-supplied adv sums (0: own minibatch)
+  const int32_t* prefetched_idx = nullptr;   // kbj_ppo_prefetch: the gathers of the next kbj_ppo_grad / kbj_ppo_forward with these indices are already queued
+  const kbj_traj* prefetched_traj = nullptr;
   const double* ext_adv_sums = nullptr;   // kbj_set_advantage_sums: (sum adv, sum adv^2, count) on the device, used instead of the minibatch's own statistics
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
@@ -900,6 +902,34 @@ int kbj_gae(kbj_ctx* ctx, const kbj_traj* tr, float* adv_d, float* target_d) {
 
 namespace {
 
+// the parameter-independent gathers in front of the first recurrences: actor observation rows, keep flags, start carries (and low-pass state)
+int head_gathers(kbj_ctx* ctx, hipStream_t st, const kbj_traj* tr, const int32_t* idx) {
+  NnWs& w = *ws_of(ctx);
+  const int T = tr->T, N = tr->N, H = w.H, B = w.B, R = T * B, D = w.D;
+  const int lda = w.net[0].ld_obs;
+  if (lda % 4 == 0 && ((size_t)tr->actor_obs_d & 15) == 0)
+    hipLaunchKernelGGL(gather_rows4_kernel, g1((size_t)R * (lda / 4)), dim3(256), 0, st, reinterpret_cast<const float4*>(tr->actor_obs_d), idx, T, N, B, lda / 4, lda / 4, lda / 4,
+                       reinterpret_cast<float4*>(w.tb[0].obs));
+  else hipLaunchKernelGGL(gather_rows_kernel, g1((size_t)R * lda), dim3(256), 0, st, tr->actor_obs_d, idx, T, N, B, lda, lda, lda, w.tb[0].obs);
+  GatherSmallArgs gs{tr->action_d, nullptr, nullptr, nullptr, nullptr, tr->aux_d, w.act, w.logp_old, w.val_old, w.adv, w.target, w.keep};
+  hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R), dim3(256), 0, st, gs, idx, T, N, B, KBJ_NU + 4, KBJ_NU + 5);   // keep flags: all the recurrences need of these
+  const float* carry0[4] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d, tr->carry0_actor_mirror_hc_d, tr->carry0_critic_mirror_hc_d};
+  if (w.mirror && (!carry0[2] || !carry0[3] || !tr->carry0_lpf_mirror_d))
+    return kbj_fail(ctx, "PPO pass: the mirror losses are enabled, the trajectory needs the mirror-branch carries");
+  GatherCarryArgs gc;
+  gc.nplanes = 0;
+  for (int n = 0; n < w.nnets; ++n)
+    for (int l = 0; l < D; ++l) {  // carry at the start of the trajectory: [N][H] planes h, c of every layer
+      gc.src[gc.nplanes] = carry0[n] + (size_t)(2 * l) * N * H; gc.dst[gc.nplanes++] = w.tb[n].Hm[l];
+      gc.src[gc.nplanes] = carry0[n] + (size_t)(2 * l + 1) * N * H; gc.dst[gc.nplanes++] = w.tb[n].Cm[l];
+    }
+  gc.nlpf = 0;
+  gc.src[gc.nplanes] = tr->carry0_lpf_d; gc.dst[gc.nplanes] = w.lpf0; gc.nlpf++;
+  if (w.mirror) { gc.src[gc.nplanes + 1] = tr->carry0_lpf_mirror_d; gc.dst[gc.nplanes + 1] = w.lpf0_m; gc.nlpf++; }
+  hipLaunchKernelGGL(gather_carry_kernel, dim3((B * H + 255) / 256, gc.nplanes + gc.nlpf), dim3(256), 0, st, gc, idx, B, H);
+  return 0;
+}
+
 // ---- the first half of a PPO minibatch pass, shared by kbj_ppo_grad and kbj_ppo_forward -----------------------------------------------
 // gathers the minibatch (observations, actions, keep flags, start-of-trajectory carries; with `grad` also the old log-probs / values,
 // advantages and targets), prepares the folded actor weights, and runs both nets forward through time: afterwards w.tb[n].Hout[D-1]
@@ -941,23 +971,14 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
   // critic's first recurrence. (One stream, mirror branches or an unfolded actor: gathered in front of the projection as before.)
   const bool gather_late = !sc.one_stream && !w.mirror && sc.fold_actor;
   if (!gather_late) gather(ns[1], tr->critic_obs_d, w.net[1].ld_obs, w.net[1].ld_obs, w.tb[1].obs, w.net[1].ld_obs);
-  gather(s, tr->actor_obs_d, w.net[0].ld_obs, w.net[0].ld_obs, w.tb[0].obs, w.net[0].ld_obs);
+  // What the FIRST recurrences read besides the parameters - the actor's observation rows, the keep flags, the start carries - depends on
+  // the trajectory and the indices only. kbj_ppo_prefetch has queued these gathers behind the end of the previous kbj_ppo_grad, on a
+  // side lane, where they run under the optimizer step and the folded-weight preparation instead of between them and the first recurrence.
   GatherSmallArgs gs{tr->action_d, grad ? tr->logp_d : nullptr, grad ? tr->value_d : nullptr, adv_d, target_d, tr->aux_d, w.act, w.logp_old, w.val_old, w.adv, w.target, w.keep};
-  hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R), dim3(256), 0, s, gs, idx, T, N, B, KBJ_NU + 4, KBJ_NU + 5);   // keep flags: all the recurrences need of these
-  const float* carry0[4] = {tr->carry0_actor_hc_d, tr->carry0_critic_hc_d, tr->carry0_actor_mirror_hc_d, tr->carry0_critic_mirror_hc_d};
-  if (w.mirror && (!carry0[2] || !carry0[3] || !tr->carry0_lpf_mirror_d))
-    return kbj_fail(ctx, "PPO pass: the mirror losses are enabled, the trajectory needs the mirror-branch carries");
-  GatherCarryArgs gc;
-  gc.nplanes = 0;
-  for (int n = 0; n < w.nnets; ++n)
-    for (int l = 0; l < D; ++l) {  // carry at the start of the trajectory: [N][H] planes h, c of every layer
-      gc.src[gc.nplanes] = carry0[n] + (size_t)(2 * l) * N * H; gc.dst[gc.nplanes++] = w.tb[n].Hm[l];
-      gc.src[gc.nplanes] = carry0[n] + (size_t)(2 * l + 1) * N * H; gc.dst[gc.nplanes++] = w.tb[n].Cm[l];
-    }
-  gc.nlpf = 0;
-  gc.src[gc.nplanes] = tr->carry0_lpf_d; gc.dst[gc.nplanes] = w.lpf0; gc.nlpf++;
-  if (w.mirror) { gc.src[gc.nplanes + 1] = tr->carry0_lpf_mirror_d; gc.dst[gc.nplanes + 1] = w.lpf0_m; gc.nlpf++; }
-  hipLaunchKernelGGL(gather_carry_kernel, dim3((B * H + 255) / 256, gc.nplanes + gc.nlpf), dim3(256), 0, s, gc, idx, B, H);
+  const bool prefetched = w.prefetched_idx == idx && w.prefetched_traj == tr && !sc.one_stream;
+  w.prefetched_idx = nullptr; w.prefetched_traj = nullptr;
+  if (prefetched) KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prefetch, 0));
+  else if (head_gathers(ctx, s, tr, idx)) return -1;
   {
     // Nothing on the forward path needs the rest: actions, old log-probs / values, advantages, targets, the advantage statistics and the
     // cleared accumulators (gradient, folded layer-0 products) are wanted at the loss, two recurrences later. They run on the actor's
@@ -1306,6 +1327,22 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d + w.nactor);
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_grad");
   if (sc.debug_sync) return kbj_synchronize(ctx);   // KBJ_DEBUG=1: surface a hand-off timeout at the call that caused it
+  return 0;
+}
+
+int kbj_ppo_prefetch(kbj_ctx* ctx, const kbj_traj* traj, const int32_t* env_idx_d) {
+  if (!ctx || !ctx->nn_ws || !traj || !env_idx_d) return kbj_fail(ctx, "kbj_ppo_prefetch: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  NnWs& w = *ws_of(ctx);
+  if (traj->T != w.T || traj->N != w.N) return kbj_fail(ctx, "kbj_ppo_prefetch: trajectory shape does not match the context");
+  if (w.sched.one_stream || w.padded()) return 0;      // nothing to overlap with on one lane; padded sizes re-pitch the carries per call: served without the hint
+  hipStream_t lane = ctx->side[1];
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));      // behind everything queued so far (the previous minibatch's last reader of these buffers)
+  KBJ_HIP(ctx, hipStreamWaitEvent(lane, ctx->ev_fork, 0));
+  if (head_gathers(ctx, lane, traj, env_idx_d)) return -1;
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_prefetch, lane));
+  w.prefetched_idx = env_idx_d; w.prefetched_traj = traj;
+  KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_prefetch");
   return 0;
 }
 

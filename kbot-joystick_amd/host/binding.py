@@ -52,6 +52,7 @@ SIGNATURES = {
     "kbj_last_error": (C.c_char_p, [_vp]),
     "kbj_check_config": (_i, [_vp, _vp, _sz]),
     "kbj_set_advantage_sums": (_i, [_vp, _vp]),
+    "kbj_ppo_prefetch": (_i, [_vp, _vp, _vp]),
     "kbj_sizeof_model": (_i, []),
     "kbj_sizeof_config": (_i, []),
     "kbj_sizeof_traj": (_i, []),
@@ -255,6 +256,10 @@ class Context:
         """kbj_ppo_forward: the on-policy pass (no gradients) for the B envs `env_idx` names; outputs are [T][B](x20) in env_idx order."""
         out = PpoVars(_ptr(logp), _ptr(value), _ptr(entropy), _ptr(action_std), _ptr(action_mean))
         self.call("kbj_ppo_forward", _ptr(params), C.byref(traj), _ptr(env_idx), B, C.byref(out))
+
+    def ppo_prefetch(self, traj: "Traj", env_idx):
+        """kbj_ppo_prefetch: queue the parameter-independent gathers of the NEXT ppo_grad (same traj / env_idx pointers) now."""
+        self.call("kbj_ppo_prefetch", C.byref(traj), _ptr(env_idx))
 
     def set_advantage_sums(self, sums):
         """kbj_set_advantage_sums: a float64 [3] device tensor (sum adv, sum adv^2, count) or None (default: each minibatch's own)."""

@@ -174,6 +174,9 @@ def launch_config(**overrides) -> HumanoidWalkingTaskConfig:
     return HumanoidWalkingTaskConfig(**kw)
 
 
+_NO_PREFETCH = os.environ.get("KBJ_NO_PREFETCH", "0") not in ("0", "")     # A/B switch: kbj_ppo_prefetch is a pure scheduling hint
+
+
 class HumanoidWalkingTask:
     """Rollout + PPO update of the K-Bot joystick task on one GPU of a data-parallel job.
 
@@ -407,6 +410,10 @@ class HumanoidWalkingTask:
                     self._adv_sums = dist_util.global_advantage_sums(self.traj.adv.index_select(1, idx.long()), self.world_size)   # kept alive until the call has run
                     self.ctx.set_advantage_sums(self._adv_sums)
                 self.ctx.ppo_grad(self.params, self.traj.c, idx, self.B, self.traj.adv, self.traj.target, self.grad, self.metrics)
+                # next-minibatch hint: its parameter-independent gathers run under this minibatch's exchange + optimizer step
+                nxt = perm[(mb + 1) * self.B:(mb + 2) * self.B] if mb + 1 < nmb else (self._perm_dev[p + 1][:self.B] if p + 1 < npass else None)
+                if nxt is not None and not _NO_PREFETCH:
+                    self.ctx.ppo_prefetch(self.traj.c, nxt.contiguous())
                 if per_pass:
                     self.grad_acc.add_(self.grad)          # kbj_ppo_grad overwrites `grad`; the pass total lives in grad_acc
                     if mb + 1 < nmb:

@@ -184,6 +184,47 @@ def test_deterministic_update_is_bit_reproducible(monkeypatch):
         t.ctx.close()
 
 
+def test_next_minibatch_prefetch_changes_nothing(monkeypatch):
+    """kbj_ppo_prefetch is a scheduling hint: with the deterministic reductions the gradient of minibatch k + 1 is bit-identical whether its
+    head gathers were queued behind minibatch k (under the optimizer step) or run inside its own call; a prefetch for OTHER indices is
+    ignored; and an update with the hint (HumanoidWalkingTask.update issues it) equals a manual loop without it."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    from tests.test_gpu_host import _small
+    for k in list(os.environ):
+        if k.startswith("KBJ_") and k != "KBJ_LIB_NAME":
+            monkeypatch.delenv(k)
+    cfg = _small(num_envs=128, batch_size=32, num_passes=1, deterministic=True)
+    task = HumanoidWalkingTask(cfg)
+    task.rollout()
+    task.ctx.gae(task.traj.c, task.traj.adv, task.traj.target)
+    perm = torch.randperm(128, generator=torch.Generator().manual_seed(1)).int().cuda()
+    i0, i1, i2 = (perm[32 * k:32 * k + 32].contiguous() for k in range(3))
+    g = [torch.zeros_like(task.params) for _ in range(4)]
+    call = lambda idx, out: task.ctx.ppo_grad(task.params, task.traj.c, idx, 32, task.traj.adv, task.traj.target, out, task.metrics)
+    call(i0, g[0]); call(i1, g[1])                                   # reference: no hint
+    call(i0, g[2]); task.ctx.ppo_prefetch(task.traj.c, i1); call(i1, g[3])
+    torch.cuda.synchronize()
+    assert torch.equal(g[0], g[2]) and torch.equal(g[1], g[3])
+    task.ctx.ppo_prefetch(task.traj.c, i2); call(i1, g[3])           # a hint for other indices is not used
+    torch.cuda.synchronize()
+    assert torch.equal(g[1], g[3])
+    # whole update (hinted) against the manual loop (not hinted)
+    ref = HumanoidWalkingTask(cfg)
+    for name in ("actor_obs", "critic_obs", "aux", "action", "logp", "value", "reward", "carry0_actor_hc", "carry0_critic_hc", "carry0_lpf"):
+        getattr(ref.traj, name).copy_(getattr(task.traj, name))
+    task.update()
+    ref.ctx.gae(ref.traj.c, ref.traj.adv, ref.traj.target)
+    gen = torch.Generator(device="cpu"); gen.manual_seed((cfg.seed * 1000003 + 0 * 97 + 0) & 0x7FFFFFFF)
+    pm = torch.randperm(128, generator=gen).int().cuda()
+    for mb in range(4):
+        ref.ctx.ppo_grad(ref.params, ref.traj.c, pm[32 * mb:32 * mb + 32].contiguous(), 32, ref.traj.adv, ref.traj.target, ref.grad, ref.metrics)
+        ref.ctx.adamw_step(ref.params, ref.opt_m, ref.opt_v, ref.grad, mb + 1, 1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(task.params, ref.params)
+    task.ctx.close(); ref.ctx.close()
+
+
 def test_deterministic_gradient_at_the_baseline_minibatch(monkeypatch):
     """512 envs x 100 steps, H = 256: the deterministic gradient is bit-identical call to call and within 1e-5 (relative L2) of the atomic one."""
     import torch
