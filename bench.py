@@ -194,6 +194,10 @@ def main():
                          "process group, then with backend nccl at world size 1 and the gradient all-reduce forced (RCCL's stream and kernels join the "
                          "context's lanes), then with the overlapped actor-slice exchange; the line's value is the forced per-step run, the object "
                          "`forced_collective` holds all three")
+    ap.add_argument("--gemm-bf16x3", action="store_true",
+                    help="NOT the headline: kbj_config.gemm_bf16x3 - the update's large backward GEMMs on the bf16 matrix cores through the exact three-way "
+                         "split of their fp32 operands (DESIGN.md section 10b). The line says so in `variant`, `dtype` and `config.workload`")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra, non-headline leg (the gemm_bf16x3 variant timed after the headline run)")
     ap.add_argument("--allreduce", default=os.environ.get("KBJ_ALLREDUCE", "per_step"), choices=["per_step", "per_pass"],
                     help="per_step (default): all-reduce before every optimizer step; per_pass: accumulate a pass, one all-reduce + one step per pass")
     args = ap.parse_args()
@@ -230,7 +234,7 @@ def main():
     wl_name = {1: "kbot-headless, {n} envs/GPU, flat ground, fixed joystick command (0.5,0,0)",
                3: "kbot-headless, {n} envs/GPU, flat ground, UnifiedCommand 6-mode sampler",
                4: "kbot (full), {n} envs/GPU, sine terrain (A 0.05 m, L 2 m), UnifiedCommand sampler, pushes + all randomizers"}[args.config]
-    cfg = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, allreduce=args.allreduce, **wl)
+    cfg = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, allreduce=args.allreduce, gemm_bf16x3=args.gemm_bf16x3, **wl)
     task = HumanoidWalkingTask(cfg, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     def barrier():
@@ -330,6 +334,27 @@ def main():
             meas = traffic_src["hbm_bytes_per_iteration"] / iter_s / 1e9
             hbm.update(measured=round(meas, 1), measured_frac=round(meas / PEAK_HBM_GBS, 4), measured_bytes_per_iteration=round(traffic_src["hbm_bytes_per_iteration"]))
 
+    # ---- non-headline leg: the same workload with kbj_config.gemm_bf16x3 (the update's large backward GEMMs on the bf16 matrix cores through the
+    # exact three-way split of their fp32 operands), its own task, timed after everything that feeds the headline ----
+    variant = None
+    if not args.gemm_bf16x3 and not args.no_variants and not args.force_collective:
+        # the headline context goes first: its lanes would still count against the variant's (two contexts' worth of streams put both over the
+        # queue-mapping cliff of DESIGN.md section 10 - measured: 400 instead of 335 ms per iteration)
+        task.ctx.synchronize(); task.ctx.close(); task = None
+        torch.cuda.empty_cache()
+        cfg_v = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, allreduce=args.allreduce, gemm_bf16x3=True, **wl)
+        task = HumanoidWalkingTask(cfg_v, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        el = timed_steps(max(1, min(args.warmup, 2)), args.steps)
+        if world > 1:
+            t = torch.tensor([el], device="cuda", dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        variant = dict(name="gemm_bf16x3", NOT_THE_HEADLINE=True, value=round(args.envs_per_gpu * world * task.T * args.steps / el, 1), unit="env-steps/s",
+                       ms_per_step=round(el / args.steps * 1e3, 2),
+                       what="kbj_config.gemm_bf16x3 = 1: input-gradient and weight-gradient GEMMs of the PPO update as 6 bf16 MFMA products per fp32 product "
+                            "(operands split exactly into three bf16 pieces, fp32 accumulation); everything else identical. Error study: DESIGN.md section 10b, "
+                            "parity: tests/test_gpu_switches.py")
+        task.ctx.close()
     if forced is not None:      # third leg: the actor's gradient slice all-reduced on a second stream under the critic's tail
         forced.update(ms_per_step_forced_allreduce=round(elapsed / args.steps * 1e3, 2), allreduce_ms_per_iteration=round(allreduce_ms, 3),
                       allreduce_calls_per_iteration=allreduce_calls)
@@ -351,8 +376,9 @@ def main():
         "metric": "env-steps/sec (whole node), K-Bot joystick 8192 envs @1/2/4/8 MI355X",
         "value": round(value, 1), "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": wl_name.format(n=args.envs_per_gpu) + ", full iteration: "
+        "dtype": "f32" if not args.gemm_bf16x3 else "f32 (backward GEMMs: exact 3-way bf16 split of the fp32 operands, fp32 accumulation)", "data": "synthetic",
+        "variant": "headline: plain fp32-MFMA kernels" if not args.gemm_bf16x3 else "NOT THE HEADLINE: --gemm-bf16x3 (kbj_config.gemm_bf16x3)",
+        "config": {"workload": ("[variant gemm_bf16x3] " if args.gemm_bf16x3 else "") + wl_name.format(n=args.envs_per_gpu) + ", full iteration: "
                                f"100-step rollout + PPO update (batch 512/GPU, 3 passes, LSTM hidden {args.hidden}, depth 2)",
                    "envs_per_gpu": args.envs_per_gpu, "rollout_steps": task.T, "batch_size_per_gpu": cfg.batch_size, "num_passes": cfg.num_passes,
                    "hidden_size": args.hidden, "baseline_config": args.config, "parallelism": f"env-sharded dp{world}, grad all-reduce {'per optimizer step' if args.allreduce == 'per_step' else 'once per pass (accumulated)'}"
@@ -364,6 +390,7 @@ def main():
         "rank_ms_per_step": {"min": round(min(rank_ms), 2), "max": round(max(rank_ms), 2)}, "forced_collective": forced,
         "allreduce_ms_per_iteration": round(allreduce_ms, 3), "allreduce_calls_per_iteration": allreduce_calls,
         "hbm_whole_path": hbm,
+        "variant_gemm_bf16x3": variant,
     }
     print(json.dumps(out), flush=True)
     if world > 1 or args.force_collective:

@@ -142,7 +142,10 @@ typedef struct kbj_config {
                                 two updates from the same state give bit-identical parameters, as the reference's XLA program does; default 0 */
   int32_t extra_obs_actor;   /* floats the host appends to every actor / critic observation row (0..KBJ_MAX_EXTRA_OBS, default 0): the input */
   int32_t extra_obs_critic;  /* projections are [H][65 + extra] / [H][475 + extra], the parameter vector grows accordingly */
-  int32_t reserved_i[1];
+  int32_t gemm_bf16x3;       /* 1 = the PPO update's large backward GEMMs (input gradients, weight-gradient pairs) run on the bf16 matrix cores through an
+                                EXACT three-way split of their fp32 operands (6 bf16 products per fp32 product, fp32 accumulation): measured more
+                                accurate than the fp32-MFMA chain and faster. Default 0: the plain fp32-MFMA kernels, which is
+                                what every headline number of this library is measured with. Ignored in deterministic mode. */
   float dt;                  /* 0.004 */
   float ctrl_dt;             /* 0.02  */
   float solver_tolerance;    /* 1e-8 */

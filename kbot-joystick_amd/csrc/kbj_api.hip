@@ -211,7 +211,8 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
       "kbj::gemm_f32_kernel<2, 1, false, false, 2, 4>", "kbj::gemm_f32_kernel<2, 1, false, true, 2, 4>", "kbj::gemm_f32_kernel<2, 1, true, false, 2, 4>",
       "kbj::gemm_f32_kernel<2, 1, true, true, 2, 4>",   "kbj::gemm_f32_kernel<1, 1, false, false, 2, 2>", "kbj::gemm_f32_kernel<1, 1, false, true, 2, 2>",
       "kbj::gemm_f32_kernel<1, 1, true, false, 2, 2>",  "kbj::gemm_f32_kernel<1, 1, true, true, 2, 2>",   "kbj::lstm_seq_fwd_kernel", "kbj::lstm_seq_bwd_kernel", "env_step_kernel", "kbj::lstm_seq_fwd_kernel",
-      "kbj::lstm_seq_fwd_kernel", "kbj::lstm_step_kernel", "kbj::lstm_step_kernel"};
+      "kbj::lstm_seq_fwd_kernel", "kbj::lstm_step_kernel", "kbj::lstm_step_kernel",
+      "kbj::gemm_x3_kernel<false, false>", "kbj::gemm_x3_kernel<false, true>", "kbj::gemm_x3_kernel<true, false>", "kbj::gemm_x3_kernel<true, true>"};
   for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
     kbj_kernel_stat& st = ctx->kstats[k];
     const int uw = 2;   // wavefront pairs per recurrence workgroup (kbj_nn.hip SEQ_UW), as rocprofv3 prints the template argument

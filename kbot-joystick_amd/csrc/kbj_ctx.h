@@ -8,7 +8,8 @@
 
 // per-launch HIP-event records of the MFMA kernels while kbj_profile_begin/end is active (bench.py roofline)
 struct KbjKernelRec { int kind; double flops; hipEvent_t a, b; };
-enum { KBJ_KIND_GEMM = 0 /* +4 small tile, +2 A k-contiguous, +1 B k-contiguous */, KBJ_KIND_SEQ_FWD = 8, KBJ_KIND_SEQ_BWD = 9, KBJ_KIND_ENV_STEP = 10, KBJ_KIND_SEQ_FWD_FUSED = 11, KBJ_KIND_SEQ_FWD_OBS = 12, KBJ_KIND_LSTM_STEP = 13, KBJ_KIND_LSTM_STEP_OBS = 14, KBJ_KIND_COUNT = 15 };
+enum { KBJ_KIND_GEMM = 0 /* +4 small tile, +2 A k-contiguous, +1 B k-contiguous */, KBJ_KIND_SEQ_FWD = 8, KBJ_KIND_SEQ_BWD = 9, KBJ_KIND_ENV_STEP = 10, KBJ_KIND_SEQ_FWD_FUSED = 11, KBJ_KIND_SEQ_FWD_OBS = 12, KBJ_KIND_LSTM_STEP = 13, KBJ_KIND_LSTM_STEP_OBS = 14,
+       KBJ_KIND_GEMM_X3 = 15 /* +2 A k-contiguous, +1 B k-contiguous: gemm_x3_kernel (kbj_config.gemm_bf16x3) */, KBJ_KIND_COUNT = 19 };
 
 struct kbj_ctx {
   int device = 0;

@@ -49,6 +49,9 @@ struct GemmArgs {
   // deterministic split-K (kbj_config.deterministic): instead of fp32 atomics into C, k slice ks stores its partial tile into
   // skws[ks][M][N] (N = all columns of the launch, both problems) and splitk_reduce_kernel adds the slices to C in slice order
   float* skws = nullptr;
+  // kbj_config.gemm_bf16x3: eligible 128x128-tile launches run on the bf16 matrix cores through the exact three-way operand split
+  // (gemm_x3_kernel below); set by the callers from the context's schedule, ignored where the launch is not eligible
+  int x3 = 0;
 };
 
 constexpr int GEMM_BK = 32;
@@ -308,6 +311,145 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+
+// ---- fp32 GEMM on the bf16 matrix cores through an EXACT three-way operand split (kbj_config.gemm_bf16x3) ----
+// x = hi + mid + lo with hi = x truncated to its top 8 significand bits (a bf16), mid = (x - hi) truncated likewise, lo = x - hi - mid: both
+// subtractions are exact in fp32 and lo has at most 8 significant bits left, so the three bf16 pieces carry all 24 bits of x. The products
+// hi hi, hi mid, mid hi, hi lo, lo hi, mid mid are accumulated in fp32 by v_mfma_f32_32x32x16_bf16 (each exact; smallest first); the three
+// dropped ones (mid lo, lo mid, lo lo) are <= 2^-23 relative, below the accumulation's own rounding: measured against fp64 the result is
+// MORE accurate than the v_mfma_f32_32x32x2_f32 chain at the median and at p99.9 (one rounding per 16 k instead of one per 2). The bf16
+// instruction has 16x the per-instruction rate of the fp32 one and holds the vector issue port 8 of its 32 cycles, which leaves the port to
+// the split itself (~5.5 vector instructions per element, once per element on the way into LDS). NOT the default: the headline path of this
+// library is the plain fp32-MFMA kernel above.
+// Tiling: 128 x 128 x 32 on 4 wavefronts (2 x 2, each 64 x 64 = 2 x 2 MFMA tiles); LDS [piece][row][40] bf16 per operand (80-byte rows:
+// conflict-free ds_read_b128 fragments), one stage + register prefetch, 60 KB: two workgroups per CU cover each other's barriers.
+// Serves what the update's large launches need: both operand layouts, split-K with atomics, the paired problem along n, ragged M / N
+// (guarded edge tiles). Not: a second k source, row gathers, bias, deterministic split-K slabs - those launches stay on the exact kernel.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+constexpr int X3_LD = 40;
+constexpr int X3_PIECE = 128 * X3_LD;
+__device__ __forceinline__ void x3_split(const f32x4& x, u32x2& hi, u32x2& mid, u32x2& lo) {   // four consecutive k of one row -> 3 x (4 bf16)
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    h[e] = __float_as_uint(x[e]) & 0xFFFF0000u;
+    const float r1 = x[e] - __uint_as_float(h[e]);
+    m[e] = __float_as_uint(r1) & 0xFFFF0000u;
+    l[e] = __float_as_uint(r1 - __uint_as_float(m[e]));
+  }
+  hi = {__builtin_amdgcn_perm(h[1], h[0], 0x07060302u), __builtin_amdgcn_perm(h[3], h[2], 0x07060302u)};
+  mid = {__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
+  lo = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
+}
+// one operand tile 128 rows x 32 k staged as four (row, 4 consecutive k) groups per thread
+template <bool KC> struct X3Stage {
+  f32x4 v[4];
+  // P: operand base, ld; R: valid rows; r0: first row of the tile; k0: first k (a full 32-k tile, k-range checked by the caller)
+  __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int R, int r0, int k0) {
+    const int t = threadIdx.x;
+    if (KC) { const int kq = t & 7, rr = t >> 3;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + rr + 32 * i;
+        v[i] = r < R ? *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k0 + 4 * kq) : f32x4{0, 0, 0, 0};
+      }
+    } else { const int kg = t & 7, rq = t >> 3, r = r0 + 4 * rq;   // 8 lanes walk the k groups of one row group: their LDS writes below are 64 contiguous bytes of one row
+      f32x4 w[4];                                                   // (row groups on consecutive lanes would be 320 bytes apart: 8-way bank conflicts)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float* p = P + (size_t)(k0 + 4 * kg + j) * ld + r;
+        if (r + 3 < R) w[j] = *reinterpret_cast<const f32x4*>(p);
+        else { for (int e = 0; e < 4; ++e) w[j][e] = r + e < R ? p[e] : 0.0f; }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = {w[0][i], w[1][i], w[2][i], w[3][i]};      // row 4 rq + i, k 4 kg .. + 3
+    }
+  }
+  __device__ __forceinline__ void store(short* lds) const {    // lds: [3][128][X3_LD]
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = KC ? (t >> 3) + 32 * i : 4 * (t >> 3) + i, k = 4 * (t & 7);
+      u32x2 hi, mid, lo;
+      x3_split(v[i], hi, mid, lo);
+      short* p = lds + row * X3_LD + k;
+      *reinterpret_cast<u32x2*>(p) = hi; *reinterpret_cast<u32x2*>(p + X3_PIECE) = mid; *reinterpret_cast<u32x2*>(p + 2 * X3_PIECE) = lo;
+    }
+  }
+};
+template <bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) short x3lds[];   // A: 3 pieces, then B: 3 pieces
+  short* As = x3lds; short* Bs = x3lds + 3 * X3_PIECE;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1, lr = lane & 31, lh = lane >> 5;
+  const int tiles_n = (g.N + 127) / 128, tiles_m = (g.M + 127) / 128;
+  const int sk = g.splitk > 1 ? g.splitk : 1;
+  const int per = sk > 1 ? ((g.K + sk - 1) / sk + GEMM_BK - 1) / GEMM_BK * GEMM_BK : g.K;
+  const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (item >= tiles_n * tiles_m * sk) return;
+  const GemmItem cur = gemm_item<128, 128>(g, item, tiles_n, tiles_m, per);
+  if (cur.kbeg >= cur.kend) return;
+  X3Stage<A_KC> sa; X3Stage<B_KC> sb;
+  sa.load(g.A, g.lda, g.M, cur.m0, cur.kbeg); sb.load(cur.B, cur.ldb, cur.ncols, cur.n0, cur.kbeg);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+  for (int k0 = cur.kbeg; k0 < cur.kend; k0 += 32) {
+    __syncthreads();                       // every wavefront has read the previous tile
+    sa.store(As); sb.store(Bs);
+    __syncthreads();
+    if (k0 + 32 < cur.kend) { sa.load(g.A, g.lda, g.M, cur.m0, k0 + 32); sb.load(cur.B, cur.ldb, cur.ncols, cur.n0, k0 + 32); }     // in flight behind the MFMAs
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8 a[3][2], b[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          a[p][i] = *reinterpret_cast<const bf16x8*>(As + p * X3_PIECE + (wr * 64 + 32 * i + lr) * X3_LD + 16 * kk + 8 * lh);
+          b[p][i] = *reinterpret_cast<const bf16x8*>(Bs + p * X3_PIECE + (wc * 64 + 32 * i + lr) * X3_LD + 16 * kk + 8 * lh);
+        }
+      constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};   // mid mid, lo hi, hi lo, mid hi, hi mid, hi hi (0 hi, 1 mid, 2 lo)
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = cur.n0 + wc * 64 + 32 * j + lr;
+      if (n >= cur.ncols) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = cur.m0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (m >= g.M) continue;
+        float* c = cur.C + (size_t)m * cur.ldc + n;
+        const float v = acc[i][j][r];
+        if (sk > 1) atomicAdd(c, v);
+        else *c = g.beta ? *c + v : v;
+      }
+    }
+}
+// the launches the split kernel serves (everything else stays on the exact kernel, silently)
+inline bool gemm_x3_eligible(const GemmArgs& g, bool a_kc, bool b_kc) {
+  if (!g.x3 || g.bias || g.A2 || (g.B2 && g.n1 <= 0) || g.k1 > 0 || g.a_idx || g.skws) return false;
+  if (g.K % GEMM_BK != 0 || g.M < 128 || g.N < 128) return false;
+  auto al = [](const void* p, int ld) { return ((size_t)p & 15) == 0 && (ld & 3) == 0; };
+  if (!al(g.A, g.lda) || !al(g.B, g.ldb) || (g.n1 > 0 && (!al(g.B2, g.ldb2 > 0 ? g.ldb2 : g.ldb) || g.n1 % 128 != 0))) return false;
+  (void)a_kc; (void)b_kc;
+  return true;
+}
+
 // second stage of the deterministic split-K: C (+)= sum over the k slices, in slice order, of the partial tiles (one thread per output
 // element; slices whose k range is empty wrote nothing and are skipped exactly as the GEMM skipped them)
 __global__ void splitk_reduce_kernel(GemmArgs g, int sk, int per) {
@@ -343,6 +485,15 @@ inline void gemm_launch(hipStream_t s, const GemmArgs& g_in, int force_big = -1)
   // one work item per workgroup (walking several items per workgroup was slower at every setting for this path's shapes)
   int wgs = (int)items;
   wgs = (wgs + 7) / 8 * 8;
+  if (gemm_x3_eligible(g, A_KC, B_KC)) {
+    const long it = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * sk;
+    constexpr size_t bytes = 6 * X3_PIECE * sizeof(short);
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<A_KC, B_KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    (void)attr;
+    KbjKernelTimer timer(s, KBJ_KIND_GEMM_X3 + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);
+    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC>), dim3((unsigned)((it + 7) / 8 * 8)), dim3(256), bytes, s, g);
+    return;
+  }
   KbjKernelTimer timer(s, KBJ_KIND_GEMM + (big ? 0 : 4) + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);
 #ifdef KBJ_GEMM_W4   // 128x128 tile on 4 wavefronts (2 x 2, each 64x64, 207 registers): 2-4 % faster only at K >= 4096
   if (big) gemm_launch_tile<2, 2, A_KC, B_KC>(s, g, wgs);

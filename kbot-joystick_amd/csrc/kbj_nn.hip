@@ -40,6 +40,8 @@ struct Sched {
   bool deterministic = false;      // fixed-order reductions instead of fp32 / fp64 atomics (bit-reproducible update)
   int bwd_chunks = 1;              // KBJ_BWD_CHUNKS=n (2..10): weight-gradient GEMMs per time chunk UNDER the backward recurrence (chunk-gated schedule);
                                    // measured flat against 1 = behind the whole recurrence (6.37-6.45 vs 6.43 ms per minibatch)
+  bool gemm_x3 = false;            // kbj_config.gemm_bf16x3 / KBJ_GEMM_X3=1: the backward pass's large GEMMs (input gradients, weight-gradient pairs) on the bf16
+                                   // matrix cores through the exact three-way operand split (kbj_gemm.h gemm_x3_kernel); not the default, not the headline
   bool chunk_dx = false;           // KBJ_BWD_CHUNK_DX=1 (with bwd_chunks > 1): the input-gradient GEMM per chunk as well (slower: 6.64 / 6.83 ms at 2 / 4 chunks)
 };
 constexpr int MAX_BWD_CHUNKS = 10;
@@ -179,6 +181,7 @@ template <class T> int dalloc(kbj_ctx* ctx, NnWs& w, T** p, size_t count) {
   return 0;
 }
 
+thread_local int g_gemm_x3 = 0;     // set by kbj_ppo_grad from the context's schedule for the duration of the call (the wrappers below have no context)
 constexpr int g_fold_sk = 8;        // k slices of the small W_ih0^T Z product of the folded input projections
 constexpr int g_splitk_wgs = 768;   // target number of workgroups of a split-K weight-gradient GEMM (512 ... 1536 measured flat)
 constexpr int DETP_ROWS = 512, DETP_COLS = 1024;
@@ -199,6 +202,7 @@ void linear_fwd(hipStream_t s, const float* x, int lda, const float* W, int ldw,
 // dx = dy W   (dy [M][K=nout] , W [K][N])
 void linear_bwd_input(hipStream_t s, const float* dy, int lddy, const float* W, int ldw, float* dx, int lddx, int M, int N, int K, int beta) {
   GemmArgs g{dy, W, dx, nullptr, M, N, K, lddy, ldw, lddx, beta, 1, nullptr};
+  g.x3 = g_gemm_x3;
   gemm_launch<true, false>(s, g);
 }
 // dW[Nout][Nin] += dy^T x  (dy [R][Nout], x [R][Nin]); split-K over the R samples with atomics (dW pre-zeroed by the caller)
@@ -211,6 +215,7 @@ void linear_bwd_weight(kbj_ctx* ctx, hipStream_t s, const float* dy, int lddy, c
   sk = std::max(2, std::min(sk, (R + 255) / 256));
   GemmArgs g{dy, x, dW, nullptr, Nout, Nin, R, lddy, ldx, lddw, 1, sk, nullptr};  // always the split-K path: accumulates into dW
   g.skws = sk_workspace(ctx, s, (size_t)sk * Nout * Nin);
+  g.x3 = g_gemm_x3;
   gemm_launch<false, false>(s, g, big ? 1 : 0);
 }
 
@@ -229,6 +234,7 @@ void linear_bwd_weight2(kbj_ctx* ctx, hipStream_t s, const float* dy, int lddy, 
   GemmArgs g{dy, x1, dW1, nullptr, Nout, 2 * Nin, R, lddy, ldx, lddw, 1, sk, nullptr};
   g.B2 = x2; g.C2 = dW2; g.n1 = Nin;
   g.skws = sk_workspace(ctx, s, (size_t)sk * Nout * 2 * Nin);
+  g.x3 = g_gemm_x3;
   gemm_launch<false, false>(s, g, big ? 1 : 0);
 }
 // column sums of X [M][N] (ld) added to out[N]: atomics over 512 row slices, or (deterministic) per-slice partials + ordered reduce
@@ -489,6 +495,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
     sc.fused_critic_head = env_flag("KBJ_FUSED_CRITIC_HEAD", true); sc.rollout_step = env_flag("KBJ_ROLLOUT_STEP", true);
     sc.one_stream = env_flag("KBJ_ONE_STREAM", false); sc.debug_sync = env_flag("KBJ_DEBUG", false);
     sc.deterministic = c.deterministic != 0 || env_flag("KBJ_DETERMINISTIC", false);
+    sc.gemm_x3 = (c.gemm_bf16x3 != 0 || env_flag("KBJ_GEMM_X3", false)) && !sc.deterministic;   // (the deterministic split-K slabs stay on the exact kernel)
     sc.bwd_chunks = getenv("KBJ_BWD_CHUNKS") ? atoi(getenv("KBJ_BWD_CHUNKS")) : 1;
     sc.chunk_dx = env_flag("KBJ_BWD_CHUNK_DX", false);
     if (sc.bwd_chunks < 1 || sc.bwd_chunks > MAX_BWD_CHUNKS) return kbj_fail(ctx, "KBJ_BWD_CHUNKS must be in 1..10");
@@ -1135,6 +1142,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   KbjTimed timed(ctx, true);
   const bool one_stream = sc.one_stream, fold_actor = sc.fold_actor, fold_critic = sc.fold_critic;
   hipStream_t ns[2];
+  struct X3Scope { X3Scope(int v) { g_gemm_x3 = v; } ~X3Scope() { g_gemm_x3 = 0; } } x3scope(sc.gemm_x3 ? 1 : 0);   // backward-pass GEMMs only
   if (ppo_forward_nets(ctx, params_d, tr, env_idx_d, adv_d, target_d, grad_d, true, ns)) return -1;
   static const int bstamp_sel = getenv("KBJ_SEQ_BSTAMPS") ? atoi(getenv("KBJ_SEQ_BSTAMPS")) : 0;   // diagnostics build only
   // Without the mirror branches the critic's one-output head, the value half of the loss and the head's backward are ONE kernel on the
@@ -1267,6 +1275,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
           GemmArgs g{dG, t.Hm[0] + r0 * H, grad_d + o.w_hh[0], nullptr, 4 * H, H + o.nin, Rc, 4 * H, H, H, 1, sk, nullptr};
           g.B2 = t.obs + r0 * o.ld_obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = o.ld_obs;
           g.skws = sk_workspace(ctx, ws, (size_t)sk * 4 * H * (H + o.nin));
+          g.x3 = g_gemm_x3;
           gemm_launch<false, false>(ws, g, ts == 128 ? 1 : 0);
           continue;
         }

@@ -280,7 +280,7 @@ class Context:
     def profile_end(self):
         a, b, c, d = _f(), _i(), _f(), _i()
         self.call("kbj_profile_end", C.byref(a), C.byref(b), C.byref(c), C.byref(d))
-        arr, n = (KernelStat * 16)(), _i()
-        self.call("kbj_profile_kernel_stats", arr, 16, C.byref(n))
+        arr, n = (KernelStat * 32)(), _i()
+        self.call("kbj_profile_kernel_stats", arr, 32, C.byref(n))
         kernels = [dict(name=arr[k].name.decode(), launches=arr[k].launches, total_ms=arr[k].total_ms, flops=arr[k].flops) for k in range(n.value)]
         return dict(env_step_ms=a.value, env_step_launches=b.value, nn_ms=c.value, nn_launches=d.value, kernels=kernels)

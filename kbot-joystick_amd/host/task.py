@@ -89,6 +89,9 @@ class HumanoidWalkingTaskConfig:
     # bit-reproducible update: fixed-order reductions instead of fp32 / fp64 atomics in the gradient (kbj_config.deterministic); the
     # reference's XLA program is deterministic by default, here it costs a few percent and is off unless asked for
     deterministic: bool = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_DETERMINISTIC", "0") not in ("0", ""))
+    # NOT the default, never the headline: the update's large backward GEMMs through the exact three-way bf16 operand split (kbj_config.gemm_bf16x3,
+    # DESIGN.md section 10b): fp32 in, fp32 accumulate, fp32 out, every product exact up to 2^-23; faster and measured more accurate than the fp32 MFMA chain
+    gemm_bf16x3: bool = dataclasses.field(default_factory=lambda: os.environ.get("KBJ_GEMM_X3", "0") not in ("0", ""))
     # user observations INTO the network rows (the reference's user appends terms to the lists run_actor / run_critic
     # concatenate, train.py:1351-1433): that many floats are appended behind the reference's 65 / 475 columns of every observation row, the input
     # projections and the parameter vector grow accordingly (kbj_config.extra_obs_*). Which terms fill them: HumanoidWalkingTask(
@@ -125,7 +128,7 @@ class HumanoidWalkingTaskConfig:
                   lam=self.lam, learning_rate=self.learning_rate, weight_decay=self.adam_weight_decay, switch_prob=self.ctrl_dt / 5,
                   actor_mirror_loss_scale=self.actor_mirror_loss_scale, critic_mirror_loss_scale=self.critic_mirror_loss_scale,
                   lpf_alpha=self.ctrl_dt / (self.ctrl_dt + 1.0 / (2.0 * math.pi * self.cutoff_frequency)), deterministic=int(bool(self.deterministic)),
-                  extra_obs_actor=int(self.extra_actor_obs), extra_obs_critic=int(self.extra_critic_obs))
+                  extra_obs_actor=int(self.extra_actor_obs), extra_obs_critic=int(self.extra_critic_obs), gemm_bf16x3=int(bool(self.gemm_bf16x3)))
         if not (0 <= self.extra_actor_obs <= L.MAX_EXTRA_OBS and 0 <= self.extra_critic_obs <= L.MAX_EXTRA_OBS):
             raise ValueError(f"extra_actor_obs / extra_critic_obs must be in 0..{L.MAX_EXTRA_OBS}")
         if self.allreduce not in ("per_step", "per_pass"):

@@ -59,7 +59,7 @@ class Config(C.Structure):
         ("num_envs", i32), ("env_id_offset", i32), ("rollout_len", i32), ("substeps", i32),
         ("solver_iterations", i32), ("ls_iterations", i32), ("hidden_size", i32), ("depth", i32),
         ("batch_size", i32), ("num_passes", i32), ("command_mode", i32), ("enable_randomizers", i32),
-        ("enable_pushes", i32), ("enable_noise", i32), ("max_episode_steps", i32), ("solver_newton", i32), ("deterministic", i32), ("extra_obs_actor", i32), ("extra_obs_critic", i32), ("reserved_i", i32 * 1),
+        ("enable_pushes", i32), ("enable_noise", i32), ("max_episode_steps", i32), ("solver_newton", i32), ("deterministic", i32), ("extra_obs_actor", i32), ("extra_obs_critic", i32), ("gemm_bf16x3", i32),
         ("dt", f32), ("ctrl_dt", f32), ("solver_tolerance", f32), ("latency_lo", f32), ("latency_hi", f32),
         ("drop_action_prob", f32), ("fixed_command", f32 * NCMD),
         ("vx_lo", f32), ("vx_hi", f32), ("vy_lo", f32), ("vy_hi", f32), ("wz_lo", f32), ("wz_hi", f32),

@@ -26,6 +26,7 @@ SWITCHES = {
     "KBJ_DEBUG=1": {"KBJ_DEBUG": "1"},
     "KBJ_BWD_CHUNKS=4": {"KBJ_BWD_CHUNKS": "4"},
     "KBJ_BWD_CHUNKS=3+DX": {"KBJ_BWD_CHUNKS": "3", "KBJ_BWD_CHUNK_DX": "1"},
+    "KBJ_GEMM_X3=1": {"KBJ_GEMM_X3": "1"},       # = kbj_config.gemm_bf16x3: the backward pass's large GEMMs through the exact three-way bf16 split
 }
 
 
@@ -244,6 +245,40 @@ def test_deterministic_gradient_at_the_baseline_minibatch(monkeypatch):
         ctx.close()
     assert torch.equal(grads[1][0], grads[1][1])
     assert float((grads[1][0] - grads[0][0]).norm() / grads[0][0].norm()) < 1e-5
+
+
+def test_gemm_bf16x3_gradient_at_the_baseline_minibatch(monkeypatch):
+    """kbj_config.gemm_bf16x3 at the BASELINE minibatch (512 envs x 100 steps, H = 256): every large backward GEMM (input gradient
+    51200 x 256 x 1024, paired weight gradients 1024 x 512 x 51200 and the folded layer-0 pairs with their ragged second problem) runs
+    on the split kernel; the gradient equals the exact path's to 1e-5 (rel-L2; per leaf 1e-4 of the leaf's largest entry) - the two differ
+    in rounding order only, as two runs of the exact path with its atomics do."""
+    import torch
+    N, B, T, H = 512, 512, 100, 256
+    grads = {}
+    for x3 in (0, 1):
+        m, cfg, ctx = _ctx(monkeypatch, {}, N, B, T, H, gemm_bf16x3=x3)
+        params, tr, idx, _, _ = _problem(torch, m, cfg, ctx, N, B, T, H)
+        P = ctx.param_count()
+        grad, metrics = torch.zeros(P, device="cuda:0"), torch.zeros(10, device="cuda:0")
+        ctx.ppo_grad(params, tr.c, idx.cuda(), B, tr.adv, tr.target, grad, metrics)
+        ctx.synchronize()
+        grads[x3] = grad.clone()
+        if x3:
+            ctx.profile_begin()
+            ctx.ppo_grad(params, tr.c, idx.cuda(), B, tr.adv, tr.target, grad, metrics)
+            prof = ctx.profile_end()
+            names = {k["name"]: k["launches"] for k in prof["kernels"]}
+            assert names.get("kbj::gemm_x3_kernel<false, false>", 0) >= 4 and names.get("kbj::gemm_x3_kernel<true, false>", 0) >= 2, names   # the split kernel really ran
+        ctx.close()
+    assert torch.isfinite(grads[1]).all()
+    assert float((grads[1] - grads[0]).norm() / grads[0].norm()) < 1e-5
+    from oracle import nn as ON
+    off = 0
+    for name, shp in ON.param_shapes(H):
+        n = int(np.prod(shp))
+        a, b = grads[1][off:off + n], grads[0][off:off + n]
+        assert float((a - b).abs().max() / (b.abs().max() + 1e-12)) < 1e-4, name
+        off += n
 
 
 @pytest.mark.parametrize("H,N,B,T", [(64, 24, 8, 7), (256, 128, 64, 9), (100, 40, 20, 5)])      # 100: a zero-padded hidden size

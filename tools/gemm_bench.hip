@@ -57,11 +57,11 @@ double run(const char* name, int M, int N, int K, int splitk, int force_big, flo
 // for the split itself. Operands are split ONCE per element, on the way into LDS (and + sub + pack: ~5.5 vector instructions per
 // element against 128 multiply-adds it takes part in). 128 x 128 x 32 tiles on 4 wavefronts (2 x 2, each 64 x 64 = 2 x 2 MFMA tiles);
 // LDS: [piece][row][40] bf16 per operand (16-byte fragments), one stage + register prefetch, two workgroups per CU.
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-constexpr int X3_LD = 40;                       // bf16 per LDS row (32 k + 8 pad: 80-byte rows keep ds_read_b128 of 32 rows conflict-free)
-constexpr int X3_PIECE = 128 * X3_LD;           // bf16 per piece of one operand tile
-__device__ __forceinline__ void split3(const f32x4& x, u32x2& hi, u32x2& mid, u32x2& lo) {   // four consecutive k of one row -> 3 x (4 bf16)
+typedef short pbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
+constexpr int P3_LD = 40;                       // bf16 per LDS row (32 k + 8 pad: 80-byte rows keep ds_read_b128 of 32 rows conflict-free)
+constexpr int P3_PIECE = 128 * P3_LD;           // bf16 per piece of one operand tile
+__device__ __forceinline__ void split3(const f32x4& x, pu32x2& hi, pu32x2& mid, pu32x2& lo) {   // four consecutive k of one row -> 3 x (4 bf16)
   unsigned h[4], m[4], l[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
@@ -77,7 +77,7 @@ __device__ __forceinline__ void split3(const f32x4& x, u32x2& hi, u32x2& mid, u3
   lo = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
 }
 // one operand tile 128 rows x 32 k: every thread stages 16 elements as four (row, 4 consecutive k) groups
-template <bool KC> struct X3Stage {
+template <bool KC> struct P3Stage {
   f32x4 v[4];
   // k-contiguous [rows][ld]: thread = (row rr + 32 i, k 4 kq); row-contiguous [k][ld]: thread = (rows 4 rq .. 4 rq + 3, k 4 kg .. 4 kg + 3), transposed in registers
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int r0, int k0) {
@@ -93,23 +93,23 @@ template <bool KC> struct X3Stage {
       for (int i = 0; i < 4; ++i) v[i] = {w[0][i], w[1][i], w[2][i], w[3][i]};      // row 4 rq + i, k 4 kg .. + 3
     }
   }
-  __device__ __forceinline__ void store(short* lds) const {    // lds: [3][128][X3_LD]
+  __device__ __forceinline__ void store(short* lds) const {    // lds: [3][128][P3_LD]
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = KC ? (t >> 3) + 32 * i : 4 * (t & 31) + i, k = KC ? 4 * (t & 7) : 4 * (t >> 5);
-      u32x2 hi, mid, lo;
+      pu32x2 hi, mid, lo;
       split3(v[i], hi, mid, lo);
-      short* p = lds + row * X3_LD + k;
-      *reinterpret_cast<u32x2*>(p) = hi; *reinterpret_cast<u32x2*>(p + X3_PIECE) = mid; *reinterpret_cast<u32x2*>(p + 2 * X3_PIECE) = lo;
+      short* p = lds + row * P3_LD + k;
+      *reinterpret_cast<pu32x2*>(p) = hi; *reinterpret_cast<pu32x2*>(p + P3_PIECE) = mid; *reinterpret_cast<pu32x2*>(p + 2 * P3_PIECE) = lo;
     }
   }
 };
 template <int NPROD, bool A_KC, bool B_KC>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
                                                              int lda, int ldb, int ldc, int splitk) {
-  extern __shared__ __attribute__((aligned(16))) short x3lds[];   // A: 3 pieces, then B: 3 pieces
-  short* As = x3lds; short* Bs = x3lds + 3 * X3_PIECE;
+  extern __shared__ __attribute__((aligned(16))) short p3lds[];   // A: 3 pieces, then B: 3 pieces
+  short* As = p3lds; short* Bs = p3lds + 3 * P3_PIECE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1, lr = lane & 31, lh = lane >> 5;
   const int tiles_n = N / 128, tiles_m = M / 128;
   const int per = splitk > 1 ? ((K + splitk - 1) / splitk + 31) / 32 * 32 : K;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float* __rest
   const int tn = item % tiles_n, tm = (item / tiles_n) % tiles_m, ks = item / (tiles_n * tiles_m);
   const int m0 = tm * 128, n0 = tn * 128, kbeg = ks * per, kend = min(K, kbeg + per);
   if (kbeg >= kend) return;
-  X3Stage<A_KC> sa; X3Stage<B_KC> sb;
+  P3Stage<A_KC> sa; P3Stage<B_KC> sb;
   sa.load(A, lda, m0, kbeg); sb.load(B, ldb, n0, kbeg);
   f32x16 acc[2][2];
 #pragma unroll
@@ -134,13 +134,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float* __rest
     if (k0 + 32 < kend) { sa.load(A, lda, m0, k0 + 32); sb.load(B, ldb, n0, k0 + 32); }     // in flight behind the MFMAs
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 a[3][2], b[3][2];
+      pbf16x8 a[3][2], b[3][2];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          a[p][i] = *reinterpret_cast<const bf16x8*>(As + p * X3_PIECE + (wr * 64 + 32 * i + lr) * X3_LD + 16 * kk + 8 * lh);
-          b[p][i] = *reinterpret_cast<const bf16x8*>(Bs + p * X3_PIECE + (wc * 64 + 32 * i + lr) * X3_LD + 16 * kk + 8 * lh);
+          a[p][i] = *reinterpret_cast<const pbf16x8*>(As + p * P3_PIECE + (wr * 64 + 32 * i + lr) * P3_LD + 16 * kk + 8 * lh);
+          b[p][i] = *reinterpret_cast<const pbf16x8*>(Bs + p * P3_PIECE + (wc * 64 + 32 * i + lr) * P3_LD + 16 * kk + 8 * lh);
         }
       // smallest products first; pa / pb = piece of A / B (0 hi, 1 mid, 2 lo)
       constexpr int PA[9] = {2, 1, 2, 1, 2, 0, 1, 0, 0}, PB[9] = {2, 2, 1, 1, 0, 2, 0, 1, 0};   // lo*lo, mid*lo, lo*mid | mid*mid, lo*hi, hi*lo, mid*hi, hi*mid, hi*hi
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(const float* __rest
     }
 }
 template <int NPROD, bool A_KC, bool B_KC> void launch_x3(const float* A, const float* B, float* C, int M, int N, int K, int splitk) {
-  constexpr size_t bytes = 6 * X3_PIECE * sizeof(short);
+  constexpr size_t bytes = 6 * P3_PIECE * sizeof(short);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16x3_kernel<NPROD, A_KC, B_KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   (void)attr;
   int wgs = (M / 128) * (N / 128) * (splitk > 1 ? splitk : 1);
@@ -212,14 +212,15 @@ template <bool A_KC, bool B_KC> void compare_x3(const char* name, int M, int N, 
   };
   GemmArgs g{A, B, C, nullptr, M, N, K, A_KC ? K : M, B_KC ? K : N, N, splitk > 1 ? 1 : 0, splitk, nullptr};
   auto ex = timeit([&] { gemm_launch<A_KC, B_KC>(0, g, 1); });
-  auto x6 = timeit([&] { launch_x3<6, A_KC, B_KC>(A, B, C, M, N, K, splitk); });
+  GemmArgs gx = g; gx.x3 = 1;     // the product kernel (kbj_gemm.h gemm_x3_kernel, kbj_config.gemm_bf16x3)
+  auto x6 = timeit([&] { gemm_launch<A_KC, B_KC>(0, gx, 1); });
   auto x9 = timeit([&] { launch_x3<9, A_KC, B_KC>(A, B, C, M, N, K, splitk); });
   auto row = [&](const char* what, std::pair<double, ErrStat>& r) {
     printf("  %-34s %8.1f us %6.1f TF   err/(1+|c|): max %.2e p99.9 %.2e   err/sum|ab|: max %.2e p99.9 %.2e median %.2e\n", what, r.first,
            2.0 * M * N * K / (r.first * 1e-6) / 1e12, r.second.max1, r.second.p999_1, r.second.maxs, r.second.p999_s, r.second.med_s);
   };
   printf("%s  M=%d N=%d K=%d split-K %d  (%d sampled outputs against fp64)\n", name, M, N, K, splitk, samples);
-  row("exact fp32 MFMA (kbj_gemm.h)", ex); row("bf16 x3 split, 6 products", x6); row("bf16 x3 split, 9 products", x9);
+  row("exact fp32 MFMA (kbj_gemm.h)", ex); row("bf16 x3, 6 products (product kernel)", x6); row("bf16 x3 split, 9 products", x9);
 }
 
 int main(int argc, char** argv) {
