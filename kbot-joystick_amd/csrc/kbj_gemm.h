@@ -342,15 +342,17 @@ __device__ __forceinline__ void x3_split(const f32x4& x, u32x2& hi, u32x2& mid, 
   mid = {__builtin_amdgcn_perm(m[1], m[0], 0x07060302u), __builtin_amdgcn_perm(m[3], m[2], 0x07060302u)};
   lo = {__builtin_amdgcn_perm(l[1], l[0], 0x07060302u), __builtin_amdgcn_perm(l[3], l[2], 0x07060302u)};
 }
-// one operand tile 128 rows x 32 k staged as four (row, 4 consecutive k) groups per thread
-template <bool KC> struct X3Stage {
-  f32x4 v[4];
+// one operand tile ROWS rows x 32 k staged as ROWS / 32 (row, 4 consecutive k) groups per thread (256 threads)
+template <bool KC, int ROWS> struct X3Stage {
+  static constexpr int NG = ROWS / 32;
+  static_assert(KC || ROWS == 128, "row-contiguous operands are transposed in 4 x 4 blocks: 128-row tiles only");
+  f32x4 v[NG];
   // P: operand base, ld; R: valid rows; r0: first row of the tile; k0: first k (a full 32-k tile, k-range checked by the caller)
   __device__ __forceinline__ void load(const float* __restrict__ P, int ld, int R, int r0, int k0) {
     const int t = threadIdx.x;
     if (KC) { const int kq = t & 7, rr = t >> 3;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NG; ++i) {
         const int r = r0 + rr + 32 * i;
         v[i] = r < R ? *reinterpret_cast<const f32x4*>(P + (size_t)r * ld + k0 + 4 * kq) : f32x4{0, 0, 0, 0};
       }
@@ -366,88 +368,136 @@ template <bool KC> struct X3Stage {
       for (int i = 0; i < 4; ++i) v[i] = {w[0][i], w[1][i], w[2][i], w[3][i]};      // row 4 rq + i, k 4 kg .. + 3
     }
   }
-  __device__ __forceinline__ void store(short* lds) const {    // lds: [3][128][X3_LD]
+  // general form of a k-contiguous tile (GEN kernels): per-group element offsets of the rows (row gathers resolved by the caller, -1 = no
+  // such row), a k range that may end inside the tile (whole float4s: the callers' K are multiples of 4)
+  __device__ __forceinline__ void load_gen(const float* __restrict__ P, const long (&roff)[NG], int k0, int kend) {
+    const int k = k0 + 4 * (threadIdx.x & 7);
+#pragma unroll
+    for (int i = 0; i < NG; ++i) v[i] = (roff[i] >= 0 && k + 3 < kend) ? *reinterpret_cast<const f32x4*>(P + roff[i] + k) : f32x4{0, 0, 0, 0};
+  }
+  __device__ __forceinline__ void store(short* lds) const {    // lds: [3][ROWS][X3_LD]
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NG; ++i) {
       const int row = KC ? (t >> 3) + 32 * i : 4 * (t >> 3) + i, k = 4 * (t & 7);
       u32x2 hi, mid, lo;
       x3_split(v[i], hi, mid, lo);
       short* p = lds + row * X3_LD + k;
-      *reinterpret_cast<u32x2*>(p) = hi; *reinterpret_cast<u32x2*>(p + X3_PIECE) = mid; *reinterpret_cast<u32x2*>(p + 2 * X3_PIECE) = lo;
+      *reinterpret_cast<u32x2*>(p) = hi; *reinterpret_cast<u32x2*>(p + ROWS * X3_LD) = mid; *reinterpret_cast<u32x2*>(p + 2 * ROWS * X3_LD) = lo;
     }
   }
 };
-template <bool A_KC, bool B_KC>
+// TM: MFMA tiles per wavefront and dimension: 2 = 128 x 128 workgroup tiles (4 wavefronts of 64 x 64), 1 = 64 x 64 (4 wavefronts of 32 x 32:
+// 30 KB of LDS, ~70 VGPRs - it fits beside the env kernel's partial last round like the exact small-tile kernel, DESIGN.md "Rollout schedule").
+// GEN (k-contiguous operands only): bias, a second k source (k1 a multiple of 32), row gathers of A, K that is only a multiple of 4.
+template <int TM, bool A_KC, bool B_KC, bool GEN>
 __global__ __launch_bounds__(256, 2) void gemm_x3_kernel(GemmArgs g) {
+  constexpr int BM = 64 * TM, PIECE = BM * X3_LD;
+  static_assert(!GEN || (A_KC && B_KC), "the general loads are written for k-contiguous operands");
   extern __shared__ __attribute__((aligned(16))) short x3lds[];   // A: 3 pieces, then B: 3 pieces
-  short* As = x3lds; short* Bs = x3lds + 3 * X3_PIECE;
+  short* As = x3lds; short* Bs = x3lds + 3 * PIECE;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1, lr = lane & 31, lh = lane >> 5;
-  const int tiles_n = (g.N + 127) / 128, tiles_m = (g.M + 127) / 128;
+  const int tiles_n = (g.N + BM - 1) / BM, tiles_m = (g.M + BM - 1) / BM;
   const int sk = g.splitk > 1 ? g.splitk : 1;
   const int per = sk > 1 ? ((g.K + sk - 1) / sk + GEMM_BK - 1) / GEMM_BK * GEMM_BK : g.K;
   const int item = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   if (item >= tiles_n * tiles_m * sk) return;
-  const GemmItem cur = gemm_item<128, 128>(g, item, tiles_n, tiles_m, per);
+  const GemmItem cur = gemm_item<BM, BM>(g, item, tiles_n, tiles_m, per);
   if (cur.kbeg >= cur.kend) return;
-  X3Stage<A_KC> sa; X3Stage<B_KC> sb;
-  sa.load(g.A, g.lda, g.M, cur.m0, cur.kbeg); sb.load(cur.B, cur.ldb, cur.ncols, cur.n0, cur.kbeg);
-  f32x16 acc[2][2];
+  X3Stage<A_KC, BM> sa; X3Stage<B_KC, BM> sb;
+  long roa[X3Stage<A_KC, BM>::NG], rob[X3Stage<B_KC, BM>::NG];
+  if (GEN) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < sa.NG; ++i) {
+      const int m = cur.m0 + (threadIdx.x >> 3) + 32 * i, n = cur.n0 + (threadIdx.x >> 3) + 32 * i;
+      long row = m;
+      if (g.a_idx && m < g.M) { const int tt = m / g.a_B; row = (long)tt * g.a_N + g.a_idx[m - tt * g.a_B]; }    // minibatch view of a trajectory array (GemmArgs::a_idx)
+      roa[i] = m < g.M ? row * g.lda : -1;
+      rob[i] = n < cur.ncols ? (long)n * cur.ldb : -1;
+    }
+  }
+  auto load_tile = [&](int k) {
+    if (GEN) {
+      const float *pa = g.A, *pb = cur.B;
+      int kk = k, ke = cur.kend;
+      if (g.k1 > 0) { if (k >= g.k1) { pa = g.A2; pb = g.B2; kk = k - g.k1; ke = g.K - g.k1; } else ke = g.k1; }
+      sa.load_gen(pa, roa, kk, ke); sb.load_gen(pb, rob, kk, ke);
+    } else { sa.load(g.A, g.lda, g.M, cur.m0, k); sb.load(cur.B, cur.ldb, cur.ncols, cur.n0, k); }
+  };
+  load_tile(cur.kbeg);
+  f32x16 acc[TM][TM];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
   for (int k0 = cur.kbeg; k0 < cur.kend; k0 += 32) {
     __syncthreads();                       // every wavefront has read the previous tile
     sa.store(As); sb.store(Bs);
     __syncthreads();
-    if (k0 + 32 < cur.kend) { sa.load(g.A, g.lda, g.M, cur.m0, k0 + 32); sb.load(cur.B, cur.ldb, cur.ncols, cur.n0, k0 + 32); }     // in flight behind the MFMAs
+    if (k0 + 32 < cur.kend) load_tile(k0 + 32);     // in flight behind the MFMAs
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
-      bf16x8 a[3][2], b[3][2];
+      bf16x8 a[3][TM], b[3][TM];
 #pragma unroll
       for (int p = 0; p < 3; ++p)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          a[p][i] = *reinterpret_cast<const bf16x8*>(As + p * X3_PIECE + (wr * 64 + 32 * i + lr) * X3_LD + 16 * kk + 8 * lh);
-          b[p][i] = *reinterpret_cast<const bf16x8*>(Bs + p * X3_PIECE + (wc * 64 + 32 * i + lr) * X3_LD + 16 * kk + 8 * lh);
+        for (int i = 0; i < TM; ++i) {
+          a[p][i] = *reinterpret_cast<const bf16x8*>(As + p * PIECE + (wr * 32 * TM + 32 * i + lr) * X3_LD + 16 * kk + 8 * lh);
+          b[p][i] = *reinterpret_cast<const bf16x8*>(Bs + p * PIECE + (wc * 32 * TM + 32 * i + lr) * X3_LD + 16 * kk + 8 * lh);
         }
       constexpr int PA[6] = {1, 2, 0, 1, 0, 0}, PB[6] = {1, 0, 2, 0, 1, 0};   // mid mid, lo hi, hi lo, mid hi, hi mid, hi hi (0 hi, 1 mid, 2 lo)
 #pragma unroll
       for (int q = 0; q < 6; ++q)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA[q]][i], b[PB[q]][j], acc[i][j], 0, 0, 0);
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = cur.n0 + wc * 64 + 32 * j + lr;
+    for (int j = 0; j < TM; ++j) {
+      const int n = cur.n0 + wc * 32 * TM + 32 * j + lr;
       if (n >= cur.ncols) continue;
+      const float bv = (GEN && g.bias && cur.ks == 0) ? g.bias[n] : 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = cur.m0 + wr * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int m = cur.m0 + wr * 32 * TM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (m >= g.M) continue;
         float* c = cur.C + (size_t)m * cur.ldc + n;
-        const float v = acc[i][j][r];
+        const float v = acc[i][j][r] + bv;
         if (sk > 1) atomicAdd(c, v);
         else *c = g.beta ? *c + v : v;
       }
     }
 }
-// the launches the split kernel serves (everything else stays on the exact kernel, silently)
-inline bool gemm_x3_eligible(const GemmArgs& g, bool a_kc, bool b_kc) {
-  if (!g.x3 || g.bias || g.A2 || (g.B2 && g.n1 <= 0) || g.k1 > 0 || g.a_idx || g.skws) return false;
-  if (g.K % GEMM_BK != 0 || g.M < 128 || g.N < 128) return false;
+// the launches the split kernel serves (everything else stays on the exact kernel, silently): 0 = none, 1 = the plain form, 2 = the general
+// form (k-contiguous operands: bias / second k source / row gather / K a multiple of 4)
+inline int gemm_x3_form(const GemmArgs& g, bool a_kc, bool b_kc, bool big) {
+  if (!g.x3 || g.skws || (g.B2 && g.n1 <= 0 && g.k1 <= 0)) return 0;
   auto al = [](const void* p, int ld) { return ((size_t)p & 15) == 0 && (ld & 3) == 0; };
-  if (!al(g.A, g.lda) || !al(g.B, g.ldb) || (g.n1 > 0 && (!al(g.B2, g.ldb2 > 0 ? g.ldb2 : g.ldb) || g.n1 % 128 != 0))) return false;
-  (void)a_kc; (void)b_kc;
-  return true;
+  if (!al(g.A, g.lda) || !al(g.B, g.ldb) || g.M < 64 || g.N < 64) return 0;
+  const bool gen = g.bias || g.k1 > 0 || g.a_idx || g.K % GEMM_BK != 0;
+  if (gen) {
+    if (!a_kc || !b_kc || g.n1 > 0 || g.splitk > 1 || g.K % 4 != 0 || g.k1 % GEMM_BK != 0) return 0;
+    if (g.k1 > 0 && (!al(g.A2, g.lda) || !al(g.B2, g.ldb))) return 0;
+    return 2;
+  }
+  if (!big && !(a_kc && b_kc)) return 0;                    // the 64 x 64 form exists for k-contiguous operands
+  if (g.n1 > 0 && (!al(g.B2, g.ldb2 > 0 ? g.ldb2 : g.ldb) || g.n1 % (big ? 128 : 64) != 0)) return 0;
+  return 1;
+}
+template <int TM, bool A_KC, bool B_KC, bool GEN> inline void gemm_x3_launch_tile(hipStream_t s, const GemmArgs& g, int sk) {
+  constexpr int BM = 64 * TM;
+  constexpr size_t bytes = 6 * BM * X3_LD * sizeof(short);
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<TM, A_KC, B_KC, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  (void)attr;
+  const long it = (long)((g.M + BM - 1) / BM) * ((g.N + BM - 1) / BM) * sk;
+  KbjKernelTimer timer(s, KBJ_KIND_GEMM_X3 + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);
+  hipLaunchKernelGGL((gemm_x3_kernel<TM, A_KC, B_KC, GEN>), dim3((unsigned)((it + 7) / 8 * 8)), dim3(256), bytes, s, g);
 }
 
 // second stage of the deterministic split-K: C (+)= sum over the k slices, in slice order, of the partial tiles (one thread per output
@@ -485,13 +535,11 @@ inline void gemm_launch(hipStream_t s, const GemmArgs& g_in, int force_big = -1)
   // one work item per workgroup (walking several items per workgroup was slower at every setting for this path's shapes)
   int wgs = (int)items;
   wgs = (wgs + 7) / 8 * 8;
-  if (gemm_x3_eligible(g, A_KC, B_KC)) {
-    const long it = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * sk;
-    constexpr size_t bytes = 6 * X3_PIECE * sizeof(short);
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<A_KC, B_KC>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    (void)attr;
-    KbjKernelTimer timer(s, KBJ_KIND_GEMM_X3 + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);
-    hipLaunchKernelGGL((gemm_x3_kernel<A_KC, B_KC>), dim3((unsigned)((it + 7) / 8 * 8)), dim3(256), bytes, s, g);
+  if (const int form = gemm_x3_form(g, A_KC, B_KC, big)) {
+    if constexpr (A_KC && B_KC) {
+      if (form == 2) { if (big) gemm_x3_launch_tile<2, true, true, true>(s, g, sk); else gemm_x3_launch_tile<1, true, true, true>(s, g, sk); }
+      else { if (big) gemm_x3_launch_tile<2, true, true, false>(s, g, sk); else gemm_x3_launch_tile<1, true, true, false>(s, g, sk); }
+    } else gemm_x3_launch_tile<2, A_KC, B_KC, false>(s, g, sk);
     return;
   }
   KbjKernelTimer timer(s, KBJ_KIND_GEMM + (big ? 0 : 4) + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);

@@ -40,8 +40,9 @@ struct Sched {
   bool deterministic = false;      // fixed-order reductions instead of fp32 / fp64 atomics (bit-reproducible update)
   int bwd_chunks = 1;              // KBJ_BWD_CHUNKS=n (2..10): weight-gradient GEMMs per time chunk UNDER the backward recurrence (chunk-gated schedule);
                                    // measured flat against 1 = behind the whole recurrence (6.37-6.45 vs 6.43 ms per minibatch)
-  bool gemm_x3 = false;            // kbj_config.gemm_bf16x3 / KBJ_GEMM_X3=1: the backward pass's large GEMMs (input gradients, weight-gradient pairs) on the bf16
-                                   // matrix cores through the exact three-way operand split (kbj_gemm.h gemm_x3_kernel); not the default, not the headline
+  bool gemm_x3 = false;            // kbj_config.gemm_bf16x3 / KBJ_GEMM_X3=1: the GEMM launches that are eligible (the update's input gradients, weight-gradient
+                                   // pairs and critic input projection, the rollout's [x | h] gate GEMMs) on the bf16 matrix cores through the exact three-way
+                                   // operand split (kbj_gemm.h gemm_x3_kernel); not the default, not the headline
   bool chunk_dx = false;           // KBJ_BWD_CHUNK_DX=1 (with bwd_chunks > 1): the input-gradient GEMM per chunk as well (slower: 6.64 / 6.83 ms at 2 / 4 chunks)
 };
 constexpr int MAX_BWD_CHUNKS = 10;
@@ -631,6 +632,7 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
       {  // gates = [x | h] [W_ih | W_hh]^T + b as ONE launch over the concatenated contraction (no read-modify-write of G)
         GemmArgs g{x, params_d + o.w_ih[l], G, params_d + o.b[l], cnt, 4 * H, 2 * H, H, H, 4 * H, 0, 1, nullptr};
         g.A2 = h; g.B2 = params_d + o.w_hh[l]; g.k1 = H;
+        g.x3 = w.sched.gemm_x3 ? 1 : 0;
         gemm_launch<true, true>(s, g, (n > 0 && w.sched.rollout_step) ? 0 : -1);   // side-lane nets: 64x64 tiles (see net_uses_step_kernel)
       }
       CellFwdArgs2 ca;
@@ -1039,6 +1041,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     if (n == 1 && gather_late) {
       GemmArgs g{tr->critic_obs_d, w.WinP[1], w.tb[1].X0, params_d + o.b_in, R, H, o.ld_obs, o.ld_obs, o.ld_obs, H, 0, 1, nullptr};
       g.a_idx = idx; g.a_B = B; g.a_N = N;
+      g.x3 = sc.gemm_x3 ? 1 : 0;
       gemm_launch<true, true>(ns[1], g);
       // the copy behind the projection, under the recurrences (beside it the two would share HBM: 175 instead of 144 us for the GEMM)
       KBJ_HIP(ctx, hipEventRecord(ctx->ev_obs, ns[1]));

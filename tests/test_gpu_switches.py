@@ -110,7 +110,7 @@ def test_switch_gradient_matches_autograd(monkeypatch, name, H, N, B, T):
     ctx.close()
 
 
-@pytest.mark.parametrize("name", ["KBJ_ROLLOUT_STEP=0", "KBJ_FOLD_ACTOR=0"])
+@pytest.mark.parametrize("name", ["KBJ_ROLLOUT_STEP=0", "KBJ_FOLD_ACTOR=0", "KBJ_GEMM_X3=1"])
 def test_switch_policy_step_matches_default(monkeypatch, name):
     """Rollout-side switches: one policy step (all carries, action mode, value) against the default formulation."""
     import torch
