@@ -34,14 +34,14 @@ typedef struct kbj_ctx kbj_ctx;
 /* ---- lifetime ---------------------------------------------------------------------------- */
 /* replaces: HumanoidWalkingTask.launch(config) set-up — get_mujoco_model / metadata / mjx.put_model
  * (train.py:1079-1089, 1760-1792). model_blob is a kbj_model produced by the spec compiler.
- * Model fields served (train.py:78-85): cfg->hidden_size in 1..256 (multiples of 64 run natively; any other size runs zero padded to the
+ * Model fields served (train.py:78-85): cfg->hidden_size in 1..512 (multiples of 64 run natively, above 256 on an untuned schedule; any other size runs zero padded to the
  * next one INSIDE the library - parameters, gradients, carries and trajectory start carries keep the caller's hidden_size layout and are
  * converted at every entry point, exact for this network), cfg->depth in 1..KBJ_MAX_DEPTH; anything else fails here. */
 int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const kbj_config* cfg, int device, void* hip_stream);
 int kbj_destroy(kbj_ctx* ctx);
 const char* kbj_last_error(const kbj_ctx* ctx); /* ctx may be NULL: error of a failed kbj_create */
 /* Host-only check of the sizes a configuration asks for (no device needed; kbj_create applies it first): 0 = served, -1 = refused with the
- * reason in `why`. Besides the range checks (hidden_size 1..256, depth 1..4, Newton solver) it refuses configurations whose largest
+ * reason in `why`. Besides the range checks (hidden_size 1..512, depth 1..4, Newton solver) it refuses configurations whose largest
  * operand - the minibatch stash [rollout_len x batch_size][4 hidden_size | 476] or one control step's [num_envs][...] rows - reaches
  * 2 GiB: those arrays are fetched with 32-bit byte offsets. (The reference has no such limit: XLA addresses with 64 bits.) */
 int kbj_check_config(const kbj_config* cfg, char* why, size_t why_bytes);

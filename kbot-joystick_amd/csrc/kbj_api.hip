@@ -57,8 +57,8 @@ int kbj_check_config(const kbj_config* cfg, char* why, size_t why_bytes) {
   if (!cfg) return fail("null config");
   if (cfg->num_envs <= 0 || cfg->substeps <= 0 || cfg->rollout_len <= 0) return fail("bad config sizes");
   if (cfg->solver_newton != 1) return fail("only the Newton solver is implemented on the GPU (solver_newton = 1)");
-  if (cfg->hidden_size < 1 || cfg->hidden_size > 256 || cfg->depth < 1 || cfg->depth > KBJ_MAX_DEPTH)
-    return fail("hidden_size must be in 1..256 (multiples of 64 run unpadded) and depth in 1..4 (train.py:78-85 defaults 128 / 2, launch 256 / 2)");
+  if (cfg->hidden_size < 1 || cfg->hidden_size > 512 || cfg->depth < 1 || cfg->depth > KBJ_MAX_DEPTH)
+    return fail("hidden_size must be in 1..512 (multiples of 64 run unpadded; above 256 on the wide, untuned schedule) and depth in 1..4 (train.py:78-85 defaults 128 / 2, launch 256 / 2)");
   if (cfg->extra_obs_actor < 0 || cfg->extra_obs_actor > KBJ_MAX_EXTRA_OBS || cfg->extra_obs_critic < 0 || cfg->extra_obs_critic > KBJ_MAX_EXTRA_OBS)
     return fail("extra_obs_actor / extra_obs_critic must be in 0.." + std::to_string(KBJ_MAX_EXTRA_OBS));
   const unsigned long long lim = 1ull << 31;
@@ -217,7 +217,7 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
     kbj_kernel_stat& st = ctx->kstats[k];
     const int uw = 2;   // wavefront pairs per recurrence workgroup (kbj_nn.hip SEQ_UW), as rocprofv3 prints the template argument
     const int hk = (ctx->cfg_h.hidden_size + 63) / 64 * 64;   // the kernels' hidden size (kbj_nn.hip NnWs::H)
-    if (k == KBJ_KIND_SEQ_BWD) snprintf(st.name, sizeof(st.name), "%s<%d, %d>", names[k], hk, uw);
+    if (k == KBJ_KIND_SEQ_BWD) snprintf(st.name, sizeof(st.name), "%s<%d, %d>", hk > 256 ? "kbj::lstm_seq_bwd_wide_kernel" : names[k], hk, uw);   // kbj_nn.hip SEQ_FUSED_MAX_H
     else if (k == KBJ_KIND_SEQ_FWD || k == KBJ_KIND_SEQ_FWD_FUSED || k == KBJ_KIND_SEQ_FWD_OBS)   // as rocprofv3 prints the template arguments
       snprintf(st.name, sizeof(st.name), "%s<%d, %d, %s, %d>", names[k], hk, uw, k == KBJ_KIND_SEQ_FWD ? "false" : "true",
                k == KBJ_KIND_SEQ_FWD_OBS ? KBJ_LD_ACTOR : hk);

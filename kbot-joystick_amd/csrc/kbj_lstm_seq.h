@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
 }
 
 template <int H, int UW>
-__global__ __launch_bounds__(256 * UW) __attribute__((amdgpu_num_vgpr(KBJ_SEQ_BWD_NUM_VGPR))) void lstm_seq_bwd_kernel(SeqBwdArgs a) {
+__device__ __forceinline__ void lstm_seq_bwd_body(const SeqBwdArgs a) {
   constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW;
   typedef SeqK<H> KH;
   constexpr int LDH = KH::LD;
@@ -523,6 +523,12 @@ __global__ __launch_bounds__(256 * UW) __attribute__((amdgpu_num_vgpr(KBJ_SEQ_BW
   }
   if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 2] = wall_clock64();
 }
+// hidden sizes up to 256: the capped register budget above. Wider layers (the weight slice alone is H / 4 registers per gate chunk pair)
+// run one recurrence at a time and without GEMM workgroups beside them (kbj_nn.hip: one_stream), so their kernel takes what it needs.
+template <int H, int UW>
+__global__ __launch_bounds__(256 * UW) __attribute__((amdgpu_num_vgpr(KBJ_SEQ_BWD_NUM_VGPR))) void lstm_seq_bwd_kernel(SeqBwdArgs a) { lstm_seq_bwd_body<H, UW>(a); }
+template <int H, int UW>
+__global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_wide_kernel(SeqBwdArgs a) { lstm_seq_bwd_body<H, UW>(a); }
 
 // Gate in front of a consumer of a time chunk (one wavefront, one lane polling): returns once *ctr >= target, i.e. once every workgroup
 // of the recurrence has handed off the chunk's last step. It only ever waits for a kernel that was enqueued BEFORE it (deadlock-free

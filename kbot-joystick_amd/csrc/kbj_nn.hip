@@ -185,7 +185,7 @@ template <class T> int dalloc(kbj_ctx* ctx, NnWs& w, T** p, size_t count) {
 thread_local int g_gemm_x3 = 0;     // set by kbj_ppo_grad from the context's schedule for the duration of the call (the wrappers below have no context)
 constexpr int g_fold_sk = 8;        // k slices of the small W_ih0^T Z product of the folded input projections
 constexpr int g_splitk_wgs = 768;   // target number of workgroups of a split-K weight-gradient GEMM (512 ... 1536 measured flat)
-constexpr int DETP_ROWS = 512, DETP_COLS = 1024;
+constexpr int DETP_ROWS = 512, DETP_COLS = 4 * 512;   // (columns: one gate row of the widest layer, 4 SEQ_MAX_H)
 
 // lane index of a stream of this context (deterministic-mode workspaces are per lane: launches on different lanes overlap)
 int lane_of(kbj_ctx* ctx, hipStream_t s) { return s == ctx->stream ? 0 : (s == ctx->stream2 ? 1 : (s == ctx->side[0] ? 2 : 3)); }
@@ -248,6 +248,12 @@ void colsum_acc(kbj_ctx* ctx, hipStream_t s, const float* X, int M, int N, int l
 // recurrence workgroups are 8 wavefronts owning 32 hidden units (kbj_lstm_seq.h; the 4-wavefront / 16-unit form of round 1 is gone:
 // slower in situ at every size)
 constexpr int SEQ_UW = 2;
+// Hidden sizes above this run "wide": the forward recurrence keeps only its W_hh slice in registers (two slices of H / 4 registers each do
+// not fit beyond 256), so the input products are GEMM launches in front of it; the backward recurrence takes the registers it needs
+// (lstm_seq_bwd_wide_kernel); the rollout's layers are [x | h] gate GEMM + cell kernel; and the update runs on one stream when two
+// recurrence launches would not be resident together. Served, not tuned: the launch configuration is 256.
+constexpr int SEQ_FUSED_MAX_H = 256;
+constexpr int SEQ_MAX_H = 512;
 constexpr int SEQ_COUNTER_WORDS = 256;   // hand-off words per recurrence launch (one per workgroup): the grid of a launch may not exceed it
 // fault injection for the tests (KBJ_DEBUG_DROP_SEQ_WG = n at kbj_create): the next n forward-recurrence launches run with one
 // workgroup missing, so its partners' bounded spins expire and the timeout / fail-stop path is exercised on real hardware
@@ -258,15 +264,18 @@ template <int H, int UW> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a0
   a.spin_limit = g_seq_spin_limit;
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
   if (g_seq_drop > 0 && grid > 1) { --g_seq_drop; --grid; }
-  if (a.X && a.ldx == KBJ_LD_ACTOR) hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, true, KBJ_LD_ACTOR>), dim3(grid), dim3(256 * UW), 0, s, a);   // gates from the observation rows
-  else if (a.X) hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, true>), dim3(grid), dim3(256 * UW), 0, s, a);   // input projection fused
-  else hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, false>), dim3(grid), dim3(256 * UW), 0, s, a);
+  if constexpr (H <= SEQ_FUSED_MAX_H) {
+    if (a.X && a.ldx == KBJ_LD_ACTOR) { hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, true, KBJ_LD_ACTOR>), dim3(grid), dim3(256 * UW), 0, s, a); return; }   // gates from the observation rows
+    if (a.X) { hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, true>), dim3(grid), dim3(256 * UW), 0, s, a); return; }   // input projection fused
+  }
+  hipLaunchKernelGGL((lstm_seq_fwd_kernel<H, UW, false>), dim3(grid), dim3(256 * UW), 0, s, a);   // (wide layers: the schedule never passes X, kbj_nn_create)
 }
 template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0) {
   SeqBwdArgs a = a0;
   a.spin_limit = g_seq_spin_limit;
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
-  hipLaunchKernelGGL((lstm_seq_bwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
+  if constexpr (H <= SEQ_FUSED_MAX_H) hipLaunchKernelGGL((lstm_seq_bwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
+  else hipLaunchKernelGGL((lstm_seq_bwd_wide_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
 int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {   // a.counters: zeroed by the caller
   KbjKernelTimer timer(st, a.X ? (a.ldx == KBJ_LD_ACTOR ? KBJ_KIND_SEQ_FWD_OBS : KBJ_KIND_SEQ_FWD_FUSED) : KBJ_KIND_SEQ_FWD, 2.0 * a.T * a.B * 4.0 * H * (H + (a.X ? (a.kx ? a.kx : H) : 0)));
@@ -275,7 +284,11 @@ int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {   // a.c
     case 128: seq_fwd_launch<128, SEQ_UW>(st, a); break;
     case 192: seq_fwd_launch<192, SEQ_UW>(st, a); break;
     case 256: seq_fwd_launch<256, SEQ_UW>(st, a); break;
-    default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 192, 256");
+    case 320: seq_fwd_launch<320, SEQ_UW>(st, a); break;
+    case 384: seq_fwd_launch<384, SEQ_UW>(st, a); break;
+    case 448: seq_fwd_launch<448, SEQ_UW>(st, a); break;
+    case 512: seq_fwd_launch<512, SEQ_UW>(st, a); break;
+    default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden sizes 64, 128, ..., 512");
   }
   return 0;
 }
@@ -286,7 +299,11 @@ int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {   // a.c
     case 128: seq_bwd_launch<128, SEQ_UW>(st, a); break;
     case 192: seq_bwd_launch<192, SEQ_UW>(st, a); break;
     case 256: seq_bwd_launch<256, SEQ_UW>(st, a); break;
-    default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden_size 64, 128, 192, 256");
+    case 320: seq_bwd_launch<320, SEQ_UW>(st, a); break;
+    case 384: seq_bwd_launch<384, SEQ_UW>(st, a); break;
+    case 448: seq_bwd_launch<448, SEQ_UW>(st, a); break;
+    case 512: seq_bwd_launch<512, SEQ_UW>(st, a); break;
+    default: return kbj_fail(ctx, "persistent LSTM kernels are built for hidden sizes 64, 128, ..., 512");
   }
   return 0;
 }
@@ -297,10 +314,15 @@ int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {   // a.c
 template <int H> hipError_t seq_min_blocks_per_cu(int* out) {
   constexpr int threads = 256 * SEQ_UW;
   int n[4] = {0, 0, 0, 0};
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], lstm_seq_fwd_kernel<H, SEQ_UW, true, H>, threads, 0);
-  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], lstm_seq_fwd_kernel<H, SEQ_UW, true, KBJ_LD_ACTOR>, threads, 0);
-  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[2], lstm_seq_fwd_kernel<H, SEQ_UW, false, H>, threads, 0);
-  if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], lstm_seq_bwd_kernel<H, SEQ_UW>, threads, 0);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[2], lstm_seq_fwd_kernel<H, SEQ_UW, false, H>, threads, 0);
+  if constexpr (H <= SEQ_FUSED_MAX_H) {
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], lstm_seq_fwd_kernel<H, SEQ_UW, true, H>, threads, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], lstm_seq_fwd_kernel<H, SEQ_UW, true, KBJ_LD_ACTOR>, threads, 0);
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], lstm_seq_bwd_kernel<H, SEQ_UW>, threads, 0);
+  } else {
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], lstm_seq_bwd_wide_kernel<H, SEQ_UW>, threads, 0);
+    n[0] = n[1] = n[2];
+  }
   *out = std::min(std::min(n[0], n[1]), std::min(n[2], n[3]));
   return e;
 }
@@ -500,6 +522,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
     sc.bwd_chunks = getenv("KBJ_BWD_CHUNKS") ? atoi(getenv("KBJ_BWD_CHUNKS")) : 1;
     sc.chunk_dx = env_flag("KBJ_BWD_CHUNK_DX", false);
     if (sc.bwd_chunks < 1 || sc.bwd_chunks > MAX_BWD_CHUNKS) return kbj_fail(ctx, "KBJ_BWD_CHUNKS must be in 1..10");
+    if (H > (size_t)SEQ_FUSED_MAX_H) sc.fuse_ih = sc.fuse_obs = sc.rollout_step = false;   // wide layers (SEQ_FUSED_MAX_H above)
     if (sc.one_stream) sc.bwd_chunks = 1;   // no lanes, nothing to run under the recurrence
     if (sc.deterministic) {
       for (int l = 0; l < 4; ++l) if (dalloc(ctx, *w, &w->detp[l], (size_t)DETP_ROWS * DETP_COLS)) return -1;
@@ -526,7 +549,11 @@ int kbj_nn_create(kbj_ctx* ctx) {
       case 128: oe = seq_min_blocks_per_cu<128>(&per_cu); break;
       case 192: oe = seq_min_blocks_per_cu<192>(&per_cu); break;
       case 256: oe = seq_min_blocks_per_cu<256>(&per_cu); break;
-      default: return kbj_fail(ctx, "kbj_create: hidden_size must be 64, 128, 192 or 256 (persistent LSTM kernels)");
+      case 320: oe = seq_min_blocks_per_cu<320>(&per_cu); break;
+      case 384: oe = seq_min_blocks_per_cu<384>(&per_cu); break;
+      case 448: oe = seq_min_blocks_per_cu<448>(&per_cu); break;
+      case 512: oe = seq_min_blocks_per_cu<512>(&per_cu); break;
+      default: return kbj_fail(ctx, "kbj_create: hidden_size above 512 (persistent LSTM kernels)");
     }
     if (oe != hipSuccess || per_cu < 1) return kbj_fail(ctx, "kbj_create: occupancy query of the persistent LSTM kernels failed");
     const long slots = (long)per_cu * cus;
@@ -536,9 +563,10 @@ int kbj_nn_create(kbj_ctx* ctx) {
                "counters hold %d per launch: lower batch_size", grid, SEQ_COUNTER_WORDS);
       return kbj_fail(ctx, msg);
     }
-    if (2L * grid > slots) {
-      snprintf(msg, sizeof(msg), "kbj_create: two concurrent persistent LSTM launches need 2 x %d resident workgroups, the device holds %ld "
-               "(%d per CU x %d CUs): lower batch_size", grid, slots, per_cu, cus);
+    if (H > SEQ_FUSED_MAX_H && 2L * grid > slots) w->sched.one_stream = true, w->sched.bwd_chunks = 1;   // wide layers: one recurrence at a time
+    if ((w->sched.one_stream ? 1L : 2L) * grid > slots) {
+      snprintf(msg, sizeof(msg), "kbj_create: %s persistent LSTM launches need %ld resident workgroups, the device holds %ld "
+               "(%d per CU x %d CUs): lower batch_size", w->sched.one_stream ? "the" : "two concurrent", (w->sched.one_stream ? 1L : 2L) * grid, slots, per_cu, cus);
       return kbj_fail(ctx, msg);
     }
   }
@@ -1172,7 +1200,11 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     const dim3 grid(2048), block(256);
 #define KBJ_CRITIC_HEAD(V) hipLaunchKernelGGL((critic_head_kernel<V>), grid, block, 0, ns[1], tc.Hout[D - 1], params_d + oc.w_out, params_d + oc.b_out, w.val_old, w.target, \
                                               pp, R, w.value, w.dvalue, tc.dOut, tc.dHa, w.stats + 2)
-    switch (H / 64) { case 1: KBJ_CRITIC_HEAD(1); break; case 2: KBJ_CRITIC_HEAD(2); break; case 3: KBJ_CRITIC_HEAD(3); break; default: KBJ_CRITIC_HEAD(4); break; }
+    switch (H / 64) {
+      case 1: KBJ_CRITIC_HEAD(1); break; case 2: KBJ_CRITIC_HEAD(2); break; case 3: KBJ_CRITIC_HEAD(3); break; case 4: KBJ_CRITIC_HEAD(4); break;
+      case 5: KBJ_CRITIC_HEAD(5); break; case 6: KBJ_CRITIC_HEAD(6); break; case 7: KBJ_CRITIC_HEAD(7); break; case 8: KBJ_CRITIC_HEAD(8); break;
+      default: return kbj_fail(ctx, "critic_head_kernel: hidden size above 512");
+    }
 #undef KBJ_CRITIC_HEAD
     if (one_stream) hipLaunchKernelGGL(ppo_loss_kernel, g1(R), dim3(256), 0, s, w.logp, w.value, w.ent, w.logp_old, w.val_old, w.adv, w.target, w.stats, pp, R, w.dlogp, w.dvalue,
                                        w.stats + 2, 1);   // (the actor's launch above was a no-op in this diagnostic mode)

@@ -108,4 +108,5 @@ def test_check_config_refuses_operands_of_two_gib():
     assert ok(num_envs=8192, batch_size=4096, rollout_len=275, hidden_size=64) == ""
     # one control step's rows: N x 1024 x 4 bytes
     assert "num_envs" in ok(num_envs=524288, batch_size=512, rollout_len=10, hidden_size=256)
-    assert "hidden_size" in ok(num_envs=64, batch_size=64, hidden_size=320)
+    assert ok(num_envs=64, batch_size=64, hidden_size=320) == "" and ok(num_envs=64, batch_size=64, hidden_size=512) == ""   # the wide schedule
+    assert "hidden_size" in ok(num_envs=64, batch_size=64, hidden_size=513)

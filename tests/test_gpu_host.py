@@ -65,7 +65,7 @@ def test_checkpoint_resume_is_bit_identical(tmp_path, mirror):
         t.ctx.close()
 
 
-@pytest.mark.parametrize("H,D,mirror", [(192, 3, False), (128, 1, False), (64, 3, True)])
+@pytest.mark.parametrize("H,D,mirror", [(192, 3, False), (128, 1, False), (64, 3, True), (384, 2, False)])
 def test_task_runs_with_other_depths_and_hidden_sizes(tmp_path, H, D, mirror):
     """The reference's model fields hidden_size / depth (train.py:78-85) through the whole task: iterations run, the checkpoint carries
     depth x (h, c) planes and the exported actor advertises carry_size = depth * 2 * hidden + 20 (convert.py:71)."""
@@ -420,7 +420,7 @@ def test_python_command_term():
     ramp.ctx.close(); twin.ctx.close()
 
 
-@pytest.mark.parametrize("H,mirror", [(96, False), (160, True)])
+@pytest.mark.parametrize("H,mirror", [(96, False), (160, True), (300, True)])
 def test_free_hidden_size_end_to_end(tmp_path, H, mirror):
     """hidden_size is an unconstrained field of the reference's config (train.py:78-81). A hidden size between the kernels' 64-unit steps
     runs zero padded behind the ABI; parameters, carries, gradients and checkpoints keep the CALLER's layout. Checks on a whole task:

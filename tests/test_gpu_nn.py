@@ -89,7 +89,8 @@ def _synthetic_traj(torch, buffers, N, T, H, seed=0, mirror=False, depth=2):
     return tr
 
 
-@pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (128, 70, 35, 6), (256, 40, 32, 9), (256, 512, 512, 100)])   # the last one = the BASELINE minibatch
+@pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (128, 70, 35, 6), (256, 40, 32, 9), (384, 300, 256, 5), (512, 600, 512, 6),   # wide layers: two lanes / one stream (kbj_nn.hip SEQ_FUSED_MAX_H)
+                                     (256, 512, 512, 100)])   # the last one = the BASELINE minibatch
 def test_ppo_grad_matches_autograd(H, N, B, T):
     m, cfg, ctx, torch, buffers = _setup(N, B, T, H)
     from oracle import nn as ON
@@ -174,10 +175,10 @@ def test_ppo_grad_matches_autograd(H, N, B, T):
     ctx.close()
 
 
-@pytest.mark.parametrize("H,D", [(192, 2), (128, 1), (64, 3), (256, 4), (96, 2), (200, 2), (40, 1), (7, 3)])
+@pytest.mark.parametrize("H,D", [(192, 2), (128, 1), (64, 3), (256, 4), (96, 2), (200, 2), (40, 1), (7, 3), (320, 2), (512, 1), (400, 3)])
 def test_other_depths_and_hidden_sizes_match_oracle(H, D):
-    """`hidden_size` and `depth` are user fields of the reference config (train.py:78-85). The library serves any hidden size up to 256
-    (multiples of 64 natively; the others zero padded to the next one at the ABI boundary: parameters, carries and gradients keep the
+    """`hidden_size` and `depth` are user fields of the reference config (train.py:78-85). The library serves any hidden size up to 512
+    (multiples of 64 natively, above 256 on the wide schedule of kbj_nn.hip SEQ_FUSED_MAX_H; the others zero padded to the next one at the ABI boundary: parameters, carries and gradients keep the
     caller's hidden_size layout) and depth 1..4: one policy step (mode, value, every carry plane) and one minibatch gradient against the
     torch oracle / autograd."""
     N, B, T = 70, 35, 6
