@@ -5,7 +5,9 @@ import torch
 from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
 from kbot_joystick_amd.spec import layout as L
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-task = HumanoidWalkingTask(launch_config(num_envs=8192, robot="kbot-headless", seed=1))
+x3 = len(sys.argv) > 2 and sys.argv[2] == "gemm_bf16x3"   # the same run on the flagged bf16 x3 GEMM path
+print("GEMM path:", "bf16 x3 (kbj_config.gemm_bf16x3)" if x3 else "plain fp32 MFMA (default)")
+task = HumanoidWalkingTask(launch_config(num_envs=8192, robot="kbot-headless", seed=1, gemm_bf16x3=x3))
 for it in range(iters):
     task.train_iteration()
     if (it + 1) % 10 == 0 or it == 0:
