@@ -60,9 +60,10 @@ class HumanoidWalkingTaskConfig:
     save_every_n_seconds: Optional[float] = 60
     valid_every_n_steps: Optional[int] = 100      # train.py:1789: deterministic (argmax) validation rollout every n iterations
     valid_every_n_seconds: Optional[float] = None # train.py:1790
-    render_length_seconds: float = 10.0           # train.py:1785: length of a validation rollout (nothing is rendered here)
+    render_length_seconds: float = 10.0           # train.py:1785: length of a validation / view rollout
     max_values_per_plot: int = 50                 # train.py:1783 (plot thinning of the reference's logger; kept for name compatibility)
-    render_track_body_id: int = 0                 # train.py:1784 (viewer only; unused)
+    render_track_body_id: int = 0                 # train.py:1784: the body the view's camera follows (0, the world, = the base)
+    run_mode: str = "train"                       # README.md:66-70 `run_mode=view`: launch() plays the checkpointed policy instead of training (host/view.py)
     # the editable part of get_rewards() / get_commands() (train.py:1206-1256): overrides by reward name
     reward_scales: Optional[dict] = None          # e.g. {"feet_airtime": 2.0, "torque": 0.0}
     reward_params: Optional[dict] = None          # e.g. {"base_height": {"standard_height": 0.85}}
@@ -227,6 +228,8 @@ class HumanoidWalkingTask:
             raise B.KbjError("HumanoidWalkingTask needs a HIP device (no CPU fallback)")
         self.config = config
         self.rank, self.world_size = rank, world_size
+        if config.run_mode not in ("train", "view"):
+            raise ValueError(f"run_mode must be 'train' or 'view' (README.md:66-70), not {config.run_mode!r}")
         if config.use_lr_decay and config.adam_weight_decay == 0.0 and config.reproduce_reference_lr_sign:
             import sys                       # every rank, at construction: a single warnings.warn is easy to lose in a multi-rank log
             print(f"[kbj rank {rank}] reproduce_reference_lr_sign: optax.chain(scale_by_adam, scale_by_schedule) as written in "
@@ -619,9 +622,10 @@ class HumanoidWalkingTask:
         return [ckpt_io.load_ckpt(path, part, hidden_size=self.H, depth=self.kcfg.depth)]
 
     # ---- validation (train.py:1564 argmax=True; valid_every_n_steps train.py:1789) ----
-    def validate(self, num_envs: int = 64, seconds: Optional[float] = None, seed_offset: int = 7919) -> dict:
+    def validate(self, num_envs: int = 64, seconds: Optional[float] = None, seed_offset: int = 7919, _capture=None) -> dict:
         """Deterministic validation rollout: a separate small env set (its own context, carries and buffers, so training state is
-        untouched), actions = the distribution's mode, `render_length_seconds` long. Returns scalar statistics."""
+        untouched), actions = the distribution's mode, `render_length_seconds` long. Returns scalar statistics.
+        `_capture(ctx, frame)` (view()): called after the reset (frame 0) and after every control step."""
         seconds = self.config.render_length_seconds if seconds is None else seconds
         T = max(1, int(round(seconds / self.config.ctrl_dt)))
         key = (num_envs, T)
@@ -646,6 +650,8 @@ class HumanoidWalkingTask:
         if feeds:
             from .traj_view import StepView
             self._observe_into_rows(tr, 0, StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob))
+        if _capture is not None:
+            _capture(vctx, 0)
         for t in range(T):
             vctx.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], carry.c, seed, t, True, tr.action[t], tr.logp[t], tr.value[t])
             vctx.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
@@ -655,6 +661,8 @@ class HumanoidWalkingTask:
                 self._apply_command(vctx, tr, t + 1, StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob),
                                     tr.aux[t][:, L.AUX["DONE"]] != 0, seed_offset + t + 1)
             vctx.carry_reset(carry.c, tr.aux[t].data_ptr() + 4 * L.AUX["DONE"], L.AUX["SIZE"])
+            if _capture is not None:
+                _capture(vctx, t + 1)
         vctx.rewards(tr.aux, T, tr.reward, tr.comps)
         vctx.synchronize()
         done = tr.done
@@ -664,6 +672,31 @@ class HumanoidWalkingTask:
         for name, v in zip(constants.REWARD_NAMES, tr.comps.mean(dim=(0, 1)).cpu().tolist()):
             out[f"valid/reward/{name}"] = v
         return out
+
+    def view(self, path: Optional[str] = None, num_envs: int = 4, seconds: Optional[float] = None, seed_offset: int = 7919):
+        """`run_mode=view` (reference README.md:66-70; train.py:1783-1784 render_track_body_id / render_length_seconds): the validation
+        rollout above on `num_envs` envs with the generalised positions recorded after every control step (kbj_env_get_state), returned
+        as a `host.view.Recording`; with `path` (a stem) also written as `<path>.npz` and a self-contained `<path>.html` player."""
+        from .view import Recording
+        frames, eps = [], []
+
+        def capture(vctx, frame):
+            ep, es = vctx.env_get_state()
+            frames.append(es[:, L.ES["QPOS"]:L.ES["QPOS"] + int(self.model_blob.nq)].copy())
+            if frame == 0:
+                eps.append(ep.copy())
+        stats = self.validate(num_envs, seconds, seed_offset, _capture=capture)
+        tr = self._valid[3]
+        T = len(frames) - 1
+        rec = Recording(self.model_blob, np.stack(frames), eps[0], tr.aux[:T + 1, :, L.AUX["CMD"]:L.AUX["CMD"] + 16].cpu().numpy(), tr.reward[:T].cpu().numpy(),
+                        tr.done[:T].cpu().numpy(), self.config.ctrl_dt, self.config.render_track_body_id,
+                        (self.kcfg.terrain_amp, self.kcfg.terrain_wavelength))
+        rec.stats = stats
+        if path is not None:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            rec.save_npz(path + ".npz")
+            rec.save_html(path + ".html", title=f"kbot-joystick policy, iteration {self.iteration}: reward/step {stats['valid/reward_per_step']:.3f}")
+        return rec
 
     def scalars(self) -> dict:
         """The scalars the reference's logger plots after each iteration (train.py:1783-1790): loss terms, reward, terminations."""
@@ -703,6 +736,15 @@ class HumanoidWalkingTask:
         deterministic validation rollout runs every `valid_every_n_steps` iterations (train.py:1789)."""
         from .scalars import ScalarLogger
         task = cls(config)
+        if getattr(config, "run_mode", "train") == "view":      # README.md:66-70 `python -m train run_mode=view`: no training, play the checkpointed policy
+            ck = os.path.join(run_dir, "checkpoints", "ckpt.bin") if run_dir is not None else None
+            if ck and os.path.exists(ck):
+                task.load_checkpoint(ck)
+            out = os.path.join(run_dir if run_dir is not None else ".", "view", f"rollout_{task.iteration}")
+            rec = task.view(out)
+            if not quiet:
+                print(f"run_mode=view: {out}.html / .npz ({rec.qpos.shape[0]} frames x {rec.qpos.shape[1]} envs, reward/step {rec.stats['valid/reward_per_step']:.4f})")
+            return task
         logger, ckpt_path = None, None
         if run_dir is not None:
             logger = ScalarLogger(os.path.join(run_dir, "logs"))

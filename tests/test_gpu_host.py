@@ -510,3 +510,40 @@ def test_user_observation_routed_into_the_networks(tmp_path):
     task.export_actor(npz)
     ex = np.load(npz)
     assert ex["actor.input_proj.weight"].shape == (64, 68) and int(ex["meta.num_inputs"]) == 68
+
+
+def test_run_mode_view_records_the_policy_rollout(tmp_path):
+    """f4, `python -m train run_mode=view` (reference README.md:66-70): launch() with run_mode="view" loads the run directory's checkpoint and
+    writes a recording of the deterministic rollout (host/view.py). The recorded positions are the env states the validation rollout went
+    through: base height and foot heights from the recording's kinematics equal the kernel's own aux columns, frame by frame; the training
+    state is untouched; the recording is reproducible."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    from kbot_joystick_amd.spec import layout as L
+    run = str(tmp_path / "run_0")
+    t = HumanoidWalkingTask.launch(_small(render_length_seconds=1.0), num_iterations=2, run_dir=run, quiet=True)
+    p0, it0 = t.params.clone(), t.iteration
+    rec = t.view(None, num_envs=4)
+    F = rec.qpos.shape[0]
+    assert rec.qpos.shape == (51, 4, 27) and rec.xpos.shape == (51, 4, 24, 3) and rec.reward.shape == (50, 4)
+    tr = t._valid[3]
+    cobs = tr.critic_obs.cpu().numpy()            # row f = what the critic saw at frame f: base position / orientation are the state's own (clean) values
+    bp, bq = L.OBS["BASEPOS"][0], L.OBS["BASEQUAT"][0]
+    mb = t.model_blob
+    for f in (0, 1, 17, 50):
+        assert np.array_equal(rec.qpos[f][:, 0:3], cobs[f][:, bp:bp + 3]) and np.array_equal(rec.qpos[f][:, 3:7], cobs[f][:, bq:bq + 4])
+        assert np.array_equal(rec.xpos[f][:, int(mb.base_body)].astype(np.float32), cobs[f][:, bp:bp + 3])
+    assert np.all(rec.xpos[:, :, int(mb.lfoot_body), 2] > -0.05) and np.all(rec.xpos[:, :, int(mb.base_body), 2] < 1.5)     # a robot on the ground, not a scrambled record
+    assert np.array_equal(rec.cmd[3], tr.aux[3][:, L.AUX["CMD"]:L.AUX["CMD"] + 16].cpu().numpy())
+    assert torch.equal(t.params, p0) and t.iteration == it0
+    rec2 = t.view(None, num_envs=4)
+    assert np.array_equal(rec.qpos, rec2.qpos)
+    # the launch-level mode: a fresh process-level call that only plays the checkpoint
+    v = HumanoidWalkingTask.launch(_small(render_length_seconds=1.0, run_mode="view"), run_dir=run, quiet=True)
+    out = os.path.join(run, "view", f"rollout_{it0}")
+    assert v.iteration == it0 and os.path.exists(out + ".html") and os.path.exists(out + ".npz")
+    z = np.load(out + ".npz")
+    assert np.array_equal(z["qpos"], rec.qpos)                                       # same parameters (from ckpt.bin), same seed: same rollout
+    with pytest.raises(ValueError, match="run_mode"):
+        HumanoidWalkingTask(_small(run_mode="render"))
+    t.ctx.close(); v.ctx.close()

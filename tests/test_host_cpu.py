@@ -194,3 +194,61 @@ def test_reward_error_scales_are_validated():
     with pytest.raises(ValueError, match="finite"):
         launch_config(reward_params={"base_height": {"standard_height": float("nan")}}).to_kbj(4096)
     launch_config(reward_params={"roll_pitch": {"error_scale_zero_cmd": 0.02}, "feet_airtime": {"touchdown_penalty": 0.0}}).to_kbj(4096)
+
+
+def test_view_kinematics_match_the_oracle_and_the_player_page_is_self_contained(tmp_path):
+    """host/view.py (run_mode=view, reference README.md:66-70): body positions / orientations from the model blob's tree against the oracle's
+    forward pass at random poses, the foot capsules under the envs' randomised geometry, and the written page (data embedded, no external
+    reference)."""
+    import json, re
+    from kbot_joystick_amd.spec import compiler
+    from kbot_joystick_amd.host import view as V
+    from oracle import oracle as O
+    m = compiler.load_model("kbot-headless")
+    cfg = L.default_config(num_envs=3)
+    ep = O.default_params(m, cfg)
+    rng = np.random.default_rng(3)
+    nb, nq = int(m.nbody), int(m.nq)
+    qs = []
+    for _ in range(5):
+        q = np.array(m.qpos0[:nq], np.float64)
+        q[7:] += rng.normal(0, 0.5, nq - 7); qq = rng.normal(0, 1, 4); q[3:7] = qq / np.linalg.norm(qq); q[:3] += rng.normal(0, 0.3, 3)
+        r = O.forward(m, cfg, ep, q, np.zeros(26))
+        xp, xq = V.forward_kinematics(m, q)
+        sgn = np.sign((xq * r["xquat"][:nb]).sum(-1, keepdims=True))
+        assert np.abs(xp - r["xpos"][:nb]).max() < 1e-12 and np.abs(xq - sgn * r["xquat"][:nb])[1:].max() < 1e-12
+        qs.append(q)
+    # batched call == per-pose calls; capsule end points sit half a length either side of the centre, along the body's rotated axis
+    Q = np.stack(qs)[:, None, :].repeat(3, axis=1)                       # [F = 5][K = 3][nq]
+    xp, xq = V.forward_kinematics(m, Q)
+    assert np.array_equal(xp[2, 1], V.forward_kinematics(m, qs[2])[0])
+    eps = np.tile(ep, (3, 1)); eps[1, L.EP["CAP_HALF"]:L.EP["CAP_HALF"] + 4] *= 1.1
+    seg, rad = V.capsule_segments(m, xp, xq, eps[None])
+    ln = np.linalg.norm(seg[..., 1, :] - seg[..., 0, :], axis=-1)
+    assert np.allclose(ln[:, 0], 2 * eps[0, L.EP["CAP_HALF"]:L.EP["CAP_HALF"] + 4]) and np.allclose(ln[:, 1], 2.2 * eps[0, L.EP["CAP_HALF"]:L.EP["CAP_HALF"] + 4], rtol=1e-6)
+    rec = V.Recording(m, Q, eps, np.zeros((5, 3, 16), np.float32), np.zeros((4, 3), np.float32), np.zeros((4, 3), np.float32), 0.02, 0)
+    stem = str(tmp_path / "roll")
+    rec.save_npz(stem + ".npz"); rec.save_html(stem + ".html")
+    z = np.load(stem + ".npz")
+    assert z["qpos"].shape == (5, 3, nq) and z["xpos"].shape == (5, 3, nb, 3) and z["caps"].shape == (5, 3, 4, 2, 3)
+    page = open(stem + ".html").read()
+    assert "http://" not in page and "https://" not in page and "src=" not in page            # plays offline, nothing fetched
+    data = json.loads(re.search(r"const R = (\{.*?\});\n", page, re.S).group(1))
+    assert data["F"] == 5 and data["K"] == 3 and data["nbody"] == nb and data["track"] == 1 and len(data["xpos"][0][0]) == nb
+    assert np.allclose(np.array(data["xpos"]), xp, atol=1e-4)
+    # the page's script runs (node with a stub canvas, when the image has node): 120 animation frames without an exception
+    import shutil, subprocess
+    if shutil.which("node"):
+        js = re.search(r"<script>\n(.*)</script>", page, re.S).group(1)
+        stub = """
+const calls = {n: 0};
+const ctx = new Proxy({}, {get: (t, k) => (k in t) ? t[k] : (...a) => { calls.n++; }, set: (t, k, v) => { t[k] = v; return true; }});
+function el(id) { return {id, getContext: () => ctx, width: 1200, height: 520, add() {}, selectedIndex: 1, value: "1", textContent: "", onclick: null, oninput: null}; }
+const els = {};
+globalThis.document = {getElementById: (id) => els[id] || (els[id] = el(id)), createElement: () => ({})};
+let frames = 0;
+globalThis.requestAnimationFrame = (f) => { if (frames++ < 120) setImmediate(() => f(frames * 16.7)); else console.log("OK " + calls.n + " " + els.hud.textContent); };
+"""
+        (tmp_path / "check.js").write_text(stub + js)
+        out = subprocess.run(["node", str(tmp_path / "check.js")], capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0 and out.stdout.startswith("OK ") and "command vx" in out.stdout, out.stderr[-400:]
