@@ -55,6 +55,62 @@ def test_scalar_logger_writes_csv_and_tensorboard_events(tmp_path):
     assert rows[0] == "step,wall_time,train/loss,reward/linvel,valid/reward_per_step" and len(rows) == 3
 
 
+def test_tensorboard_event_file_decodes_with_the_protobuf_runtime(tmp_path):
+    """An INDEPENDENT reader for the hand-written event file: TFRecord framing walked here, every payload parsed by google.protobuf against
+    the schema TensorBoard reads (tensorflow/core/util/event.proto + framework/summary.proto field numbers: Event{wall_time = 1 double,
+    step = 2 int64, file_version = 3 string, summary = 5}, Summary{value = 1 repeated}, Value{tag = 1 string, simple_value = 2 float}),
+    descriptors built at run time; record CRCs checked against RFC 3720's CRC-32C test vectors' implementation below, not the writer's."""
+    pb = pytest.importorskip("google.protobuf")
+    import struct
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    from kbot_joystick_amd.host import scalars as S
+    fd = descriptor_pb2.FileDescriptorProto(name="kbj_tb_event.proto", package="tensorboard", syntax="proto3")
+    T = descriptor_pb2.FieldDescriptorProto
+    val = fd.message_type.add(name="Value")
+    val.field.add(name="tag", number=1, type=T.TYPE_STRING, label=T.LABEL_OPTIONAL)
+    val.field.add(name="simple_value", number=2, type=T.TYPE_FLOAT, label=T.LABEL_OPTIONAL)
+    summ = fd.message_type.add(name="Summary")
+    summ.field.add(name="value", number=1, type=T.TYPE_MESSAGE, label=T.LABEL_REPEATED, type_name=".tensorboard.Value")
+    evd = fd.message_type.add(name="Event")
+    evd.field.add(name="wall_time", number=1, type=T.TYPE_DOUBLE, label=T.LABEL_OPTIONAL)
+    evd.field.add(name="step", number=2, type=T.TYPE_INT64, label=T.LABEL_OPTIONAL)
+    evd.field.add(name="file_version", number=3, type=T.TYPE_STRING, label=T.LABEL_OPTIONAL)
+    evd.field.add(name="summary", number=5, type=T.TYPE_MESSAGE, label=T.LABEL_OPTIONAL, type_name=".tensorboard.Summary")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    Event = message_factory.GetMessageClass(pool.FindMessageTypeByName("tensorboard.Event"))
+
+    def crc32c_bitwise(data):                      # the definition (reflected polynomial 0x1EDC6F41), no table
+        c = 0xFFFFFFFF
+        for b in data:
+            c ^= b
+            for _ in range(8):
+                c = (c >> 1) ^ (0x82F63B78 & -(c & 1))
+        return c ^ 0xFFFFFFFF
+    assert crc32c_bitwise(bytes(32)) == 0x8A9136AA and crc32c_bitwise(bytes([0xFF] * 32)) == 0x62A8AB43      # RFC 3720 B.4
+    mask = lambda c: (((c >> 15) | (c << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+    lg = S.ScalarLogger(str(tmp_path))
+    lg.log(7, {"train/loss": 0.75, "reward/feet_airtime": -0.125})
+    lg.log(1 << 40, {"perf/env_steps_per_s": 2.25e6})
+    lg.close()
+    raw = open(glob.glob(str(tmp_path / "events.out.tfevents.*"))[0], "rb").read()
+    off, events = 0, []
+    while off < len(raw):
+        (n,) = struct.unpack_from("<Q", raw, off)
+        assert struct.unpack_from("<I", raw, off + 8)[0] == mask(crc32c_bitwise(raw[off:off + 8]))
+        payload = raw[off + 12:off + 12 + n]
+        assert struct.unpack_from("<I", raw, off + 12 + n)[0] == mask(crc32c_bitwise(payload))
+        e = Event()
+        e.ParseFromString(payload)
+        assert e.SerializeToString() == payload          # nothing in the payload the schema does not know, canonical field order
+        events.append(e)
+        off += 16 + n
+    assert off == len(raw) and events[0].file_version == "brain.Event:2" and events[0].wall_time > 1e9
+    got = [(e.step, {v.tag: v.simple_value for v in e.summary.value}) for e in events[1:]]
+    assert got == [(7, {"train/loss": 0.75, "reward/feet_airtime": -0.125}), (1 << 40, {"perf/env_steps_per_s": 2.25e6})]
+    assert all(e.wall_time > 1e9 for e in events[1:])
+
+
 def test_reward_and_command_overrides_reach_kbj_config():
     from kbot_joystick_amd.host.task import launch_config
     c = launch_config(reward_scales={"torque": 0.0, "feet_airtime": 2.0}, reward_params={"base_height": {"standard_height": 0.85}},
