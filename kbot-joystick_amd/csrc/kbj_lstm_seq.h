@@ -586,6 +586,11 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_rs_kernel(const SeqBwdA
     if (SEQ_BSTAMP_ON && a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 10 + 9] = wall_clock64();
     float dhm[2] = {0.0f, 0.0f};
     float act[2][4], tc[2], cprev[2], dha[2], kp[2];
+    // this step's own inputs were fetched a step ago; the next step's are issued here, in front of the flag wait (whose barrier also keeps the
+    // compiler from sinking them to their use): they land during the wait, the partial loads and the cell
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { tc[i] = tcn[i]; cprev[i] = cprevn[i]; dha[i] = dhan[i]; kp[i] = kpn[i]; for (int k = 0; k < 4; ++k) act[i][k] = actn[i][k]; }
+    fetch_inputs(t - 1);
     if (t != T - 1) {
       if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)(T - 1 - t), a.err, &flag, a.spin_limit)) return;
       SEQ_BSTAMP(1);
@@ -606,43 +611,51 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_rs_kernel(const SeqBwdA
       SEQ_BSTAMP(2);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { tc[i] = tcn[i]; cprev[i] = cprevn[i]; dha[i] = dhan[i]; kp[i] = kpn[i]; for (int k = 0; k < 4; ++k) act[i][k] = actn[i][k]; }
-    fetch_inputs(t - 1);   // own inputs of the next step: behind the partial loads and their wait, they land during the cell and the matrix phase
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int r = r0 + erow[i];
-      float d0 = 0.0f, d1 = 0.0f, d2 = 0.0f, d3 = 0.0f;
+    for (int i = 0; i < 2; ++i) {     // rows beyond the batch: their inputs were fetched as zeros, so every term below is zero - no branch around the arithmetic
+      const int r = r0 + erow[i];
+      const float ig = act[i][0], fg = act[i][1], gg = act[i][2], og = act[i][3];
+      const float dh = dha[i] + kp[i] * dhm[i];
+      const float dc = kp[i] * dcm[i] + dh * og * (1 - tc[i] * tc[i]);
+      const float d0 = dc * gg * ig * (1 - ig), d1 = dc * cprev[i] * fg * (1 - fg), d2 = dc * ig * (1 - gg * gg), d3 = dh * tc[i] * og * (1 - og);
+      float* q = dgt + erow[i] * LDK + eunit[i];
+      q[0] = d0; q[UNITS] = d1; q[2 * UNITS] = d2; q[3 * UNITS] = d3;
+      bsum[i][0] += d0; bsum[i][1] += d1; bsum[i][2] += d2; bsum[i][3] += d3;
+      dcm[i] = dc * fg;
       if (r < B) {
-        float ig = act[i][0], fg = act[i][1], gg = act[i][2], og = act[i][3];
-        float dh = dha[i] + kp[i] * dhm[i];
-        float dc = kp[i] * dcm[i] + dh * og * (1 - tc[i] * tc[i]);
         float* dg = a.dG + ((size_t)t * B + r) * 4 * H + u0 + eunit[i];
-        d0 = dc * gg * ig * (1 - ig); d1 = dc * cprev[i] * fg * (1 - fg); d2 = dc * ig * (1 - gg * gg); d3 = dh * tc[i] * og * (1 - og);
         seq_store(dg, d0);            // the input of the batched dW / dX GEMMs (write-through: the chunk-gated schedule reads it while this kernel runs)
         seq_store(dg + H, d1);
         seq_store(dg + 2 * H, d2);
         seq_store(dg + 3 * H, d3);
-        bsum[i][0] += d0; bsum[i][1] += d1; bsum[i][2] += d2; bsum[i][3] += d3;
-        dcm[i] = dc * fg;
       }
-      float* q = dgt + erow[i] * LDK + eunit[i];
-      q[0] = d0; q[UNITS] = d1; q[2 * UNITS] = d2; q[3 * UNITS] = d3;
     }
     SEQ_BSTAMP(3);
     if (t > 0) {
       __syncthreads();
       SEQ_BSTAMP(4);
-      float* pout = a.part + (size_t)(t & 1) * par_stride + ((size_t)(rg * NUG + ug) * SEQ_ROWS) * H + c0 + (lane & 15);
+      // operands swapped (weights as A, the dG fragment as B): D[i][j] = column c0 + 16 ct + i of batch row j, so a lane's four accumulator
+      // registers are four CONSECUTIVE columns of one row - one 16-byte write-through store each instead of four 4-byte ones
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, 0x7FFFFFFF, 0x00020000);
+      const unsigned pbase = (unsigned)(((size_t)(t & 1) * par_stride + ((size_t)(rg * NUG + ug) * SEQ_ROWS + (lane & 15)) * H + c0 + 4 * (lane >> 4)) * sizeof(float));
+      const float* p0 = dgt + (lane & 15) * LDK + 4 * (lane >> 4);
+      const float* p1 = p0 + 16 * LDK;
+      static_assert(KK::REM == 0, "the workgroup's dG entries come in 16-k blocks");
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) {
         f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-        KK::template mma<false>(dgt, lane, wreg[ct], acc0, acc1, 0, KK::NB);
-        static_assert(KK::REM == 0, "the workgroup's dG entries come in 16-k blocks");
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {      // this column tile's stores drain under the next tile's MFMAs
-          seq_store(pout + (size_t)((lane >> 4) * 4 + r) * H + 16 * ct, acc0[r]);
-          seq_store(pout + (size_t)(16 + (lane >> 4) * 4 + r) * H + 16 * ct, acc1[r]);
+        for (int j = 0; j < KK::NB; ++j) {
+          const f32x4m f0 = *reinterpret_cast<const f32x4m*>(p0 + 16 * j), f1 = *reinterpret_cast<const f32x4m*>(p1 + 16 * j);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ct][4 * j + q], f0[q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ct][4 * j + q], f1[q], acc1, 0, 0, 0);
+          }
         }
+        // this column tile's stores drain under the next tile's MFMAs
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc0), prs, pbase + (unsigned)(16 * ct * sizeof(float)), 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc1), prs, pbase + (unsigned)((16 * H + 16 * ct) * sizeof(float)), 0, 16);
         if (ct == 0) SEQ_BSTAMP(5);
       }
       SEQ_BSTAMP(6);
