@@ -85,7 +85,6 @@ struct SeqBwdArgs {
   float* db_part = nullptr;   // deterministic mode: [row groups][4H] per-row-group column sums instead (added to db in order by reduce_rows_kernel)
   unsigned spin_limit = SEQ_SPIN_LIMIT;
   long long* stamps = nullptr;   // optional [T][10] shader-clock stamps of workgroup 0 (diagnostics)
-  float* part = nullptr;         // lstm_seq_bwd_rs_kernel: [2][row groups][H / 32][32][H] partial products of the step in flight (two parities)
 };
 
 // gate non-linearities on the hardware exp/rcp units (v_exp_f32, v_rcp_f32: ~1 ulp each; shared with the rollout cell kernel)
@@ -524,167 +523,6 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const SeqBwdArgs a) {
   }
   if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x + 2] = wall_clock64();
 }
-// The same recurrence with the contraction on the PRODUCER's side ("reduce-scatter" form). A workgroup owns 32 hidden units, i.e. 128 of the
-// 4H entries of a dG row. Above, every workgroup gathers the whole dG_{t+1} tile of its row group (128 KB per step through L2, four LDS
-// stagings with a barrier each) to contract it with its 32 columns of W_hh. Here it contracts ITS OWN 128 entries - still in LDS from the
-// cell stage, no round trip - with the matching 128 ROWS of W_hh (all H columns, 64 registers per lane again), hands the [32 x H] partial
-// product to its partners (32 KB out), and each workgroup sums the eight partials of its 32 columns (32 KB in, straight into registers).
-// Per step and workgroup: 64 KB of hand-off traffic instead of 144, one barrier instead of five, 17 KB of LDS instead of 52; the matrix
-// work is the same 128 MFMAs per wavefront. dh = sum of eight partial chains instead of one chain: rounding differs at the 1e-7 level.
-template <int H, int UW>
-__global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_rs_kernel(const SeqBwdArgs a) {
-  constexpr int NTH = 256 * UW, UNITS = SEQ_UNITS * UW, NW = NTH / 64;
-  constexpr int NUG = H / UNITS;
-  constexpr int KO = 4 * UNITS;              // this workgroup's entries of a dG row: kk = gate * UNITS + unit
-  typedef SeqK<KO> KK;
-  constexpr int LDK = KK::LD;
-  static_assert(H % (16 * NW) == 0, "every wavefront owns whole 16-column tiles of the partial product");
-  constexpr int CT = H / (16 * NW);          // 16-column tiles per wavefront
-  __shared__ __attribute__((aligned(16))) float dgt[SEQ_ROWS * LDK];
-  __shared__ int flag;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nblk = gridDim.x;
-  const int lid = (nblk % 8 == 0) ? (int)(blockIdx.x % 8) * (nblk / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;   // XCD-aware, as above
-  const int ug = lid % NUG, rg = lid / NUG;
-  const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
-  const int B = a.B, T = a.T;
-  const int c0 = wave * 16 * CT;             // first output column of this wavefront
-  // B operands: k-step s, column tile ct: B[k slot g][col] = Whh[row(KK::kidx(s, g))][c0 + 16 ct + col], row(kk) = (kk / UNITS) H + u0 + kk % UNITS
-  float wreg[CT][KK::STEPS];
-#pragma unroll
-  for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-    for (int st = 0; st < KK::STEPS; ++st) {
-      const int kk = KK::kidx(st, lane >> 4);
-      wreg[ct][st] = a.Whh[(size_t)((kk / UNITS) * H + u0 + kk % UNITS) * H + c0 + 16 * ct + (lane & 15)];
-    }
-  int erow[2], eunit[2];
-  float dcm[2] = {0.0f, 0.0f};
-  float bsum[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-#pragma unroll
-  for (int i = 0; i < 2; ++i) { int e = tid + NTH * i; erow[i] = e / UNITS; eunit[i] = e % UNITS; }
-  float actn[2][4], tcn[2], cprevn[2], dhan[2], kpn[2];
-  auto fetch_inputs = [&](int tt) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      int r = r0 + erow[i];
-      bool ok = r < B && tt >= 0;
-      size_t o1 = ((size_t)(ok ? tt : 0) * B + (ok ? r : 0)) * H + u0 + eunit[i];
-      const float* g = a.Gact + ((size_t)(ok ? tt : 0) * B + (ok ? r : 0)) * 4 * H + u0 + eunit[i];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) actn[i][k] = ok ? g[k * H] : 0.0f;
-      tcn[i] = ok ? a.TanhC[o1] : 0.0f;
-      cprevn[i] = ok ? a.Cm[o1] : 0.0f;
-      dhan[i] = ok ? a.dHabove[o1] : 0.0f;
-      kpn[i] = ok ? a.keep[(size_t)tt * B + r] : 0.0f;
-    }
-  };
-  const size_t par_stride = (size_t)(gridDim.x / NUG) * NUG * SEQ_ROWS * H;     // one parity of the partial-product buffer
-  fetch_inputs(T - 1);
-  for (int t = T - 1; t >= 0; --t) {
-    SEQ_BSTAMP(0);
-    if (SEQ_BSTAMP_ON && a.stamps && blockIdx.x == 0 && tid == 0) a.stamps[t * 10 + 9] = wall_clock64();
-    float dhm[2] = {0.0f, 0.0f};
-    float act[2][4], tc[2], cprev[2], dha[2], kp[2];
-    // this step's own inputs were fetched a step ago; the next step's are issued here, in front of the flag wait (whose barrier also keeps the
-    // compiler from sinking them to their use): they land during the wait, the partial loads and the cell
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { tc[i] = tcn[i]; cprev[i] = cprevn[i]; dha[i] = dhan[i]; kp[i] = kpn[i]; for (int k = 0; k < 4; ++k) act[i][k] = actn[i][k]; }
-    fetch_inputs(t - 1);
-    if (t != T - 1) {
-      if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)(T - 1 - t), a.err, &flag, a.spin_limit)) return;
-      SEQ_BSTAMP(1);
-      // the eight partial products of step t + 1 for this workgroup's columns (sc1 loads: written by other CUs a moment ago)
-      const float* pin = a.part + (size_t)((t + 1) & 1) * par_stride + (size_t)rg * NUG * SEQ_ROWS * H + u0;
-      float pv[2][NUG];
-#pragma unroll
-      for (int src = 0; src < NUG; ++src)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) pv[i][src] = __hip_atomic_load(pin + ((size_t)src * SEQ_ROWS + erow[i]) * H + eunit[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float s0 = 0.0f;
-#pragma unroll
-        for (int src = 0; src < NUG; ++src) s0 += pv[i][src];      // fixed order: the sum is reproducible
-        dhm[i] = s0;
-      }
-      SEQ_BSTAMP(2);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {     // rows beyond the batch: their inputs were fetched as zeros, so every term below is zero - no branch around the arithmetic
-      const int r = r0 + erow[i];
-      const float ig = act[i][0], fg = act[i][1], gg = act[i][2], og = act[i][3];
-      const float dh = dha[i] + kp[i] * dhm[i];
-      const float dc = kp[i] * dcm[i] + dh * og * (1 - tc[i] * tc[i]);
-      const float d0 = dc * gg * ig * (1 - ig), d1 = dc * cprev[i] * fg * (1 - fg), d2 = dc * ig * (1 - gg * gg), d3 = dh * tc[i] * og * (1 - og);
-      float* q = dgt + erow[i] * LDK + eunit[i];
-      q[0] = d0; q[UNITS] = d1; q[2 * UNITS] = d2; q[3 * UNITS] = d3;
-      bsum[i][0] += d0; bsum[i][1] += d1; bsum[i][2] += d2; bsum[i][3] += d3;
-      dcm[i] = dc * fg;
-      if (r < B) {
-        float* dg = a.dG + ((size_t)t * B + r) * 4 * H + u0 + eunit[i];
-        seq_store(dg, d0);            // the input of the batched dW / dX GEMMs (write-through: the chunk-gated schedule reads it while this kernel runs)
-        seq_store(dg + H, d1);
-        seq_store(dg + 2 * H, d2);
-        seq_store(dg + 3 * H, d3);
-      }
-    }
-    SEQ_BSTAMP(3);
-    if (t > 0) {
-      __syncthreads();
-      SEQ_BSTAMP(4);
-      // operands swapped (weights as A, the dG fragment as B): D[i][j] = column c0 + 16 ct + i of batch row j, so a lane's four accumulator
-      // registers are four CONSECUTIVE columns of one row - one 16-byte write-through store each instead of four 4-byte ones
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(a.part, 0, 0x7FFFFFFF, 0x00020000);
-      const unsigned pbase = (unsigned)(((size_t)(t & 1) * par_stride + ((size_t)(rg * NUG + ug) * SEQ_ROWS + (lane & 15)) * H + c0 + 4 * (lane >> 4)) * sizeof(float));
-      const float* p0 = dgt + (lane & 15) * LDK + 4 * (lane >> 4);
-      const float* p1 = p0 + 16 * LDK;
-      static_assert(KK::REM == 0, "the workgroup's dG entries come in 16-k blocks");
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct) {
-        f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-#pragma unroll
-        for (int j = 0; j < KK::NB; ++j) {
-          const f32x4m f0 = *reinterpret_cast<const f32x4m*>(p0 + 16 * j), f1 = *reinterpret_cast<const f32x4m*>(p1 + 16 * j);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ct][4 * j + q], f0[q], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wreg[ct][4 * j + q], f1[q], acc1, 0, 0, 0);
-          }
-        }
-        // this column tile's stores drain under the next tile's MFMAs
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc0), prs, pbase + (unsigned)(16 * ct * sizeof(float)), 0, 16);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc1), prs, pbase + (unsigned)((16 * H + 16 * ct) * sizeof(float)), 0, 16);
-        if (ct == 0) SEQ_BSTAMP(5);
-      }
-      SEQ_BSTAMP(6);
-    }
-    SEQ_BSTAMP(7);
-    seq_publish(a.counters + rg * NUG + ug, (unsigned)(T - t));     // (its barrier also ends this step's reads of dgt)
-    if (a.progress && tid == 0 && t % a.chunk_steps == 0) __hip_atomic_fetch_add(a.progress + t / a.chunk_steps, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    SEQ_BSTAMP(8);
-  }
-  if (a.db || a.db_part) {      // bias gradient: this workgroup's 32 rows reduced through LDS (dgt is free now), one atomic per column
-    __syncthreads();
-    float (*pb)[SEQ_ROWS][UNITS + 1] = reinterpret_cast<float (*)[SEQ_ROWS][UNITS + 1]>(dgt);
-    static_assert(4 * SEQ_ROWS * (UNITS + 1) <= SEQ_ROWS * LDK, "the bias reduction fits the dG tile");
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      pb[k][erow[0]][eunit[0]] = bsum[0][k];
-      pb[k][erow[1]][eunit[1]] = bsum[1][k];
-    }
-    __syncthreads();
-    if (tid < 4 * UNITS) {
-      int k = tid / UNITS, u = tid % UNITS;
-      float s0 = 0;
-      for (int r = 0; r < SEQ_ROWS; ++r) s0 += pb[k][r][u];
-      if (a.db_part) a.db_part[(size_t)rg * 4 * H + k * H + u0 + u] = s0;
-      else atomicAdd(a.db + k * H + u0 + u, s0);
-    }
-  }
-}
-
 // hidden sizes up to 256: the capped register budget above. Wider layers (the weight slice alone is H / 4 registers per gate chunk pair)
 // run one recurrence at a time and without GEMM workgroups beside them (kbj_nn.hip: one_stream), so their kernel takes what it needs.
 template <int H, int UW>

@@ -43,8 +43,6 @@ struct Sched {
   bool gemm_x3 = false;            // kbj_config.gemm_bf16x3 / KBJ_GEMM_X3=1: the GEMM launches that are eligible (the update's input gradients, weight-gradient
                                    // pairs and critic input projection, the rollout's [x | h] gate GEMMs) on the bf16 matrix cores through the exact three-way
                                    // operand split (kbj_gemm.h gemm_x3_kernel); not the default, not the headline
-  bool bwd_rs = false;             // KBJ_SEQ_BWD_RS=1: backward recurrences in the producer-side ("reduce-scatter") form, hidden sizes 128 / 256
-                                   // (kbj_lstm_seq.h lstm_seq_bwd_rs_kernel)
   bool chunk_dx = false;           // KBJ_BWD_CHUNK_DX=1 (with bwd_chunks > 1): the input-gradient GEMM per chunk as well (slower: 6.64 / 6.83 ms at 2 / 4 chunks)
 };
 constexpr int MAX_BWD_CHUNKS = 10;
@@ -98,7 +96,6 @@ struct NnWs {
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
   unsigned* bwd_progress = nullptr;  // [layer][net][MAX_BWD_CHUNKS] chunk completion counts of the backward recurrences (cleared with the hand-off counters)
-  float* seq_part[2] = {nullptr, nullptr};   // bwd_rs: partial products in flight, one buffer per lane ([2 parities][row groups][H / 32][32][H])
   long long* seq_stamps = nullptr;   // diagnostics (KBJ_SEQ_STAMPS=1): per-step clock stamps of one workgroup
   long long* seq_bstamps = nullptr;  // same for a backward recurrence (KBJ_SEQ_BSTAMPS = 1 + net + 2 * layer)
   std::vector<void*> allocs;
@@ -277,9 +274,6 @@ template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0
   SeqBwdArgs a = a0;
   a.spin_limit = g_seq_spin_limit;
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
-  if constexpr (H == 128 || H == 256) {
-    if (a.part) { hipLaunchKernelGGL((lstm_seq_bwd_rs_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a); return; }
-  }
   if constexpr (H <= SEQ_FUSED_MAX_H) hipLaunchKernelGGL((lstm_seq_bwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
   else hipLaunchKernelGGL((lstm_seq_bwd_wide_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
@@ -325,11 +319,6 @@ template <int H> hipError_t seq_min_blocks_per_cu(int* out) {
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], lstm_seq_fwd_kernel<H, SEQ_UW, true, H>, threads, 0);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], lstm_seq_fwd_kernel<H, SEQ_UW, true, KBJ_LD_ACTOR>, threads, 0);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], lstm_seq_bwd_kernel<H, SEQ_UW>, threads, 0);
-    if constexpr (H == 128 || H == 256) {
-      int nr = 0;
-      if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nr, lstm_seq_bwd_rs_kernel<H, SEQ_UW>, threads, 0);
-      n[3] = std::min(n[3], nr);
-    }
   } else {
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], lstm_seq_bwd_wide_kernel<H, SEQ_UW>, threads, 0);
     n[0] = n[1] = n[2];
@@ -532,11 +521,6 @@ int kbj_nn_create(kbj_ctx* ctx) {
     sc.gemm_x3 = (c.gemm_bf16x3 != 0 || env_flag("KBJ_GEMM_X3", false)) && !sc.deterministic;   // (the deterministic split-K slabs stay on the exact kernel)
     sc.bwd_chunks = getenv("KBJ_BWD_CHUNKS") ? atoi(getenv("KBJ_BWD_CHUNKS")) : 1;
     sc.chunk_dx = env_flag("KBJ_BWD_CHUNK_DX", false);
-    sc.bwd_rs = env_flag("KBJ_SEQ_BWD_RS", false) && (H == 128 || H == 256);
-    if (sc.bwd_rs) {
-      const size_t par = (size_t)((B + SEQ_ROWS - 1) / SEQ_ROWS) * SEQ_ROWS * (H / (SEQ_UNITS * SEQ_UW)) * H;
-      for (int l = 0; l < 2; ++l) if (dalloc(ctx, *w, &w->seq_part[l], 2 * par)) return -1;
-    }
     if (sc.bwd_chunks < 1 || sc.bwd_chunks > MAX_BWD_CHUNKS) return kbj_fail(ctx, "KBJ_BWD_CHUNKS must be in 1..10");
     if (H > (size_t)SEQ_FUSED_MAX_H) sc.fuse_ih = sc.fuse_obs = sc.rollout_step = false;   // wide layers (SEQ_FUSED_MAX_H above)
     if (sc.one_stream) sc.bwd_chunks = 1;   // no lanes, nothing to run under the recurrence
@@ -1292,7 +1276,6 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + SEQ_COUNTER_WORDS * (4 * (D + l) + n), w.seq_err, T, B, grad_d + o.b[l]};
       ba.db_part = det_partials(ctx, ns[n & 1]);   // deterministic mode: per-row-group bias sums, added in order below
       if (nch > 1) { ba.progress = w.bwd_progress + (size_t)(4 * l + n) * MAX_BWD_CHUNKS; ba.chunk_steps = TC; }
-      if (sc.bwd_rs) ba.part = w.seq_part[n & 1];
       if (w.seq_bstamps && bstamp_sel == 1 + n + 2 * l) ba.stamps = w.seq_bstamps;
       if (seq_bwd(ctx, ns[n & 1], H, ba)) return -1;
       if (ba.db_part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, ns[n & 1], ba.db_part, nrg, 4 * H, grad_d + o.b[l]);

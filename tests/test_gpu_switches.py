@@ -27,9 +27,6 @@ SWITCHES = {
     "KBJ_BWD_CHUNKS=4": {"KBJ_BWD_CHUNKS": "4"},
     "KBJ_BWD_CHUNKS=3+DX": {"KBJ_BWD_CHUNKS": "3", "KBJ_BWD_CHUNK_DX": "1"},
     "KBJ_GEMM_X3=1": {"KBJ_GEMM_X3": "1"},       # = kbj_config.gemm_bf16x3: the backward pass's large GEMMs through the exact three-way bf16 split
-    "KBJ_SEQ_BWD_RS=1": {"KBJ_SEQ_BWD_RS": "1"},  # backward recurrences in the producer-side form (lstm_seq_bwd_rs_kernel; hidden sizes 128 / 256)
-    "KBJ_SEQ_BWD_RS=1+DET": {"KBJ_SEQ_BWD_RS": "1", "KBJ_DETERMINISTIC": "1"},
-    "KBJ_SEQ_BWD_RS=1+CHUNKS": {"KBJ_SEQ_BWD_RS": "1", "KBJ_BWD_CHUNKS": "3"},
 }
 
 
@@ -92,16 +89,6 @@ def _autograd(torch, cfg, tr, idx, H, aux):
 @pytest.mark.parametrize("name", [k for k in SWITCHES if k != "KBJ_ROLLOUT_STEP=0"])
 @pytest.mark.parametrize("H,N,B,T", [(64, 12, 8, 7), (256, 96, 64, 9)])      # T = 9 in 4 chunks: 3 + 3 + 3 steps (one chunk empty); in 3: 3 + 3 + 3
 def test_switch_gradient_matches_autograd(monkeypatch, name, H, N, B, T):
-    _check_switch_gradient(monkeypatch, name, H, N, B, T)
-
-
-@pytest.mark.parametrize("name", ["KBJ_SEQ_BWD_RS=1", "KBJ_SEQ_BWD_RS=1+DET"])
-def test_bwd_rs_with_a_ragged_last_row_group(monkeypatch, name):
-    """The producer-side backward recurrence at H = 128 (one column tile per wavefront) with 35 rows: a second row group of 3 rows."""
-    _check_switch_gradient(monkeypatch, name, 128, 70, 35, 6)
-
-
-def _check_switch_gradient(monkeypatch, name, H, N, B, T):
     import torch
     from oracle import nn as ON
     m, cfg, ctx = _ctx(monkeypatch, SWITCHES[name], N, B, T, H)
