@@ -14,10 +14,10 @@ fail() { echo "profile_all.sh: step failed: $*" >&2; exit 1; }
 # the diagnostics builds the stamp tools load (hipcc is on the GPU box too): never profile against a missing library
 make -C $R/kbot-joystick_amd/csrc -s stamps bstamps > $O/make_diag.log 2>&1 || fail "make stamps bstamps"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $O/stats -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/stats.log 2>&1 || fail "rocprofv3 --stats"
+rocprofv3 --kernel-trace --stats -d $O/stats -o run -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants > $O/stats.log 2>&1 || fail "rocprofv3 --stats"
 python3 $R/tools/rocprof_summary.py $O/stats/run_results.db > $O/kernel_stats.md || fail rocprof_summary
-python3 $R/tools/pmc_sq.py $O/pmc_bench --set hbm --set mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_bench.txt 2>&1 || fail "pmc_sq bench"
-KBJ_PROFILE_CMD="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline" python3 $R/tools/pmc_traffic.py $O/pmc_bench/pass0 $O/pmc_bench/pass1 > $O/pmc_traffic.json || fail pmc_traffic
+python3 $R/tools/pmc_sq.py $O/pmc_bench --set hbm --set mfma -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-variants > $O/pmc_bench.txt 2>&1 || fail "pmc_sq bench"
+KBJ_PROFILE_CMD="python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-variants" python3 $R/tools/pmc_traffic.py $O/pmc_bench/pass0 $O/pmc_bench/pass1 > $O/pmc_traffic.json || fail pmc_traffic
 python3 $R/tools/pmc_sq.py $O/pmc_env --kernel env_step --set sq --set hbm -- python3 $R/tools/bench_env.py 8192 > $O/pmc_env.txt 2>&1 || fail "pmc_sq env"
 # the raw traces are hundreds of MB: only the summaries travel back (gpurun_out is capped at 64 MiB)
 cp $O/pmc_bench/summary.json $O/pmc_bench_summary.json && cp $O/pmc_env/summary.json $O/pmc_env_summary.json || fail "copy summaries"

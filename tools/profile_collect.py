@@ -27,7 +27,7 @@ def main():
     json.dump(bench, open(os.path.join(out, f"{tag}_bench_n1.json"), "w"), indent=1)
     md = open(os.path.join(src, "kernel_stats.md")).read()
     with open(os.path.join(out, f"{tag}_rocprofv3_kernel_stats.md"), "w") as f:
-        f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline ({tag}, one MI355X)\n\n" + md)
+        f.write(f"# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-variants ({tag}, one MI355X)\n\n" + md)
     # HBM traffic (passes 0 = FETCH_SIZE, 1 = WRITE_SIZE of the bench command)
     tr = json.load(open(os.path.join(src, "pmc_traffic.json")))      # written on the GPU box by tools/pmc_traffic.py (carries the source fingerprint)
     try:
