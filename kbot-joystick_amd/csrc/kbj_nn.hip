@@ -1263,6 +1263,11 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // steps [c * TC, (c + 1) * TC); the recurrence runs downwards, so chunks complete from the last one to chunk 0. A gate only waits for a
   // kernel enqueued before it. (Own lanes for the input-gradient chunks - KBJ_DX_LANE=1 - cost 0.7 ms per minibatch by merely existing:
   // two more streams change how HIP maps this context's lanes onto hardware queues.)
+  // KBJ_DW_AFTER_DX=0: a layer's weight-gradient GEMMs start beside its input-gradient GEMM instead of behind it. Behind is the default: the
+  // input gradient is on the net's critical chain (the next layer's recurrence reads it) and ran at 0.73 ms next to the low-priority weight
+  // gradients against 0.29 ms alone; the weight gradients lose nothing, they overlap the next layer's recurrence either way (368.6 -> 365.6 ms
+  // per iteration, three alternations on one box)
+  static const bool dw_after_dx = env_flag("KBJ_DW_AFTER_DX", true);
   const int nch_req = (sc.bwd_chunks > 1 && T >= 2 * sc.bwd_chunks) ? sc.bwd_chunks : 1;
   const int TC = (T + nch_req - 1) / nch_req;
   const int nch = (T + TC - 1) / TC;      // chunks that hold at least one step (T = 9 in 4 chunks of 3 steps: 3 chunks)
@@ -1292,7 +1297,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       // lane orders.)
       const bool own_lane = l == 0 && nch == 1 && !w.mirror && folded;
       if (own_lane) ws = s;
-      else if (nch == 1) fork_side(n);     // the side lane starts behind the whole recurrence
+      else if (nch == 1 && !(dw_after_dx && !folded)) fork_side(n);     // the side lane starts behind the whole recurrence
       // (the dx and side lanes need no event from the net's lane here: a gate passes only once this layer's recurrence runs, and that
       // recurrence started behind everything the lane did before - the previous readers of the dX buffer included)
       for (int c = nch - 1; c >= 0; --c) {
@@ -1319,6 +1324,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
           linear_bwd_input(dx_of(n), dG, 4 * H, params_d + o.w_ih[l], H, dx_out[n] + r0 * H, H, Rc, H, 4 * H, 0);
         } else if (c == nch - 1) {   // the input gradient as ONE product on the net's own lane, behind the recurrence (it is the next layer's input)
           linear_bwd_input(s, t.dGl[l], 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
+          if (dw_after_dx && nch == 1 && !own_lane) fork_side(n);   // the weight gradients start behind the input gradient, not beside it
         }
         linear_bwd_weight2(ctx, ws, dG, 4 * H, t.Hm[l] + r0 * H, (l == 0 ? t.X0 : t.Hout[l - 1]) + r0 * H, H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, Rc);
       }
