@@ -337,24 +337,25 @@ def main():
     # ---- non-headline leg: the same workload with kbj_config.gemm_bf16x3 (the update's large backward GEMMs on the bf16 matrix cores through the
     # exact three-way split of their fp32 operands), its own task, timed after everything that feeds the headline ----
     variant = None
-    if not args.gemm_bf16x3 and not args.no_variants and not args.force_collective:
-        # the headline context goes first: its lanes would still count against the variant's (two contexts' worth of streams put both over the
-        # queue-mapping cliff of DESIGN.md section 10 - measured: 400 instead of 335 ms per iteration)
-        task.ctx.synchronize(); task.ctx.close(); task = None
-        torch.cuda.empty_cache()
-        cfg_v = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, allreduce=args.allreduce, gemm_bf16x3=True, **wl)
-        task = HumanoidWalkingTask(cfg_v, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
-        el = timed_steps(max(1, min(args.warmup, 2)), args.steps)
-        if world > 1:
-            t = torch.tensor([el], device="cuda", dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
-        variant = dict(name="gemm_bf16x3", NOT_THE_HEADLINE=True, value=round(args.envs_per_gpu * world * task.T * args.steps / el, 1), unit="env-steps/s",
-                       ms_per_step=round(el / args.steps * 1e3, 2),
-                       what="kbj_config.gemm_bf16x3 = 1: input-gradient and weight-gradient GEMMs of the PPO update as 6 bf16 MFMA products per fp32 product "
-                            "(operands split exactly into three bf16 pieces, fp32 accumulation); everything else identical. Error study: DESIGN.md section 10b, "
-                            "parity: tests/test_gpu_switches.py")
-        task.ctx.close()
+    rollout_steps = task.T
+    if not args.gemm_bf16x3 and not args.no_variants and not args.force_collective and world == 1:
+        # (one GPU only: a multi-rank job reports its headline and nothing else - a leg that one rank could fail alone must not sit in front of the line)
+        try:
+            # the headline context goes first: its lanes would still count against the variant's (two contexts' worth of streams put both over the
+            # queue-mapping cliff of DESIGN.md section 10 - measured: 400 instead of 335 ms per iteration)
+            task.ctx.synchronize(); task.ctx.close(); task = None
+            torch.cuda.empty_cache()
+            cfg_v = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, allreduce=args.allreduce, gemm_bf16x3=True, **wl)
+            task = HumanoidWalkingTask(cfg_v, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
+            el = timed_steps(max(1, min(args.warmup, 2)), args.steps)
+            variant = dict(name="gemm_bf16x3", NOT_THE_HEADLINE=True, value=round(args.envs_per_gpu * world * task.T * args.steps / el, 1), unit="env-steps/s",
+                           ms_per_step=round(el / args.steps * 1e3, 2),
+                           what="kbj_config.gemm_bf16x3 = 1: input-gradient and weight-gradient GEMMs of the PPO update as 6 bf16 MFMA products per fp32 product "
+                                "(operands split exactly into three bf16 pieces, fp32 accumulation); everything else identical. Error study: DESIGN.md section 10b, "
+                                "parity: tests/test_gpu_switches.py")
+            task.ctx.close()
+        except Exception as e:     # the headline above is already measured: never lose the line to the non-headline leg
+            variant = dict(name="gemm_bf16x3", NOT_THE_HEADLINE=True, value=None, error=f"{type(e).__name__}: {e}"[:300])
     if forced is not None:      # third leg: the actor's gradient slice all-reduced on a second stream under the critic's tail
         forced.update(ms_per_step_forced_allreduce=round(elapsed / args.steps * 1e3, 2), allreduce_ms_per_iteration=round(allreduce_ms, 3),
                       allreduce_calls_per_iteration=allreduce_calls)
@@ -380,7 +381,7 @@ def main():
         "variant": "headline: plain fp32-MFMA kernels" if not args.gemm_bf16x3 else "NOT THE HEADLINE: --gemm-bf16x3 (kbj_config.gemm_bf16x3)",
         "config": {"workload": ("[variant gemm_bf16x3] " if args.gemm_bf16x3 else "") + wl_name.format(n=args.envs_per_gpu) + ", full iteration: "
                                f"100-step rollout + PPO update (batch 512/GPU, 3 passes, LSTM hidden {args.hidden}, depth 2)",
-                   "envs_per_gpu": args.envs_per_gpu, "rollout_steps": task.T, "batch_size_per_gpu": cfg.batch_size, "num_passes": cfg.num_passes,
+                   "envs_per_gpu": args.envs_per_gpu, "rollout_steps": rollout_steps, "batch_size_per_gpu": cfg.batch_size, "num_passes": cfg.num_passes,
                    "hidden_size": args.hidden, "baseline_config": args.config, "parallelism": f"env-sharded dp{world}, grad all-reduce {'per optimizer step' if args.allreduce == 'per_step' else 'once per pass (accumulated)'}"
                                   + (f" [{args.backend}{', ranks share GPU 0' if args.share_gpu else ''}]" if world > 1 else "")},
         "roofline": roofline, "roofline_secondary": roofline2, "cpu_baseline": cpu,
