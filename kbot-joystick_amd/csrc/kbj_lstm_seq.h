@@ -82,6 +82,8 @@ struct SeqBwdArgs {
   // and drained, and the GEMMs that consume them (seq_gate_kernel in front of them on their own lanes) start while the recurrence goes on
   unsigned* progress = nullptr;
   int chunk_steps = 0;
+  unsigned* entered = nullptr;   // optional: every workgroup adds 1 on entry; a gate kernel on another lane (seq_gate_kernel) lets that lane's GEMMs
+                                 // start only once the whole grid is resident (kbj_nn.hip: KBJ_DW_GATE)
   float* db_part = nullptr;   // deterministic mode: [row groups][4H] per-row-group column sums instead (added to db in order by reduce_rows_kernel)
   unsigned spin_limit = SEQ_SPIN_LIMIT;
   long long* stamps = nullptr;   // optional [T][10] shader-clock stamps of workgroup 0 (diagnostics)
@@ -397,6 +399,7 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const SeqBwdArgs a) {
   const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
+  if (a.entered && tid == 0) __hip_atomic_fetch_add(a.entered, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x] = wall_clock64();   // per-workgroup entry / loop start / exit
   constexpr int KW = H / 4;        // k range of one wave inside a gate chunk
   constexpr int KS = KW / 4;       // k-steps per (wave, gate chunk)

@@ -95,6 +95,7 @@ struct NnWs {
   const double* ext_adv_sums = nullptr;   // kbj_set_advantage_sums: (sum adv, sum adv^2, count) on the device, used instead of the minibatch's own statistics
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
+  unsigned* bwd_entered = nullptr;   // [layer][net] workgroups of a backward recurrence that have started (same allocation, same clear)
   unsigned* bwd_progress = nullptr;  // [layer][net][MAX_BWD_CHUNKS] chunk completion counts of the backward recurrences (cleared with the hand-off counters)
   long long* seq_stamps = nullptr;   // diagnostics (KBJ_SEQ_STAMPS=1): per-step clock stamps of one workgroup
   long long* seq_bstamps = nullptr;  // same for a backward recurrence (KBJ_SEQ_BSTAMPS = 1 + net + 2 * layer)
@@ -505,7 +506,8 @@ int kbj_nn_create(kbj_ctx* ctx) {
   for (int n = 0; n < w->nnets; ++n) if (dalloc(ctx, *w, &w->Zeff[n], 4 * H * w->net[n & 1].ld_obs)) return -1;
   for (int k = 0; k < 2; ++k) if (dalloc(ctx, *w, &w->WinP[k], H * w->net[k].ld_obs)) return -1;
   if (hipMemset(w->Weff, 0, (size_t)4 * H * w->net[0].ld_obs * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset Weff");
-  if (dalloc(ctx, *w, &w->seq_counters, 2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS)) return -1;
+  if (dalloc(ctx, *w, &w->seq_counters, 2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS + MAXD * 4)) return -1;
+  w->bwd_entered = w->seq_counters + 2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS;
   w->bwd_progress = w->seq_counters + 2 * MAXD * 4 * SEQ_COUNTER_WORDS;   // same allocation: one clear covers both   // [phase: forward layer l = l, backward layer l = D + l][net][row group x unit group]
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
   if (getenv("KBJ_SEQ_STAMPS")) { if (dalloc(ctx, *w, &w->seq_stamps, (size_t)T * 6)) return -1; }
@@ -980,7 +982,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
   hipStream_t s = ctx->stream;
   ns[0] = ctx->stream; ns[1] = sc.one_stream ? ctx->stream : ctx->stream2;
   // hand-off counters of all eight (sixteen with the mirror branches) recurrence launches of this call: one clear, ahead of both lanes
-  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, (2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS) * sizeof(unsigned), s));
+  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, (2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS + MAXD * 4) * sizeof(unsigned), s));
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   // the gates of the dx lanes poll the chunk counters: never before this call's clear (the side lanes follow their net's lane later on)
@@ -1268,12 +1270,23 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // gradients against 0.29 ms alone; the weight gradients lose nothing, they overlap the next layer's recurrence either way (368.6 -> 365.6 ms
   // per iteration, three alternations on one box)
   static const bool dw_after_dx = env_flag("KBJ_DW_AFTER_DX", true);
+  // KBJ_DW_GATE=0 switches this off: a layer's weight-gradient GEMMs are enqueued behind the NEXT layer's recurrence launches and wait
+  // (seq_gate_kernel on their side lane) until every workgroup of those recurrences is resident. Without it both become eligible in the same
+  // microsecond, GEMM workgroups (72 KB of LDS each, two per CU) take the CUs, and the recurrence - which advances at the pace of its last
+  // workgroup to enter - stands still for 0.2-0.7 ms (`[kbj seq_bwd stamps] last entry`); with it the recurrence's 256 workgroups are placed
+  // first (layer-0 backward recurrences 0.72-0.79 ms instead of 1.2-1.4 in the trace of the bf16 x3 line) and the GEMMs fill in around them.
+  // The end of the minibatch moves little - the work is conserved and a GEMM workgroup beside a recurrence workgroup gets a quarter of a CU:
+  // 362.9 / 365.0 -> 362.1 / 363.3 ms per iteration, bf16 x3 line 333.9 / 335.8 -> 330.0 / 329.4 (alternating runs on one box).
+  static const bool dw_gate_env = env_flag("KBJ_DW_GATE", true);
+  struct PendingDW { int n, l; };
+  std::vector<PendingDW> pending_dw;
   const int nch_req = (sc.bwd_chunks > 1 && T >= 2 * sc.bwd_chunks) ? sc.bwd_chunks : 1;
   const int TC = (T + nch_req - 1) / nch_req;
   const int nch = (T + TC - 1) / TC;      // chunks that hold at least one step (T = 9 in 4 chunks of 3 steps: 3 chunks)
   const unsigned seq_grid = (unsigned)(nrg * (H / (SEQ_UNITS * SEQ_UW)));
   auto gate = [&](hipStream_t st, const unsigned* ctr) { hipLaunchKernelGGL(seq_gate_kernel, dim3(1), dim3(64), 0, st, ctr, seq_grid, w.seq_err, g_seq_spin_limit); };
   auto dx_of = [&](int n) { return ctx->dxs[n & 1] ? ctx->dxs[n & 1] : side_of(n); };   // without dx lanes: on the side lane, ahead of the chunk's weight gradients
+  const bool dw_gate = dw_gate_env && dw_after_dx && nch == 1 && !one_stream;
   for (int l = D - 1; l >= 0; --l) {
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
@@ -1282,9 +1295,19 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       ba.db_part = det_partials(ctx, ns[n & 1]);   // deterministic mode: per-row-group bias sums, added in order below
       if (nch > 1) { ba.progress = w.bwd_progress + (size_t)(4 * l + n) * MAX_BWD_CHUNKS; ba.chunk_steps = TC; }
       if (w.seq_bstamps && bstamp_sel == 1 + n + 2 * l) ba.stamps = w.seq_bstamps;
+      if (dw_gate) ba.entered = w.bwd_entered + 4 * l + n;
       if (seq_bwd(ctx, ns[n & 1], H, ba)) return -1;
       if (ba.db_part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, ns[n & 1], ba.db_part, nrg, 4 * H, grad_d + o.b[l]);
     }
+    for (const PendingDW& p : pending_dw) {   // the layer above's weight gradients: behind this layer's recurrences (of the net and of its partner lane's net)
+      const NetOff& o = w.net[p.n & 1];
+      TrainBufs& t = w.tb[p.n];
+      hipStream_t ws = side_of(p.n);
+      gate(ws, w.bwd_entered + 4 * l + p.n);
+      if ((p.n ^ 1) < w.nnets) gate(ws, w.bwd_entered + 4 * l + (p.n ^ 1));
+      linear_bwd_weight2(ctx, ws, t.dGl[p.l], 4 * H, t.Hm[p.l], p.l == 0 ? t.X0 : t.Hout[p.l - 1], H, grad_d + o.w_hh[p.l], grad_d + o.w_ih[p.l], H, 4 * H, H, R);
+    }
+    pending_dw.clear();
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
@@ -1326,7 +1349,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
           linear_bwd_input(s, t.dGl[l], 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
           if (dw_after_dx && nch == 1 && !own_lane) fork_side(n);   // the weight gradients start behind the input gradient, not beside it
         }
-        linear_bwd_weight2(ctx, ws, dG, 4 * H, t.Hm[l] + r0 * H, (l == 0 ? t.X0 : t.Hout[l - 1]) + r0 * H, H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, Rc);
+        if (dw_gate && l > 0 && !own_lane) pending_dw.push_back(PendingDW{n, l});   // enqueued behind the next layer's recurrence launches (above)
+        else linear_bwd_weight2(ctx, ws, dG, 4 * H, t.Hm[l] + r0 * H, (l == 0 ? t.X0 : t.Hout[l - 1]) + r0 * H, H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, Rc);
       }
       if (folded) {
         // dW_in += W_ih0^T Z, dW_ih0 += Z W_in^T (the bias terms follow from db_0 at the end)
