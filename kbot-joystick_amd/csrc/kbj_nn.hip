@@ -1270,14 +1270,17 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // gradients against 0.29 ms alone; the weight gradients lose nothing, they overlap the next layer's recurrence either way (368.6 -> 365.6 ms
   // per iteration, three alternations on one box)
   static const bool dw_after_dx = env_flag("KBJ_DW_AFTER_DX", true);
-  // KBJ_DW_GATE=0 switches this off: a layer's weight-gradient GEMMs are enqueued behind the NEXT layer's recurrence launches and wait
+  // KBJ_DW_GATE=1 (off by default): a layer's weight-gradient GEMMs are enqueued behind the NEXT layer's recurrence launches and wait
   // (seq_gate_kernel on their side lane) until every workgroup of those recurrences is resident. Without it both become eligible in the same
   // microsecond, GEMM workgroups (72 KB of LDS each, two per CU) take the CUs, and the recurrence - which advances at the pace of its last
   // workgroup to enter - stands still for 0.2-0.7 ms (`[kbj seq_bwd stamps] last entry`); with it the recurrence's 256 workgroups are placed
   // first (layer-0 backward recurrences 0.72-0.79 ms instead of 1.2-1.4 in the trace of the bf16 x3 line) and the GEMMs fill in around them.
   // The end of the minibatch moves little - the work is conserved and a GEMM workgroup beside a recurrence workgroup gets a quarter of a CU:
   // 362.9 / 365.0 -> 362.1 / 363.3 ms per iteration, bf16 x3 line 333.9 / 335.8 -> 330.0 / 329.4 (alternating runs on one box).
-  static const bool dw_gate_env = env_flag("KBJ_DW_GATE", true);
+  // NOT the default: a gate needs the kernel it waits for to run CONCURRENTLY with it. Under a profiler that serialises kernels
+  // (rocprofv3 --pmc) the gate is dispatched alone, spins to its bound and the call fails (fail-stop, but a failed profile run); the default
+  // schedule has no kernel that waits for another kernel.
+  static const bool dw_gate_env = env_flag("KBJ_DW_GATE", false);
   struct PendingDW { int n, l; };
   std::vector<PendingDW> pending_dw;
   const int nch_req = (sc.bwd_chunks > 1 && T >= 2 * sc.bwd_chunks) ? sc.bwd_chunks : 1;
