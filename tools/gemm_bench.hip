@@ -238,6 +238,12 @@ int main(int argc, char** argv) {
     compare_x3<true, true>("square", 4096, 4096, 4096, 1, A, B, C, 8000);
     return 0;
   }
+  if (only == 7) {   // tile-count quantisation of the 128 x 128 kernel on the input-gradient shape: 512 slots (2 workgroups per CU)
+    // (M <= 51200: the operand buffers hold 51200 x 1024 floats)
+    for (int M : {16384, 32768, 40960, 49152, 51200}) run<true, false>("dx (M x H x 4H), M sweep", M, 256, 1024, 1, -1, A, B, C, false);
+    for (int M : {32768, 49152, 51200}) run<true, true>("fwd in critic (M x H x 476), M sweep", M, 256, 476, 1, -1, A, B, C, false);
+    return 0;
+  }
   if (only) {
     if (only == 1) run<true, true>("fwd ih (R x 4H x H)", 51200, 1024, 256, 1, -1, A, B, C, false);
     if (only == 2) run<true, false>("dx (R x H x 4H)", 51200, 256, 1024, 1, -1, A, B, C, false);
