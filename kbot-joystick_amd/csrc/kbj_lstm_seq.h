@@ -546,6 +546,15 @@ __global__ void seq_gate_kernel(const unsigned* ctr, unsigned target, unsigned* 
   }
 }
 
+// A fixed pause on a lane (one lane of one wavefront sleeping until `ticks` of the constant-rate clock have passed): it waits for NOTHING, so
+// it is safe under any serialisation of kernels. kbj_nn.hip puts it in front of the weight-gradient GEMMs of a layer so that the next
+// layer's recurrences - eligible at the same moment - have their workgroups placed before the GEMM workgroups take the CUs.
+__global__ void seq_delay_kernel(unsigned ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long t0 = wall_clock64();
+  for (unsigned i = 0; i < (1u << 16) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
 // ---- one LSTM layer step for MANY independent rows (rollout: 8192 envs, no recurrence inside the launch) ------------------------------
 // Same register-resident weight slices and fused cell as the forward recurrence above, but the loop runs over row groups instead of
 // time: workgroup (chunk, ug) keeps the 128 gate columns of its 32 hidden units as MFMA B operands (W_ih and W_hh slices, 128 VGPRs)

@@ -1281,6 +1281,13 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // (rocprofv3 --pmc) the gate is dispatched alone, spins to its bound and the call fails (fail-stop, but a failed profile run); the default
   // schedule has no kernel that waits for another kernel.
   static const bool dw_gate_env = env_flag("KBJ_DW_GATE", false);
+  // KBJ_DW_DELAY_US=n (default 30, 0 = off): the profiler-safe form of the same idea. The weight-gradient lanes wait (stream events only) until
+  // BOTH lanes' input gradients are done - i.e. until both next-layer recurrences are eligible and nothing new is being dispatched - then pause
+  // n microseconds (seq_delay_kernel: waits for nothing) and only then start: the recurrences' workgroups are placed in that window.
+  // 365.9 / 365.4 / 364.7 ms per iteration without, 363.0 / 362.0 / 363.8 with 20 us, 362.2 / 362.9 / 363.4 with 60 us, 362.4 / 361.6 / 362.7
+  // with the gate (alternating runs on one box).
+  static const int dw_delay_us = getenv("KBJ_DW_DELAY_US") ? atoi(getenv("KBJ_DW_DELAY_US")) : 30;
+  static const unsigned wall_khz = [&] { int k = 0; hipDeviceGetAttribute(&k, hipDeviceAttributeWallClockRate, ctx->device); return (unsigned)(k > 0 ? k : 100000); }();
   struct PendingDW { int n, l; };
   std::vector<PendingDW> pending_dw;
   const int nch_req = (sc.bwd_chunks > 1 && T >= 2 * sc.bwd_chunks) ? sc.bwd_chunks : 1;
@@ -1290,6 +1297,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   auto gate = [&](hipStream_t st, const unsigned* ctr) { hipLaunchKernelGGL(seq_gate_kernel, dim3(1), dim3(64), 0, st, ctr, seq_grid, w.seq_err, g_seq_spin_limit); };
   auto dx_of = [&](int n) { return ctx->dxs[n & 1] ? ctx->dxs[n & 1] : side_of(n); };   // without dx lanes: on the side lane, ahead of the chunk's weight gradients
   const bool dw_gate = dw_gate_env && dw_after_dx && nch == 1 && !one_stream;
+  const bool dw_delay = !dw_gate && dw_delay_us > 0 && dw_after_dx && nch == 1 && !one_stream;
   for (int l = D - 1; l >= 0; --l) {
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
@@ -1306,8 +1314,14 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       const NetOff& o = w.net[p.n & 1];
       TrainBufs& t = w.tb[p.n];
       hipStream_t ws = side_of(p.n);
-      gate(ws, w.bwd_entered + 4 * l + p.n);
-      if ((p.n ^ 1) < w.nnets) gate(ws, w.bwd_entered + 4 * l + (p.n ^ 1));
+      if (dw_gate) {
+        gate(ws, w.bwd_entered + 4 * l + p.n);
+        if ((p.n ^ 1) < w.nnets) gate(ws, w.bwd_entered + 4 * l + (p.n ^ 1));
+      } else {   // dw_delay: both lanes' input gradients (recorded below, an iteration ago), then the pause
+        hipStreamWaitEvent(ws, ctx->ev_dx[p.n & 1], 0);
+        if (w.nnets > 1) hipStreamWaitEvent(ws, ctx->ev_dx[(p.n & 1) ^ 1], 0);
+        hipLaunchKernelGGL(seq_delay_kernel, dim3(1), dim3(64), 0, ws, (unsigned)((unsigned long long)dw_delay_us * wall_khz / 1000u));
+      }
       linear_bwd_weight2(ctx, ws, t.dGl[p.l], 4 * H, t.Hm[p.l], p.l == 0 ? t.X0 : t.Hout[p.l - 1], H, grad_d + o.w_hh[p.l], grad_d + o.w_ih[p.l], H, 4 * H, H, R);
     }
     pending_dw.clear();
@@ -1350,9 +1364,10 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
           linear_bwd_input(dx_of(n), dG, 4 * H, params_d + o.w_ih[l], H, dx_out[n] + r0 * H, H, Rc, H, 4 * H, 0);
         } else if (c == nch - 1) {   // the input gradient as ONE product on the net's own lane, behind the recurrence (it is the next layer's input)
           linear_bwd_input(s, t.dGl[l], 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
-          if (dw_after_dx && nch == 1 && !own_lane) fork_side(n);   // the weight gradients start behind the input gradient, not beside it
+          if (dw_delay && l > 0 && !own_lane) hipEventRecord(ctx->ev_dx[n & 1], s);   // (the side lane picks it up behind the next layer's recurrence launches)
+          else if (dw_after_dx && nch == 1 && !own_lane) fork_side(n);   // the weight gradients start behind the input gradient, not beside it
         }
-        if (dw_gate && l > 0 && !own_lane) pending_dw.push_back(PendingDW{n, l});   // enqueued behind the next layer's recurrence launches (above)
+        if ((dw_gate || dw_delay) && l > 0 && !own_lane) pending_dw.push_back(PendingDW{n, l});   // enqueued behind the next layer's recurrence launches (above)
         else linear_bwd_weight2(ctx, ws, dG, 4 * H, t.Hm[l] + r0 * H, (l == 0 ? t.X0 : t.Hout[l - 1]) + r0 * H, H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, Rc);
       }
       if (folded) {

@@ -27,6 +27,7 @@ SWITCHES = {
     "KBJ_BWD_CHUNKS=4": {"KBJ_BWD_CHUNKS": "4"},
     "KBJ_BWD_CHUNKS=3+DX": {"KBJ_BWD_CHUNKS": "3", "KBJ_BWD_CHUNK_DX": "1"},
     "KBJ_DW_AFTER_DX=0": {"KBJ_DW_AFTER_DX": "0"},
+    "KBJ_DW_DELAY_US=0": {"KBJ_DW_DELAY_US": "0"},
     "KBJ_DW_GATE=1": {"KBJ_DW_GATE": "1"},
     "KBJ_DW_GATE=1+DET": {"KBJ_DW_GATE": "1", "KBJ_DETERMINISTIC": "1"},
     "KBJ_GEMM_X3=1": {"KBJ_GEMM_X3": "1"},       # = kbj_config.gemm_bf16x3: the backward pass's large GEMMs through the exact three-way bf16 split
