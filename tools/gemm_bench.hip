@@ -244,6 +244,10 @@ int main(int argc, char** argv) {
     for (int M : {32768, 49152, 51200}) run<true, true>("fwd in critic (M x H x 476), M sweep", M, 256, 476, 1, -1, A, B, C, false);
     return 0;
   }
+  if (only == 8) {   // the paired weight-gradient product (4H x 2H x R) over its split-K factor: workgroups = 32 tiles x sk
+    for (int sk : {8, 12, 16, 20, 24, 25, 28, 32, 40, 48}) run<false, false>("dW pair (4H x 2H x R), sk sweep", 1024, 512, 51200, sk, 1, A, B, C, false);
+    return 0;
+  }
   if (only) {
     if (only == 1) run<true, true>("fwd ih (R x 4H x H)", 51200, 1024, 256, 1, -1, A, B, C, false);
     if (only == 2) run<true, false>("dx (R x H x 4H)", 51200, 256, 1024, 1, -1, A, B, C, false);
