@@ -116,7 +116,9 @@ def cpu_baseline(repeats: int = 3):
     tr0.train_iteration()
     t0 = float(np.median([timed(tr0) for _ in range(3)]))
     return dict(value=2048 * 100 / t_large, unit="env-steps/s", cores=best_l, kind="port", host_cores=os.cpu_count(), usable_cores=usable,
-                sample=f"oracle full iteration (rollout + GAE + 3 passes) on 2048 envs x 100 steps, batch 512, hidden 256: one iteration = {t_large:.2f} s at the best "
+                samples=1,
+                sample=f"SINGLE SAMPLE (one timed iteration, ~20 s of CPU work; BASELINE.md section 3's median-of-3 applies to small_sample): "
+                       f"oracle full iteration (rollout + GAE + 3 passes) on 2048 envs x 100 steps, batch 512, hidden 256: one iteration = {t_large:.2f} s at the best "
                        f"of the thread sweep ({best_l} threads; this process may use {usable} of the host's {os.cpu_count()} cores)",
                 thread_sweep_probe="2048 envs x 20 steps, batch 512: seconds per iteration by thread count (stops at the first setting > 1.3x the best or after 60 s)",
                 thread_sweep_seconds_per_iteration={str(k): v for k, v in sweep_l.items()},
@@ -176,6 +178,76 @@ def spawn_ranks(n: int) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def run_leg_in_child(leg: str, args, timeout_s: float) -> dict:
+    """A non-headline leg (`--leg variant` / `--leg train_loop`) in a FRESH child process of this one: a hard fault, abort or hang in it can
+    cost its own object of the line, never the headline that is already measured (a try / except only catches Python exceptions). The child is
+    started with subprocess (fork + exec of a new interpreter - never an exec of this GPU-initialised process) and prints one JSON object."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--leg", leg, "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--envs-per-gpu", str(args.envs_per_gpu), "--hidden", str(args.hidden), "--config", str(args.config), "--allreduce", args.allreduce,
+           "--loop-iterations", str(args.loop_iterations)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+    except subprocess.TimeoutExpired:
+        return dict(value=None, error=f"leg {leg}: no result after {timeout_s:.0f} s (child killed)")
+    for line in reversed(out.stdout.strip().splitlines()):
+        if line.startswith("{"):
+            try:
+                return json.loads(line)
+            except json.JSONDecodeError:
+                break
+    return dict(value=None, error=f"leg {leg}: child exited with {out.returncode}: {out.stderr.strip()[-300:]}")
+
+
+def leg_variant(args, cfg_kw, wl) -> dict:
+    """Child process: the headline workload with kbj_config.gemm_bf16x3, timed like the headline."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
+    task = HumanoidWalkingTask(launch_config(gemm_bf16x3=True, **cfg_kw, **wl), device=torch.device("cuda", 0))
+    for _ in range(max(1, min(args.warmup, 2))):
+        task.train_iteration()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        task.train_iteration()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    out = dict(name="gemm_bf16x3", NOT_THE_HEADLINE=True, value=round(args.envs_per_gpu * task.T * args.steps / el, 1), unit="env-steps/s",
+               ms_per_step=round(el / args.steps * 1e3, 2), process="child of bench.py (own context, nothing else on the GPU)",
+               what="kbj_config.gemm_bf16x3 = 1: input-gradient and weight-gradient GEMMs of the PPO update as 6 bf16 MFMA products per fp32 product "
+                    "(operands split exactly into three bf16 pieces, fp32 accumulation); everything else identical. Error study: DESIGN.md section 10b, "
+                    "parity: tests/test_gpu_switches.py")
+    task.close()
+    return out
+
+
+def leg_train_loop(args, cfg_kw, wl) -> dict:
+    """Child process: HumanoidWalkingTask.launch() as a user of the reference runs it (train.py:1759-1792) - scalar logging every iteration (CSV +
+    TensorBoard event file), deterministic validation rollouts, ckpt.bin rewritten on a timer - on the headline workload. The reference's
+    block validates every 100 iterations and saves every 60 s; over the bounded length of this leg that would be no validation at all, so
+    the leg validates every 25 iterations and saves every 10 s (both MORE often than the reference: a conservative figure)."""
+    import tempfile
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
+    n = max(1, args.loop_iterations)
+    with tempfile.TemporaryDirectory(prefix="kbj_train_loop_") as run_dir:
+        cfg = launch_config(valid_every_n_steps=25, save_every_n_seconds=10, **cfg_kw, **wl)
+        task = HumanoidWalkingTask.launch(cfg, num_iterations=n, run_dir=run_dir, quiet=True)
+        st = dict(task.loop_stats)
+        ck = os.path.getsize(os.path.join(run_dir, "checkpoints", "ckpt.bin"))
+        task.close()
+    return dict(name="train_loop", value=round(st["env_steps_per_s"], 1), unit="env-steps/s", iterations=st["iterations"],
+                ms_per_iteration=round(st["loop_seconds"] / st["iterations"] * 1e3, 2), validations=st["validations"],
+                validation_seconds=round(st["validation_seconds"], 3), checkpoints_in_loop=st["checkpoints"],
+                checkpoint_seconds_in_line=round(st["checkpoint_seconds"], 3), final_checkpoint_seconds=round(st.get("final_checkpoint_seconds", 0.0), 3),
+                checkpoint_bytes=ck, process="child of bench.py (own context, nothing else on the GPU)",
+                what="HumanoidWalkingTask.launch(): every iteration followed by task.scalars() + CSV / TensorBoard logging; validate() (64 envs x "
+                     "render_length_seconds, argmax actions) every 25 iterations; ckpt.bin every 10 s (device arrays snapshotted in line, container "
+                     "written by a background thread); wall time from the first iteration to the end of the last, iteration 1's one-time "
+                     "allocations included")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -197,7 +269,9 @@ def main():
     ap.add_argument("--gemm-bf16x3", action="store_true",
                     help="NOT the headline: kbj_config.gemm_bf16x3 - the update's large backward GEMMs on the bf16 matrix cores through the exact three-way "
                          "split of their fp32 operands (DESIGN.md section 10b). The line says so in `variant`, `dtype` and `config.workload`")
-    ap.add_argument("--no-variants", action="store_true", help="skip the extra, non-headline leg (the gemm_bf16x3 variant timed after the headline run)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the extra, non-headline legs (the gemm_bf16x3 variant and the launch()-based training loop, each run in a child process after the headline is measured)")
+    ap.add_argument("--leg", default=None, choices=["variant", "train_loop"], help="internal: run ONE non-headline leg in this (child) process and print its JSON object")
+    ap.add_argument("--loop-iterations", type=int, default=64, help="length of the train_loop leg (launch() with validation / checkpoints / logging)")
     ap.add_argument("--allreduce", default=os.environ.get("KBJ_ALLREDUCE", "per_step"), choices=["per_step", "per_pass"],
                     help="per_step (default): all-reduce before every optimizer step; per_pass: accumulate a pass, one all-reduce + one step per pass")
     args = ap.parse_args()
@@ -234,7 +308,13 @@ def main():
     wl_name = {1: "kbot-headless, {n} envs/GPU, flat ground, fixed joystick command (0.5,0,0)",
                3: "kbot-headless, {n} envs/GPU, flat ground, UnifiedCommand 6-mode sampler",
                4: "kbot (full), {n} envs/GPU, sine terrain (A 0.05 m, L 2 m), UnifiedCommand sampler, pushes + all randomizers"}[args.config]
-    cfg = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, allreduce=args.allreduce, gemm_bf16x3=args.gemm_bf16x3, **wl)
+    cfg_kw = dict(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, allreduce=args.allreduce)
+    if args.leg:       # child process of a one-GPU bench.py: one non-headline leg, one JSON object
+        if world != 1:
+            sys.exit("bench.py: --leg is the one-GPU child of bench.py")
+        print(json.dumps(leg_variant(args, cfg_kw, wl) if args.leg == "variant" else leg_train_loop(args, cfg_kw, wl)), flush=True)
+        return
+    cfg = launch_config(gemm_bf16x3=args.gemm_bf16x3, **cfg_kw, **wl)
     task = HumanoidWalkingTask(cfg, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
     def barrier():
@@ -334,28 +414,22 @@ def main():
             meas = traffic_src["hbm_bytes_per_iteration"] / iter_s / 1e9
             hbm.update(measured=round(meas, 1), measured_frac=round(meas / PEAK_HBM_GBS, 4), measured_bytes_per_iteration=round(traffic_src["hbm_bytes_per_iteration"]))
 
-    # ---- non-headline leg: the same workload with kbj_config.gemm_bf16x3 (the update's large backward GEMMs on the bf16 matrix cores through the
-    # exact three-way split of their fp32 operands), its own task, timed after everything that feeds the headline ----
-    variant = None
+    # ---- non-headline legs, each in a child process started AFTER everything that feeds the headline is measured: (1) the same workload with
+    # kbj_config.gemm_bf16x3 (the update's large GEMMs on the bf16 matrix cores through the exact three-way split of their fp32 operands,
+    # DESIGN.md section 10b); (2) the training loop a user runs - HumanoidWalkingTask.launch() with logging, validation rollouts and periodic
+    # checkpoints. A hard fault or hang in either costs its own object, not the line.
+    variant = train_loop = None
     rollout_steps = task.T
     if not args.gemm_bf16x3 and not args.no_variants and not args.force_collective and world == 1:
-        # (one GPU only: a multi-rank job reports its headline and nothing else - a leg that one rank could fail alone must not sit in front of the line)
-        try:
-            # the headline context goes first: its lanes would still count against the variant's (two contexts' worth of streams put both over the
-            # queue-mapping cliff of DESIGN.md section 10 - measured: 400 instead of 335 ms per iteration)
-            task.ctx.synchronize(); task.ctx.close(); task = None
-            torch.cuda.empty_cache()
-            cfg_v = launch_config(num_envs=args.envs_per_gpu * world, hidden_size=args.hidden, seed=0, allreduce=args.allreduce, gemm_bf16x3=True, **wl)
-            task = HumanoidWalkingTask(cfg_v, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
-            el = timed_steps(max(1, min(args.warmup, 2)), args.steps)
-            variant = dict(name="gemm_bf16x3", NOT_THE_HEADLINE=True, value=round(args.envs_per_gpu * world * task.T * args.steps / el, 1), unit="env-steps/s",
-                           ms_per_step=round(el / args.steps * 1e3, 2),
-                           what="kbj_config.gemm_bf16x3 = 1: input-gradient and weight-gradient GEMMs of the PPO update as 6 bf16 MFMA products per fp32 product "
-                                "(operands split exactly into three bf16 pieces, fp32 accumulation); everything else identical. Error study: DESIGN.md section 10b, "
-                                "parity: tests/test_gpu_switches.py")
-            task.ctx.close()
-        except Exception as e:     # the headline above is already measured: never lose the line to the non-headline leg
-            variant = dict(name="gemm_bf16x3", NOT_THE_HEADLINE=True, value=None, error=f"{type(e).__name__}: {e}"[:300])
+        # (one GPU only: a multi-rank job reports its headline and nothing else)
+        task.ctx.synchronize(); task.close(); task = None      # the headline context goes first: the child has the GPU to itself
+        torch.cuda.empty_cache()
+        variant = run_leg_in_child("variant", args, 120 + 3.0 * (args.steps + args.warmup))
+        variant.setdefault("name", "gemm_bf16x3"); variant.setdefault("NOT_THE_HEADLINE", True)
+        train_loop = run_leg_in_child("train_loop", args, 180 + 3.0 * args.loop_iterations)
+        train_loop.setdefault("name", "train_loop")
+        if train_loop.get("value"):
+            train_loop["vs_headline"] = round(train_loop["value"] / value, 4)
     if forced is not None:      # third leg: the actor's gradient slice all-reduced on a second stream under the critic's tail
         forced.update(ms_per_step_forced_allreduce=round(elapsed / args.steps * 1e3, 2), allreduce_ms_per_iteration=round(allreduce_ms, 3),
                       allreduce_calls_per_iteration=allreduce_calls)
@@ -392,6 +466,8 @@ def main():
         "allreduce_ms_per_iteration": round(allreduce_ms, 3), "allreduce_calls_per_iteration": allreduce_calls,
         "hbm_whole_path": hbm,
         "variant_gemm_bf16x3": variant,
+        # the number launch() delivers: the same workload through the reference-shaped training loop (logging + validation + checkpoints)
+        "train_loop": train_loop,
     }
     print(json.dumps(out), flush=True)
     if world > 1 or args.force_collective:

@@ -140,10 +140,6 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
     KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_side[n], hipEventDisableTiming));
   }
   for (int n = 0; n < 2; ++n) KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_dx[n], hipEventDisableTiming));
-  // experiment only (KBJ_DX_LANE=1): own lanes for the input-gradient chunks of the chunk-gated backward. Creating them costs 0.7 ms per
-  // minibatch even when nothing runs on them (6.45 -> 7.17 ms): the context's four lanes no longer get hardware queues of their own
-  if (getenv("KBJ_DX_LANE") && atoi(getenv("KBJ_DX_LANE")) != 0)
-    for (int n = 0; n < 2; ++n) KBJ_TRY(hipStreamCreateWithPriority(&ctx->dxs[n], hipStreamNonBlocking, n == 1 ? prio_greatest : 0));
   for (int k = 0; k < 32; ++k) KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_pool[k], hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_actor_grad, hipEventDisableTiming));
   KBJ_TRY(hipEventCreateWithFlags(&ctx->ev_small, hipEventDisableTiming));
@@ -181,7 +177,6 @@ int kbj_destroy(kbj_ctx* ctx) {
   for (int n = 0; n < 2; ++n) {
     if (ctx->side[n]) hipStreamDestroy(ctx->side[n]);
     if (ctx->ev_side[n]) hipEventDestroy(ctx->ev_side[n]);
-    if (ctx->dxs[n]) hipStreamDestroy(ctx->dxs[n]);
     if (ctx->ev_dx[n]) hipEventDestroy(ctx->ev_dx[n]);
   }
   delete ctx;
@@ -212,7 +207,10 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
       "kbj::gemm_f32_kernel<2, 1, true, true, 2, 4>",   "kbj::gemm_f32_kernel<1, 1, false, false, 2, 2>", "kbj::gemm_f32_kernel<1, 1, false, true, 2, 2>",
       "kbj::gemm_f32_kernel<1, 1, true, false, 2, 2>",  "kbj::gemm_f32_kernel<1, 1, true, true, 2, 2>",   "kbj::lstm_seq_fwd_kernel", "kbj::lstm_seq_bwd_kernel", "env_step_kernel", "kbj::lstm_seq_fwd_kernel",
       "kbj::lstm_seq_fwd_kernel", "kbj::lstm_step_kernel", "kbj::lstm_step_kernel",
-      "kbj::gemm_x3_kernel<false, false>", "kbj::gemm_x3_kernel<false, true>", "kbj::gemm_x3_kernel<true, false>", "kbj::gemm_x3_kernel<true, true>"};
+      // gemm_x3_kernel<TM, A_KC, B_KC, GEN> as rocprofv3 prints the instantiations the launcher uses (kbj_ctx.h kbj_kind_gemm_x3)
+      "kbj::gemm_x3_kernel<2, false, false, false>", "kbj::gemm_x3_kernel<2, false, true, false>", "kbj::gemm_x3_kernel<2, true, false, false>",
+      "kbj::gemm_x3_kernel<2, true, true, false>", "kbj::gemm_x3_kernel<2, true, true, true>", "kbj::gemm_x3_kernel<1, true, true, false>",
+      "kbj::gemm_x3_kernel<1, true, true, true>"};
   for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
     kbj_kernel_stat& st = ctx->kstats[k];
     const int uw = 2;   // wavefront pairs per recurrence workgroup (kbj_nn.hip SEQ_UW), as rocprofv3 prints the template argument

@@ -9,7 +9,13 @@
 // per-launch HIP-event records of the MFMA kernels while kbj_profile_begin/end is active (bench.py roofline)
 struct KbjKernelRec { int kind; double flops; hipEvent_t a, b; };
 enum { KBJ_KIND_GEMM = 0 /* +4 small tile, +2 A k-contiguous, +1 B k-contiguous */, KBJ_KIND_SEQ_FWD = 8, KBJ_KIND_SEQ_BWD = 9, KBJ_KIND_ENV_STEP = 10, KBJ_KIND_SEQ_FWD_FUSED = 11, KBJ_KIND_SEQ_FWD_OBS = 12, KBJ_KIND_LSTM_STEP = 13, KBJ_KIND_LSTM_STEP_OBS = 14,
-       KBJ_KIND_GEMM_X3 = 15 /* +2 A k-contiguous, +1 B k-contiguous: gemm_x3_kernel (kbj_config.gemm_bf16x3) */, KBJ_KIND_COUNT = 19 };
+       // gemm_x3_kernel<TM, A_KC, B_KC, GEN> (kbj_config.gemm_bf16x3), one kind per instantiation the launcher uses: 15..18 = <2, A_KC, B_KC, false>
+       // (+2 A k-contiguous, +1 B k-contiguous), 19 = <2, true, true, true>, 20 = <1, true, true, false>, 21 = <1, true, true, true>
+       KBJ_KIND_GEMM_X3 = 15, KBJ_KIND_GEMM_X3_GEN = 19, KBJ_KIND_GEMM_X3_SMALL = 20, KBJ_KIND_GEMM_X3_SMALL_GEN = 21, KBJ_KIND_COUNT = 22 };
+inline int kbj_kind_gemm_x3(int tm, bool a_kc, bool b_kc, bool gen) {
+  if (tm == 2) return gen ? KBJ_KIND_GEMM_X3_GEN : KBJ_KIND_GEMM_X3 + (a_kc ? 2 : 0) + (b_kc ? 1 : 0);
+  return gen ? KBJ_KIND_GEMM_X3_SMALL_GEN : KBJ_KIND_GEMM_X3_SMALL;
+}
 
 struct kbj_ctx {
   int device = 0;
@@ -17,8 +23,7 @@ struct kbj_ctx {
   hipStream_t stream2 = nullptr;   // second lane for the critic network inside kbj_ppo_grad
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t side[2] = {nullptr, nullptr};   // per-net side lanes for weight-gradient GEMMs
-  hipStream_t dxs[2] = {nullptr, nullptr};    // per-net lanes of the input-gradient GEMM chunks that run under the backward recurrence (chunk-gated schedule)
-  hipEvent_t ev_dx[2] = {nullptr, nullptr};
+  hipEvent_t ev_dx[2] = {nullptr, nullptr};   // per net lane: the layer's input-gradient GEMM is done (the weight-gradient lanes start behind both)
   hipEvent_t ev_side[2] = {nullptr, nullptr};
   hipEvent_t ev_obs = nullptr;                // the critic's gathered observation rows are in place (side lane, ppo_forward_nets)
   hipEvent_t ev_prefetch = nullptr;           // kbj_ppo_prefetch: the next minibatch's head gathers are done

@@ -222,7 +222,9 @@ __global__ void init_reward_carry_kernel(float* carry, int N) {
 
 }  // namespace
 
-// one control step of the envs [env0, env0 + count) on stream s; row pointers are those of env 0 (kbj_rollout pipelines two halves)
+void kbj_nn_drop_prefetch(kbj_ctx* ctx);   // kbj_nn.hip: a pending next-minibatch hint dies with the trajectory contents it was made from
+
+// one control step of the envs [env0, env0 + count) on stream s; row pointers are those of env 0
 int kbj_env_step_range(kbj_ctx* ctx, hipStream_t s, int env0, int count, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d,
                        float* aux_next_d) {
   KbjKernelTimer timer(s, KBJ_KIND_ENV_STEP, 0.0);
@@ -240,6 +242,7 @@ int kbj_env_reset_all(kbj_ctx* ctx, uint32_t seed, float* actor0_d, float* criti
   ctx->seed = seed;
   int N = ctx->cfg_h.num_envs;
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  kbj_nn_drop_prefetch(ctx);
   hipLaunchKernelGGL(init_reward_carry_kernel, dim3((N + 255) / 256), dim3(256), 0, ctx->stream, ctx->rcarry_d, N);
   KBJ_CHECK_LAUNCH(ctx, "init_reward_carry_kernel");
   hipLaunchKernelGGL(env_reset_kernel, dim3(N), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->mc_d, (const PhysConst*)ctx->pc_d, seed, ctx->ep_d, ctx->es_d, actor0_d,
@@ -252,12 +255,14 @@ int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* act
   if (!ctx) return kbj_fail(nullptr, "kbj_env_step: null ctx");
   if (!action_d || !aux_t_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_step: null pointer");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  kbj_nn_drop_prefetch(ctx);
   return kbj_env_step_range(ctx, ctx->stream, 0, ctx->cfg_h.num_envs, action_d, aux_t_d, actor_next_d, critic_next_d, aux_next_d);
 }
 
 int kbj_env_reset_where(kbj_ctx* ctx, const float* mask_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {
   if (!ctx || !mask_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_reset_where: null argument");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  kbj_nn_drop_prefetch(ctx);
   hipLaunchKernelGGL(env_reset_where_kernel, dim3(ctx->cfg_h.num_envs), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->mc_d, (const PhysConst*)ctx->pc_d, ctx->seed, ctx->ep_d, ctx->es_d,
                      mask_d, actor_next_d, critic_next_d, aux_next_d);
   KBJ_CHECK_LAUNCH(ctx, "env_reset_where_kernel");
@@ -267,6 +272,7 @@ int kbj_env_reset_where(kbj_ctx* ctx, const float* mask_d, float* actor_next_d, 
 int kbj_env_set_command(kbj_ctx* ctx, const float* mask_d, const float* cmd_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {
   if (!ctx || !cmd_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_set_command: null argument");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  kbj_nn_drop_prefetch(ctx);
   const int N = ctx->cfg_h.num_envs, n = N * KBJ_NCMD;
   hipLaunchKernelGGL(env_set_command_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, N, KBJ_LD_OF(KBJ_NOBS_ACTOR + ctx->cfg_h.extra_obs_actor),
                      KBJ_LD_OF(KBJ_NOBS_CRITIC + ctx->cfg_h.extra_obs_critic), ctx->es_d, mask_d, cmd_d, actor_next_d, critic_next_d, aux_next_d);
@@ -314,6 +320,7 @@ int kbj_rewards(kbj_ctx* ctx, const float* aux_d, int T, float* reward_d, float*
   if (!ctx) return kbj_fail(nullptr, "kbj_rewards: null ctx");
   if (!aux_d || !reward_d || T <= 0) return kbj_fail(ctx, "kbj_rewards: bad arguments");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  kbj_nn_drop_prefetch(ctx);
   int N = ctx->cfg_h.num_envs;
   hipLaunchKernelGGL(rewards_kernel, dim3((N + 63) / 64), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, aux_d, T, N, ctx->rcarry_d,
                      reward_d, comps_d);

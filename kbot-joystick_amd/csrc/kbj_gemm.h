@@ -496,7 +496,7 @@ template <int TM, bool A_KC, bool B_KC, bool GEN> inline void gemm_x3_launch_til
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x3_kernel<TM, A_KC, B_KC, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
   (void)attr;
   const long it = (long)((g.M + BM - 1) / BM) * ((g.N + BM - 1) / BM) * sk;
-  KbjKernelTimer timer(s, KBJ_KIND_GEMM_X3 + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);
+  KbjKernelTimer timer(s, kbj_kind_gemm_x3(TM, A_KC, B_KC, GEN), 2.0 * g.M * g.N * g.K);
   hipLaunchKernelGGL((gemm_x3_kernel<TM, A_KC, B_KC, GEN>), dim3((unsigned)((it + 7) / 8 * 8)), dim3(256), bytes, s, g);
 }
 

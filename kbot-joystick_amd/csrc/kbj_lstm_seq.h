@@ -77,13 +77,6 @@ struct SeqBwdArgs {
   unsigned* err;
   int T, B;
   float* db;             // optional [4H]: bias gradient accumulated with atomics (column sums of dG)
-  // chunk-gated schedule: after its hand-off of step t = c * chunk_steps (the last step of time chunk c, the recurrence runs downwards)
-  // every workgroup adds 1 to progress[c]; once the count reaches the grid size the chunk's dG rows [c * chunk_steps, ...) are complete
-  // and drained, and the GEMMs that consume them (seq_gate_kernel in front of them on their own lanes) start while the recurrence goes on
-  unsigned* progress = nullptr;
-  int chunk_steps = 0;
-  unsigned* entered = nullptr;   // optional: every workgroup adds 1 on entry; a gate kernel on another lane (seq_gate_kernel) lets that lane's GEMMs
-                                 // start only once the whole grid is resident (kbj_nn.hip: KBJ_DW_GATE)
   float* db_part = nullptr;   // deterministic mode: [row groups][4H] per-row-group column sums instead (added to db in order by reduce_rows_kernel)
   unsigned spin_limit = SEQ_SPIN_LIMIT;
   long long* stamps = nullptr;   // optional [T][10] shader-clock stamps of workgroup 0 (diagnostics)
@@ -399,7 +392,6 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const SeqBwdArgs a) {
   const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
-  if (a.entered && tid == 0) __hip_atomic_fetch_add(a.entered, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x] = wall_clock64();   // per-workgroup entry / loop start / exit
   constexpr int KW = H / 4;        // k range of one wave inside a gate chunk
   constexpr int KS = KW / 4;       // k-steps per (wave, gate chunk)
@@ -504,7 +496,6 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const SeqBwdArgs a) {
     }
     SEQ_BSTAMP(7);
     seq_publish(a.counters + rg * NUG + ug, (unsigned)(T - t));
-    if (a.progress && tid == 0 && t % a.chunk_steps == 0) __hip_atomic_fetch_add(a.progress + t / a.chunk_steps, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     SEQ_BSTAMP(8);
   }
   // bias gradient = column sums of dG over all rows and steps: reduce this workgroup's 32 rows in LDS, one atomic per column
@@ -532,19 +523,6 @@ template <int H, int UW>
 __global__ __launch_bounds__(256 * UW) __attribute__((amdgpu_num_vgpr(KBJ_SEQ_BWD_NUM_VGPR))) void lstm_seq_bwd_kernel(SeqBwdArgs a) { lstm_seq_bwd_body<H, UW>(a); }
 template <int H, int UW>
 __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_wide_kernel(SeqBwdArgs a) { lstm_seq_bwd_body<H, UW>(a); }
-
-// Gate in front of a consumer of a time chunk (one wavefront, one lane polling): returns once *ctr >= target, i.e. once every workgroup
-// of the recurrence has handed off the chunk's last step. It only ever waits for a kernel that was enqueued BEFORE it (deadlock-free
-// whatever streams share a hardware queue), the spin is bounded, and it gives up at once when a recurrence has already timed out.
-__global__ void seq_gate_kernel(const unsigned* ctr, unsigned target, unsigned* err, unsigned spin_limit) {
-  if (threadIdx.x != 0) return;
-  unsigned spins = 0;
-  while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    __builtin_amdgcn_s_sleep(32);
-    if (++spins > spin_limit) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-  }
-}
 
 // A fixed pause on a lane (one lane of one wavefront sleeping until `ticks` of the constant-rate clock have passed): it waits for NOTHING, so
 // it is safe under any serialisation of kernels. kbj_nn.hip puts it in front of the weight-gradient GEMMs of a layer so that the next

@@ -38,14 +38,11 @@ struct Sched {
   bool one_stream = false;         // KBJ_ONE_STREAM=1: the whole update on the caller's stream (no lanes)
   bool debug_sync = false;         // KBJ_DEBUG=1: kbj_ppo_grad synchronises and reports device-side errors at the call that caused them
   bool deterministic = false;      // fixed-order reductions instead of fp32 / fp64 atomics (bit-reproducible update)
-  int bwd_chunks = 1;              // KBJ_BWD_CHUNKS=n (2..10): weight-gradient GEMMs per time chunk UNDER the backward recurrence (chunk-gated schedule);
-                                   // measured flat against 1 = behind the whole recurrence (6.37-6.45 vs 6.43 ms per minibatch)
+  int dw_delay_us = 30;            // KBJ_DW_DELAY_US=n (0 = off): pause of the weight-gradient lanes behind both lanes' input gradients (kbj_ppo_grad)
   bool gemm_x3 = false;            // kbj_config.gemm_bf16x3 / KBJ_GEMM_X3=1: the GEMM launches that are eligible (the update's input gradients, weight-gradient
                                    // pairs and critic input projection, the rollout's [x | h] gate GEMMs) on the bf16 matrix cores through the exact three-way
                                    // operand split (kbj_gemm.h gemm_x3_kernel); not the default, not the headline
-  bool chunk_dx = false;           // KBJ_BWD_CHUNK_DX=1 (with bwd_chunks > 1): the input-gradient GEMM per chunk as well (slower: 6.64 / 6.83 ms at 2 / 4 chunks)
 };
-constexpr int MAX_BWD_CHUNKS = 10;
 bool env_flag(const char* name, bool dflt) { const char* v = getenv(name); return v ? atoi(v) != 0 : dflt; }
 
 constexpr int MAX_PAD_DESC = 2 * (4 + 3 * MAXD);
@@ -95,8 +92,6 @@ struct NnWs {
   const double* ext_adv_sums = nullptr;   // kbj_set_advantage_sums: (sum adv, sum adv^2, count) on the device, used instead of the minibatch's own statistics
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
-  unsigned* bwd_entered = nullptr;   // [layer][net] workgroups of a backward recurrence that have started (same allocation, same clear)
-  unsigned* bwd_progress = nullptr;  // [layer][net][MAX_BWD_CHUNKS] chunk completion counts of the backward recurrences (cleared with the hand-off counters)
   long long* seq_stamps = nullptr;   // diagnostics (KBJ_SEQ_STAMPS=1): per-step clock stamps of one workgroup
   long long* seq_bstamps = nullptr;  // same for a backward recurrence (KBJ_SEQ_BSTAMPS = 1 + net + 2 * layer)
   std::vector<void*> allocs;
@@ -256,6 +251,7 @@ constexpr int SEQ_UW = 2;
 constexpr int SEQ_FUSED_MAX_H = 256;
 constexpr int SEQ_MAX_H = 512;
 constexpr int SEQ_COUNTER_WORDS = 256;   // hand-off words per recurrence launch (one per workgroup): the grid of a launch may not exceed it
+constexpr int SEQ_COUNTER_TOTAL = 2 * MAXD * 4 * SEQ_COUNTER_WORDS;   // all launches of one call (forward + backward, MAXD layers, 4 nets): ONE clear
 // fault injection for the tests (KBJ_DEBUG_DROP_SEQ_WG = n at kbj_create): the next n forward-recurrence launches run with one
 // workgroup missing, so its partners' bounded spins expire and the timeout / fail-stop path is exercised on real hardware
 int g_seq_drop = 0;
@@ -418,6 +414,16 @@ int kbj_nn_check_errors(kbj_ctx* ctx) {
   return 0;
 }
 
+// A pending kbj_ppo_prefetch is tied to the CONTENTS of the trajectory and of the index array it was given: every entry point that writes
+// trajectory arrays (rollout, policy / env steps, GAE, rewards) calls this first - the stale gathers are ordered in front of the writer (they
+// only read the trajectory, but their workspace rows must not be consumed) and the marker is cleared, so the next kbj_ppo_grad gathers afresh.
+void kbj_nn_drop_prefetch(kbj_ctx* ctx) {
+  NnWs* w = ws_of(ctx);
+  if (!w || !w->prefetched_idx) return;
+  hipStreamWaitEvent(ctx->stream, ctx->ev_prefetch, 0);
+  w->prefetched_idx = nullptr; w->prefetched_traj = nullptr;
+}
+
 int kbj_nn_create(kbj_ctx* ctx) {
   NnWs* w = new NnWs();
   ctx->nn_ws = w;
@@ -506,9 +512,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
   for (int n = 0; n < w->nnets; ++n) if (dalloc(ctx, *w, &w->Zeff[n], 4 * H * w->net[n & 1].ld_obs)) return -1;
   for (int k = 0; k < 2; ++k) if (dalloc(ctx, *w, &w->WinP[k], H * w->net[k].ld_obs)) return -1;
   if (hipMemset(w->Weff, 0, (size_t)4 * H * w->net[0].ld_obs * sizeof(float)) != hipSuccess) return kbj_fail(ctx, "hipMemset Weff");
-  if (dalloc(ctx, *w, &w->seq_counters, 2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS + MAXD * 4)) return -1;
-  w->bwd_entered = w->seq_counters + 2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS;
-  w->bwd_progress = w->seq_counters + 2 * MAXD * 4 * SEQ_COUNTER_WORDS;   // same allocation: one clear covers both   // [phase: forward layer l = l, backward layer l = D + l][net][row group x unit group]
+  if (dalloc(ctx, *w, &w->seq_counters, SEQ_COUNTER_TOTAL)) return -1;   // [phase: forward layer l = l, backward layer l = D + l][net][row group x unit group]
   if (dalloc(ctx, *w, &w->seq_err, 4)) return -1;
   if (getenv("KBJ_SEQ_STAMPS")) { if (dalloc(ctx, *w, &w->seq_stamps, (size_t)T * 6)) return -1; }
   if (getenv("KBJ_SEQ_BSTAMPS")) { if (dalloc(ctx, *w, &w->seq_bstamps, (size_t)T * 10 + 768)) return -1; }
@@ -520,12 +524,9 @@ int kbj_nn_create(kbj_ctx* ctx) {
     sc.fused_critic_head = env_flag("KBJ_FUSED_CRITIC_HEAD", true); sc.rollout_step = env_flag("KBJ_ROLLOUT_STEP", true);
     sc.one_stream = env_flag("KBJ_ONE_STREAM", false); sc.debug_sync = env_flag("KBJ_DEBUG", false);
     sc.deterministic = c.deterministic != 0 || env_flag("KBJ_DETERMINISTIC", false);
+    if (getenv("KBJ_DW_DELAY_US")) sc.dw_delay_us = std::max(0, std::min(1000, atoi(getenv("KBJ_DW_DELAY_US"))));
     sc.gemm_x3 = (c.gemm_bf16x3 != 0 || env_flag("KBJ_GEMM_X3", false)) && !sc.deterministic;   // (the deterministic split-K slabs stay on the exact kernel)
-    sc.bwd_chunks = getenv("KBJ_BWD_CHUNKS") ? atoi(getenv("KBJ_BWD_CHUNKS")) : 1;
-    sc.chunk_dx = env_flag("KBJ_BWD_CHUNK_DX", false);
-    if (sc.bwd_chunks < 1 || sc.bwd_chunks > MAX_BWD_CHUNKS) return kbj_fail(ctx, "KBJ_BWD_CHUNKS must be in 1..10");
     if (H > (size_t)SEQ_FUSED_MAX_H) sc.fuse_ih = sc.fuse_obs = sc.rollout_step = false;   // wide layers (SEQ_FUSED_MAX_H above)
-    if (sc.one_stream) sc.bwd_chunks = 1;   // no lanes, nothing to run under the recurrence
     if (sc.deterministic) {
       for (int l = 0; l < 4; ++l) if (dalloc(ctx, *w, &w->detp[l], (size_t)DETP_ROWS * DETP_COLS)) return -1;
       if (dalloc(ctx, *w, &w->detd, 2 * 512)) return -1;
@@ -565,7 +566,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
                "counters hold %d per launch: lower batch_size", grid, SEQ_COUNTER_WORDS);
       return kbj_fail(ctx, msg);
     }
-    if (H > SEQ_FUSED_MAX_H && 2L * grid > slots) w->sched.one_stream = true, w->sched.bwd_chunks = 1;   // wide layers: one recurrence at a time
+    if (H > SEQ_FUSED_MAX_H && 2L * grid > slots) w->sched.one_stream = true;   // wide layers: one recurrence at a time
     if ((w->sched.one_stream ? 1L : 2L) * grid > slots) {
       snprintf(msg, sizeof(msg), "kbj_create: %s persistent LSTM launches need %ld resident workgroups, the device holds %ld "
                "(%d per CU x %d CUs): lower batch_size", w->sched.one_stream ? "the" : "two concurrent", (w->sched.one_stream ? 1L : 2L) * grid, slots, per_cu, cus);
@@ -810,6 +811,7 @@ int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_
     unpad_carry(ctx, ctx->stream, *carry);
     return rc;
   }
+  kbj_nn_drop_prefetch(ctx);   // action / logp / value may be trajectory rows
   KbjTimed timed(ctx, true);
   if (policy_nets(ctx, ctx->stream, params_d, 0, w.nnets, 0, w.N, actor_obs_d, critic_obs_d, carry, seed, step_index, argmax, action_d, logp_d, value_d, 0,
                   fold_actor_weights(ctx, ctx->stream, params_d))) return -1;
@@ -835,9 +837,6 @@ int kbj_carry_reset(kbj_ctx* ctx, kbj_carry* carry, const float* done_d, int don
   return 0;
 }
 
-// The rollout is a two-lane software pipeline over env halves: while the env kernel (VALU/latency bound, one wavefront per env)
-// steps one half, the matrix cores run the actor of the other half; the critic (and the mirror branches), which the env
-// never waits for, run on side lanes under the env kernel of their own half. Per-env results do not depend on the split.
 int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t seed, uint32_t first_step_index, kbj_traj* tr) {
   if (!ctx || !params_d || !carry || !tr) return kbj_fail(ctx, "kbj_rollout: null argument");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
@@ -862,6 +861,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
     return rc;
   }
   hipStream_t s = ctx->stream;
+  kbj_nn_drop_prefetch(ctx);
   size_t la = w.net[0].ld_obs, lc = w.net[1].ld_obs, lx = KBJ_AUX_SIZE;
   // observation row T of the previous rollout is row 0 of this one
   KBJ_HIP(ctx, hipMemcpyAsync(tr->actor_obs_d, tr->actor_obs_d + (size_t)T * N * la, N * la * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -878,51 +878,39 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
     KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_critic_mirror_hc_d, carry->critic_mirror_hc_d, hcb, hipMemcpyDeviceToDevice, s));
     KBJ_HIP(ctx, hipMemcpyAsync(tr->carry0_lpf_mirror_d, carry->lpf_mirror_d, (size_t)N * KBJ_NU * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
-  // KBJ_ROLLOUT_PIPELINE (read per call): 2 (default) = one lane for actor -> env -> carry reset, the critic (and mirror branches),
-  // which the env never waits for, on a side lane: its small kernels and GEMMs slip into the env kernel's ramp-up / tail
-  // (-8.5 ms per iteration); 1 = additionally two env halves on two lanes (no further gain: with 12 env wavefronts per CU no GEMM
-  // workgroup can be co-resident, the lanes only alternate); 0 = strictly serial on the caller's stream.
+  // The actor -> env step -> carry reset chain runs on the caller's stream; the critic (and the mirror branches), which the env never waits
+  // for, on a side lane: its small kernels and GEMMs slip into the env kernel's ramp-up / tail (-8.5 ms per iteration against the serial
+  // order). KBJ_ROLLOUT_PIPELINE=0 (read per call, diagnostics): strictly serial on the caller's stream. (A two-lane software pipeline over
+  // env halves existed until round 4: with 12 env wavefronts per CU no GEMM workgroup can be co-resident, the lanes only alternated - gone.)
   const char* pipe_env = getenv("KBJ_ROLLOUT_PIPELINE");
-  const int pipe_mode = pipe_env ? atoi(pipe_env) : 2;
-  const bool serial = pipe_mode == 0;
-  const int lanes = (pipe_mode == 1 && N >= 256 && N % 2 == 0) ? 2 : 1;
-  hipStream_t ls[2] = {ctx->stream, ctx->stream2};                      // actor + env of each half
-  hipStream_t cs[2] = {serial ? ctx->stream : ctx->side[0], serial ? ctx->stream : ctx->side[1]};   // critic + mirror branches of each half
+  const bool serial = pipe_env && atoi(pipe_env) == 0;
+  hipStream_t cs = serial ? s : ctx->side[0];                 // critic + mirror branches
   const float* weff = fold_actor_weights(ctx, s, params_d);   // once: the parameters are fixed for the whole rollout
-  KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
-  if (lanes == 2) KBJ_HIP(ctx, hipStreamWaitEvent(ls[1], ctx->ev_fork, 0));
-  if (!serial) for (int h = 0; h < lanes; ++h) KBJ_HIP(ctx, hipStreamWaitEvent(cs[h], ctx->ev_fork, 0));
-  const int cnt = N / lanes;
+  if (!serial) {
+    KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
+    KBJ_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_fork, 0));
+  }
   for (int t = 0; t < T; ++t) {
     const float* ao = tr->actor_obs_d + (size_t)t * N * la;
     const float* co = tr->critic_obs_d + (size_t)t * N * lc;
     float* aux_t = tr->aux_d + (size_t)t * N * lx;
     float* act = tr->action_d + (size_t)t * N * KBJ_NU;
-    for (int h = 0; h < lanes; ++h) {
-      const int n0 = h * cnt;
-      if (policy_nets(ctx, ls[h], params_d, 0, 1, n0, cnt, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
-      if (policy_nets(ctx, cs[h], params_d, 1, w.nnets, n0, cnt, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
-      int rc = kbj_env_step_range(ctx, ls[h], n0, cnt, act, aux_t, tr->actor_obs_d + (size_t)(t + 1) * N * la, tr->critic_obs_d + (size_t)(t + 1) * N * lc,
-                                  tr->aux_d + (size_t)(t + 1) * N * lx);
-      if (rc) return rc;
-      carry_reset_nets(ctx, ls[h], 0, 1, n0, cnt, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE, (t + 1) & 1);   // the planes step t + 1 reads
-      if (!serial) {   // the side lane needs this step's done flags and the next critic observation
-        KBJ_HIP(ctx, hipEventRecord(ctx->ev_side[h], ls[h]));
-        KBJ_HIP(ctx, hipStreamWaitEvent(cs[h], ctx->ev_side[h], 0));
-      }
-      carry_reset_nets(ctx, cs[h], 1, w.nnets, n0, cnt, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE, (t + 1) & 1);
+    if (policy_nets(ctx, s, params_d, 0, 1, 0, N, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
+    if (policy_nets(ctx, cs, params_d, 1, w.nnets, 0, N, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
+    int rc = kbj_env_step_range(ctx, s, 0, N, act, aux_t, tr->actor_obs_d + (size_t)(t + 1) * N * la, tr->critic_obs_d + (size_t)(t + 1) * N * lc,
+                                tr->aux_d + (size_t)(t + 1) * N * lx);
+    if (rc) return rc;
+    carry_reset_nets(ctx, s, 0, 1, 0, N, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE, (t + 1) & 1);   // the planes step t + 1 reads
+    if (!serial) {   // the side lane needs this step's done flags and the next critic observation
+      KBJ_HIP(ctx, hipEventRecord(ctx->ev_side[0], s));
+      KBJ_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_side[0], 0));
     }
+    carry_reset_nets(ctx, cs, 1, w.nnets, 0, N, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE, (t + 1) & 1);
   }
   KBJ_CHECK_LAUNCH(ctx, "kbj_rollout");
-  if (!serial) {   // join every lane back into the caller's stream
-    for (int h = 0; h < lanes; ++h) {
-      KBJ_HIP(ctx, hipEventRecord(ctx->ev_side[h], cs[h]));
-      KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_side[h], 0));
-    }
-    if (lanes == 2) {
-      KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ls[1]));
-      KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_join, 0));
-    }
+  if (!serial) {   // join the side lane back into the caller's stream
+    KBJ_HIP(ctx, hipEventRecord(ctx->ev_side[0], cs));
+    KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_side[0], 0));
   }
   if (w.sched.rollout_step && (T & 1) && carry_h_home(ctx, s, 0, w.nnets, carry)) return -1;   // an odd number of steps leaves the live h planes in the partners
   return kbj_rewards(ctx, tr->aux_d, T, tr->reward_d, tr->reward_comps_d);
@@ -932,6 +920,7 @@ int kbj_gae(kbj_ctx* ctx, const kbj_traj* tr, float* adv_d, float* target_d) {
   if (!ctx || !tr || !adv_d || !target_d) return kbj_fail(ctx, "kbj_gae: null argument");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   const kbj_config& c = ctx->cfg_h;
+  kbj_nn_drop_prefetch(ctx);
   hipLaunchKernelGGL(gae_kernel, g1(tr->N, 64), dim3(64), 0, ctx->stream, tr->value_d, tr->reward_d, tr->aux_d, tr->T, tr->N, c.gamma, c.lam, adv_d, target_d);
   KBJ_CHECK_LAUNCH(ctx, "gae_kernel");
   return 0;
@@ -982,11 +971,9 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
   hipStream_t s = ctx->stream;
   ns[0] = ctx->stream; ns[1] = sc.one_stream ? ctx->stream : ctx->stream2;
   // hand-off counters of all eight (sixteen with the mirror branches) recurrence launches of this call: one clear, ahead of both lanes
-  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, (2 * MAXD * 4 * SEQ_COUNTER_WORDS + MAXD * 4 * MAX_BWD_CHUNKS + MAXD * 4) * sizeof(unsigned), s));
+  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, SEQ_COUNTER_TOTAL * sizeof(unsigned), s));
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
-  // the gates of the dx lanes poll the chunk counters: never before this call's clear (the side lanes follow their net's lane later on)
-  for (int k = 0; k < 2; ++k) if (ctx->dxs[k]) KBJ_HIP(ctx, hipStreamWaitEvent(ctx->dxs[k], ctx->ev_fork, 0));
   // (first on the actor's lane, ahead of the gathers: the two small launches depend on the parameters only, and behind the gathers they
   // queue for CU slots behind the 800 workgroups of the critic's input projection - 87 us on the actor's chain instead of ~25)
   if (sc.fold_actor) {
@@ -1014,10 +1001,13 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
   // the trajectory and the indices only. kbj_ppo_prefetch has queued these gathers behind the end of the previous kbj_ppo_grad, on a
   // side lane, where they run under the optimizer step and the folded-weight preparation instead of between them and the first recurrence.
   GatherSmallArgs gs{tr->action_d, grad ? tr->logp_d : nullptr, grad ? tr->value_d : nullptr, adv_d, target_d, tr->aux_d, w.act, w.logp_old, w.val_old, w.adv, w.target, w.keep};
-  const bool prefetched = w.prefetched_idx == idx && w.prefetched_traj == tr && !sc.one_stream;
+  // A pending hint is ALWAYS waited for, matching or not: its gathers write the same workspace rows (observation copy, keep flags, start
+  // carries) from a side lane, so a call with other arguments must order its own gathers behind them before it overwrites them.
+  const bool pending = w.prefetched_idx != nullptr;
+  const bool prefetched = pending && w.prefetched_idx == idx && w.prefetched_traj == tr && !sc.one_stream;
   w.prefetched_idx = nullptr; w.prefetched_traj = nullptr;
-  if (prefetched) KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prefetch, 0));
-  else if (head_gathers(ctx, s, tr, idx)) return -1;
+  if (pending) KBJ_HIP(ctx, hipStreamWaitEvent(s, ctx->ev_prefetch, 0));
+  if (!prefetched && head_gathers(ctx, s, tr, idx)) return -1;
   {
     // Nothing on the forward path needs the rest: actions, old log-probs / values, advantages, targets, the advantage statistics and the
     // cleared accumulators (gradient, folded layer-0 products) are wanted at the loss, two recurrences later. They run on the actor's
@@ -1256,15 +1246,12 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     dh_above[n] = t.dHa; dx_out[n] = t.dHb;
   }
   const int nrg = (B + SEQ_ROWS - 1) / SEQ_ROWS;
-  // Chunk-gated schedule (Sched::bwd_chunks > 1, off by default). The backward recurrence of a layer stays ONE persistent launch, but it
-  // counts the completion of every time chunk (SeqBwdArgs::progress), and the GEMMs that consume the chunk's dG rows - the layer's weight
-  // gradients on the net's side lane, with Sched::chunk_dx also its input gradient - are launched per chunk behind a seq_gate_kernel:
-  // they run UNDER the rest of the recurrence instead of after it. Meant to fill the layer-1 backward phase (the only one with idle matrix
-  // cores and nothing else to run) and to shorten the GEMM-only tail behind layer 0 to the last chunk; measured flat, because a GEMM
-  // workgroup that shares a CU with a recurrence workgroup stretches the recurrence by what it gains. Chunk c = time
-  // steps [c * TC, (c + 1) * TC); the recurrence runs downwards, so chunks complete from the last one to chunk 0. A gate only waits for a
-  // kernel enqueued before it. (Own lanes for the input-gradient chunks - KBJ_DX_LANE=1 - cost 0.7 ms per minibatch by merely existing:
-  // two more streams change how HIP maps this context's lanes onto hardware queues.)
+  // INVARIANT of the schedule: no kernel waits for another LAUNCH. The only inter-workgroup waits are those of the persistent recurrences,
+  // inside one launch whose grid is resident by construction (kbj_nn_create). Everything else is ordered by stream events, so any
+  // serialisation of kernels (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL=3) runs the same schedule to the same results. (Round 3 / 4 carried
+  // chunk-gated variants - a one-wavefront gate kernel polling a recurrence's progress in front of the GEMMs that consume it, KBJ_BWD_CHUNKS /
+  // KBJ_DW_GATE: measured flat to 0.3 %, and dispatched alone under a serialising profiler the gate spins to its bound. They are gone,
+  // DESIGN.md section 10.)
   // the bias terms of layer 0 (db_0 is complete with the net's layer-0 recurrence; the read-modify-write of dW_ih0 must follow the folded product into it, on the same lane): db_in = W_ih0^T db_0, dW_ih0 += db_0 b_in^T
   // (X0 = obs W_in^T + b_in)
   auto fold_bias_terms = [&](int k, hipStream_t st) {
@@ -1275,63 +1262,37 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     hipLaunchKernelGGL(outer_acc_kernel, g1((size_t)4 * H * H), dim3(256), 0, st, grad_d + oa.w_ih[0], grad_d + oa.b[0], params_d + oa.b_in, 4 * H, H);
   };
   bool bias_done[2] = {false, false};
-  // KBJ_DW_AFTER_DX=0: a layer's weight-gradient GEMMs start beside its input-gradient GEMM instead of behind it. Behind is the default: the
-  // input gradient is on the net's critical chain (the next layer's recurrence reads it) and ran at 0.73 ms next to the low-priority weight
-  // gradients against 0.29 ms alone; the weight gradients lose nothing, they overlap the next layer's recurrence either way (368.6 -> 365.6 ms
-  // per iteration, three alternations on one box)
-  static const bool dw_after_dx = env_flag("KBJ_DW_AFTER_DX", true);
-  // KBJ_DW_GATE=1 (off by default): a layer's weight-gradient GEMMs are enqueued behind the NEXT layer's recurrence launches and wait
-  // (seq_gate_kernel on their side lane) until every workgroup of those recurrences is resident. Without it both become eligible in the same
-  // microsecond, GEMM workgroups (72 KB of LDS each, two per CU) take the CUs, and the recurrence - which advances at the pace of its last
-  // workgroup to enter - stands still for 0.2-0.7 ms (`[kbj seq_bwd stamps] last entry`); with it the recurrence's 256 workgroups are placed
-  // first (layer-0 backward recurrences 0.72-0.79 ms instead of 1.2-1.4 in the trace of the bf16 x3 line) and the GEMMs fill in around them.
-  // The end of the minibatch moves little - the work is conserved and a GEMM workgroup beside a recurrence workgroup gets a quarter of a CU:
-  // 362.9 / 365.0 -> 362.1 / 363.3 ms per iteration, bf16 x3 line 333.9 / 335.8 -> 330.0 / 329.4 (alternating runs on one box).
-  // NOT the default: a gate needs the kernel it waits for to run CONCURRENTLY with it. Under a profiler that serialises kernels
-  // (rocprofv3 --pmc) the gate is dispatched alone, spins to its bound and the call fails (fail-stop, but a failed profile run); the default
-  // schedule has no kernel that waits for another kernel.
-  static const bool dw_gate_env = env_flag("KBJ_DW_GATE", false);
-  // KBJ_DW_DELAY_US=n (default 30, 0 = off): the profiler-safe form of the same idea. The weight-gradient lanes wait (stream events only) until
-  // BOTH lanes' input gradients are done - i.e. until both next-layer recurrences are eligible and nothing new is being dispatched - then pause
-  // n microseconds (seq_delay_kernel: waits for nothing) and only then start: the recurrences' workgroups are placed in that window.
-  // 365.9 / 365.4 / 364.7 ms per iteration without, 363.0 / 362.0 / 363.8 with 20 us, 362.2 / 362.9 / 363.4 with 60 us, 362.4 / 361.6 / 362.7
-  // with the gate (alternating runs on one box).
-  static const int dw_delay_us = getenv("KBJ_DW_DELAY_US") ? atoi(getenv("KBJ_DW_DELAY_US")) : 30;
+  // A layer's weight-gradient GEMMs start BEHIND its input-gradient GEMM, not beside it: the input gradient is on the net's critical chain
+  // (the next layer's recurrence reads it) and ran at 0.73 ms next to the low-priority weight gradients against 0.29 ms alone; the weight
+  // gradients lose nothing, they overlap the next layer's recurrence either way (368.6 -> 365.6 ms per iteration, three alternations on one box).
+  // KBJ_DW_DELAY_US=n (default 30, 0 = off): the weight-gradient lanes additionally wait (stream events only) until BOTH lanes' input
+  // gradients are done - i.e. until both next-layer recurrences are eligible and nothing new is being dispatched - then pause n microseconds
+  // (seq_delay_kernel: waits for nothing) and only then start: the recurrences' workgroups are placed in that window. Without it both become
+  // eligible in the same microsecond, GEMM workgroups (72 KB of LDS each, two per CU) take the CUs, and the recurrence - which advances at the
+  // pace of its last workgroup to enter - stands still for 0.2-0.7 ms. 365.9 / 365.4 / 364.7 ms per iteration without, 363.0 / 362.0 / 363.8
+  // with 20 us, 362.2 / 362.9 / 363.4 with 60 us (alternating runs on one box).
+  const int dw_delay_us = sc.dw_delay_us;
   static const unsigned wall_khz = [&] { int k = 0; hipDeviceGetAttribute(&k, hipDeviceAttributeWallClockRate, ctx->device); return (unsigned)(k > 0 ? k : 100000); }();
   struct PendingDW { int n, l; };
   std::vector<PendingDW> pending_dw;
-  const int nch_req = (sc.bwd_chunks > 1 && T >= 2 * sc.bwd_chunks) ? sc.bwd_chunks : 1;
-  const int TC = (T + nch_req - 1) / nch_req;
-  const int nch = (T + TC - 1) / TC;      // chunks that hold at least one step (T = 9 in 4 chunks of 3 steps: 3 chunks)
-  const unsigned seq_grid = (unsigned)(nrg * (H / (SEQ_UNITS * SEQ_UW)));
-  auto gate = [&](hipStream_t st, const unsigned* ctr) { hipLaunchKernelGGL(seq_gate_kernel, dim3(1), dim3(64), 0, st, ctr, seq_grid, w.seq_err, g_seq_spin_limit); };
-  auto dx_of = [&](int n) { return ctx->dxs[n & 1] ? ctx->dxs[n & 1] : side_of(n); };   // without dx lanes: on the side lane, ahead of the chunk's weight gradients
-  const bool dw_gate = dw_gate_env && dw_after_dx && nch == 1 && !one_stream;
-  const bool dw_delay = !dw_gate && dw_delay_us > 0 && dw_after_dx && nch == 1 && !one_stream;
+  const bool dw_delay = dw_delay_us > 0 && !one_stream;
   for (int l = D - 1; l >= 0; --l) {
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
       SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + SEQ_COUNTER_WORDS * (4 * (D + l) + n), w.seq_err, T, B, grad_d + o.b[l]};
       ba.db_part = det_partials(ctx, ns[n & 1]);   // deterministic mode: per-row-group bias sums, added in order below
-      if (nch > 1) { ba.progress = w.bwd_progress + (size_t)(4 * l + n) * MAX_BWD_CHUNKS; ba.chunk_steps = TC; }
       if (w.seq_bstamps && bstamp_sel == 1 + n + 2 * l) ba.stamps = w.seq_bstamps;
-      if (dw_gate) ba.entered = w.bwd_entered + 4 * l + n;
       if (seq_bwd(ctx, ns[n & 1], H, ba)) return -1;
       if (ba.db_part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, ns[n & 1], ba.db_part, nrg, 4 * H, grad_d + o.b[l]);
     }
-    for (const PendingDW& p : pending_dw) {   // the layer above's weight gradients: behind this layer's recurrences (of the net and of its partner lane's net)
+    for (const PendingDW& p : pending_dw) {   // the layer above's weight gradients: behind both lanes' input gradients (recorded below, an iteration ago), then the pause
       const NetOff& o = w.net[p.n & 1];
       TrainBufs& t = w.tb[p.n];
       hipStream_t ws = side_of(p.n);
-      if (dw_gate) {
-        gate(ws, w.bwd_entered + 4 * l + p.n);
-        if ((p.n ^ 1) < w.nnets) gate(ws, w.bwd_entered + 4 * l + (p.n ^ 1));
-      } else {   // dw_delay: both lanes' input gradients (recorded below, an iteration ago), then the pause
-        hipStreamWaitEvent(ws, ctx->ev_dx[p.n & 1], 0);
-        if (w.nnets > 1) hipStreamWaitEvent(ws, ctx->ev_dx[(p.n & 1) ^ 1], 0);
-        hipLaunchKernelGGL(seq_delay_kernel, dim3(1), dim3(64), 0, ws, (unsigned)((unsigned long long)dw_delay_us * wall_khz / 1000u));
-      }
+      hipStreamWaitEvent(ws, ctx->ev_dx[p.n & 1], 0);
+      if (w.nnets > 1) hipStreamWaitEvent(ws, ctx->ev_dx[(p.n & 1) ^ 1], 0);
+      hipLaunchKernelGGL(seq_delay_kernel, dim3(1), dim3(64), 0, ws, (unsigned)((unsigned long long)dw_delay_us * wall_khz / 1000u));
       linear_bwd_weight2(ctx, ws, t.dGl[p.l], 4 * H, t.Hm[p.l], p.l == 0 ? t.X0 : t.Hout[p.l - 1], H, grad_d + o.w_hh[p.l], grad_d + o.w_ih[p.l], H, 4 * H, H, R);
     }
     pending_dw.clear();
@@ -1339,53 +1300,29 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
       hipStream_t s = ns[n & 1], ws = side_of(n);
-      const unsigned* prog = w.bwd_progress + (size_t)(4 * l + n) * MAX_BWD_CHUNKS;
       const bool folded = fold_actor && l == 0 && ((n & 1) == 0 || fold_critic);
       // The last thing a lane does - layer 0 of its net - needs no side lane: nothing is left on the net's lane for the weight
       // gradients to run beside, and a cross-lane hop costs 15-20 us each way (fork + join) in the minibatch's tail. (Not with mirror
       // branches: two nets per lane then read-modify-write the same dW_ih0 through their small products, which only the shared side
       // lane orders.)
-      const bool own_lane = l == 0 && nch == 1 && !w.mirror && folded;
-      if (own_lane) ws = s;
-      else if (nch == 1 && !(dw_after_dx && !folded)) fork_side(n);     // the side lane starts behind the whole recurrence
-      // (the dx and side lanes need no event from the net's lane here: a gate passes only once this layer's recurrence runs, and that
-      // recurrence started behind everything the lane did before - the previous readers of the dX buffer included)
-      for (int c = nch - 1; c >= 0; --c) {
-        const int t0 = c * TC, t1 = std::min(T, t0 + TC);
-        const size_t r0 = (size_t)t0 * B;
-        const int Rc = (t1 - t0) * B;
-        const float* dG = t.dGl[l] + r0 * 4 * H;
-        if (nch > 1) gate(ws, prog + c);
-        if (folded) {
-          // layer 0 backwards through the (activation-free) input projection without dX0: dW_hh0 += dG0^T Hm and Z = dG0^T obs in
-          // one launch (per chunk); two small products then carry Z back to the stored parameters (below, behind the last chunk)
-          float* Z = w.Zeff[n];
-          const int ts = H % 128 == 0 ? 128 : 64;   // the column split (n1 = H) must fall on a tile boundary
-          int sk = std::max(2, std::min(g_splitk_wgs / ((4 * H / ts) * (H / ts + (o.nin + ts - 1) / ts)), (Rc + 255) / 256));
-          GemmArgs g{dG, t.Hm[0] + r0 * H, grad_d + o.w_hh[0], nullptr, 4 * H, H + o.nin, Rc, 4 * H, H, H, 1, sk, nullptr};
-          g.B2 = t.obs + r0 * o.ld_obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = o.ld_obs;
-          g.skws = sk_workspace(ctx, ws, (size_t)sk * 4 * H * (H + o.nin));
-          g.x3 = g_gemm_x3;
-          gemm_launch<false, false>(ws, g, ts == 128 ? 1 : 0);
-          continue;
-        }
-        if (nch > 1 && sc.chunk_dx) {
-          if (dx_of(n) != ws) gate(dx_of(n), prog + c);
-          linear_bwd_input(dx_of(n), dG, 4 * H, params_d + o.w_ih[l], H, dx_out[n] + r0 * H, H, Rc, H, 4 * H, 0);
-        } else if (c == nch - 1) {   // the input gradient as ONE product on the net's own lane, behind the recurrence (it is the next layer's input)
-          linear_bwd_input(s, t.dGl[l], 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
-          if (dw_delay && l > 0 && !own_lane) hipEventRecord(ctx->ev_dx[n & 1], s);   // (the side lane picks it up behind the next layer's recurrence launches)
-          else if (dw_after_dx && nch == 1 && !own_lane) fork_side(n);   // the weight gradients start behind the input gradient, not beside it
-        }
-        if ((dw_gate || dw_delay) && l > 0 && !own_lane) pending_dw.push_back(PendingDW{n, l});   // enqueued behind the next layer's recurrence launches (above)
-        else linear_bwd_weight2(ctx, ws, dG, 4 * H, t.Hm[l] + r0 * H, (l == 0 ? t.X0 : t.Hout[l - 1]) + r0 * H, H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, Rc);
-      }
+      const bool own_lane = l == 0 && !w.mirror && folded;
       if (folded) {
+        if (own_lane) ws = s;
+        else fork_side(n);     // the side lane starts behind the whole recurrence
+        // layer 0 backwards through the (activation-free) input projection without dX0: dW_hh0 += dG0^T Hm and Z = dG0^T obs in
+        // one launch; two small products then carry Z back to the stored parameters
+        float* Z = w.Zeff[n];
+        const int ts = H % 128 == 0 ? 128 : 64;   // the column split (n1 = H) must fall on a tile boundary
+        int sk = std::max(2, std::min(g_splitk_wgs / ((4 * H / ts) * (H / ts + (o.nin + ts - 1) / ts)), (R + 255) / 256));
+        GemmArgs g{t.dGl[0], t.Hm[0], grad_d + o.w_hh[0], nullptr, 4 * H, H + o.nin, R, 4 * H, H, H, 1, sk, nullptr};
+        g.B2 = t.obs; g.C2 = Z; g.n1 = H; g.ldb2 = o.ld_obs; g.ldc2 = o.ld_obs;
+        g.skws = sk_workspace(ctx, ws, (size_t)sk * 4 * H * (H + o.nin));
+        g.x3 = g_gemm_x3;
+        gemm_launch<false, false>(ws, g, ts == 128 ? 1 : 0);
         // dW_in += W_ih0^T Z, dW_ih0 += Z W_in^T (the bias terms follow from db_0 at the end)
         // (a 4H-deep contraction on a handful of output tiles: split over k so that it is a short kernel, not a 130 us tail on 32 workgroups)
-        float* Z = w.Zeff[n];
         GemmArgs g1a{params_d + o.w_ih[0], Z, grad_d + o.w_in, nullptr, H, o.nin, 4 * H, H, o.ld_obs, o.nin, 1, g_fold_sk, nullptr};
-        g1a.skws = sk_workspace(ctx, ws, (size_t)g_fold_sk * H * o.nin);   // (same lane, stream-ordered behind the launches above: the slab is free again)
+        g1a.skws = sk_workspace(ctx, ws, (size_t)g_fold_sk * H * o.nin);   // (same lane, stream-ordered behind the launch above: the slab is free again)
         gemm_launch<false, false>(ws, g1a);
         GemmArgs g2a{Z, params_d + o.w_in, grad_d + o.w_ih[0], nullptr, 4 * H, H, o.nin, o.ld_obs, o.nin, H, 1, 1, nullptr};
         gemm_launch<true, true>(ws, g2a);
@@ -1393,8 +1330,14 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
         if (own_lane && n < 2) { fold_bias_terms(n, ws); bias_done[n] = true; }   // right here, on the net's own lane: not behind the side lane's join at the end
         continue;
       }
-      if (nch > 1 && sc.chunk_dx) {   // the next layer's recurrence (and the input-projection gradient) read the whole dX: the net's lane waits for its dx lane
-        hipEventRecord(ctx->ev_dx[n & 1], dx_of(n)); hipStreamWaitEvent(s, ctx->ev_dx[n & 1], 0);
+      // the input gradient as ONE product on the net's own lane, behind the recurrence (it is the next layer's input)
+      linear_bwd_input(s, t.dGl[l], 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
+      if (dw_delay && l > 0) {   // the side lane picks the weight gradients up behind the next layer's recurrence launches (above)
+        hipEventRecord(ctx->ev_dx[n & 1], s);
+        pending_dw.push_back(PendingDW{n, l});
+      } else {
+        fork_side(n);   // the weight gradients start behind the input gradient
+        linear_bwd_weight2(ctx, ws, t.dGl[l], 4 * H, t.Hm[l], l == 0 ? t.X0 : t.Hout[l - 1], H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
       }
       std::swap(dh_above[n], dx_out[n]);
     }

@@ -81,16 +81,19 @@ def _add(tar: tarfile.TarFile, name: str, data: bytes):
 
 
 def save_ckpt(path: str, params: np.ndarray, opt_m: np.ndarray, opt_v: np.ndarray, opt_count: int, hidden_size: int, depth: int,
-              state: dict, config: dict, extras: Optional[Dict[str, np.ndarray]] = None, schedule_count: Optional[int] = None, extra_obs=(0, 0)) -> None:
+              state: dict, config: dict, extras: Optional[Dict[str, np.ndarray]] = None, schedule_count: Optional[int] = None, extra_obs=(0, 0),
+              compresslevel: int = 1) -> None:
     """Write `ckpt.bin`. `extras` (name -> array) are this build's resume payload (kbj_* members). `schedule_count`: with a learning-rate
     schedule (train.py:1067-1077, either branch) optax's state tree ends in a ScaleByScheduleState(count) leaf - (count, mu.., nu.., count);
-    pass the optimizer-step count to write that trailing leaf so that the reference's optimizer tree has as many leaves as the file."""
+    pass the optimizer-step count to write that trailing leaf so that the reference's optimizer tree has as many leaves as the file.
+    `compresslevel`: gzip level of the container (any level reads back the same). The payload is ~150 MB of fp32 at 8192 envs, which deflate
+    barely shrinks: level 9 (tarfile's default) costs 6-10 s per save, level 1 about a second - and a training loop saves every minute."""
     model = [a for _, a in split_leaves(np.asarray(params), hidden_size, depth, extra_obs)]
     mu = [a for _, a in split_leaves(np.asarray(opt_m), hidden_size, depth, extra_obs)]
     nu = [a for _, a in split_leaves(np.asarray(opt_v), hidden_size, depth, extra_obs)]
     import os
     tmp = path + ".tmp"        # never leave a truncated ckpt.bin behind: write beside it, flush to disk, then rename over it
-    with open(tmp, "wb") as fh, tarfile.open(fileobj=fh, mode="w:gz") as tar:
+    with open(tmp, "wb") as fh, tarfile.open(fileobj=fh, mode="w:gz", compresslevel=compresslevel) as tar:
         _add(tar, "model_0", _npy_blobs(model))
         tail = [] if schedule_count is None else [np.asarray(schedule_count, np.int32)]
         _add(tar, "opt_state_0", _npy_blobs([np.asarray(opt_count, np.int32)] + mu + nu + tail))

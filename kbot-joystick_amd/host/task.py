@@ -527,9 +527,13 @@ class HumanoidWalkingTask:
         return v
 
     # ---- checkpointing in the xax `ckpt.bin` layout (host/ckpt.py; convert.sh:4, train.py:1788) ----
-    def save_checkpoint(self, path: str):
+    def save_checkpoint(self, path: str, background: bool = False):
         """Everything a bit-exact resume needs: parameters, optimizer, counters (upstream members) + env rows, reward carries, model
-        carries and the pending observation rows (kbj_* members)."""
+        carries and the pending observation rows (kbj_* members). The device arrays are copied to the host here, synchronously (a
+        consistent snapshot: ~150 MB at 8192 envs); with `background` the container (npy blobs, gzip, fsync, rename) is written by a
+        thread while training goes on - `wait_for_checkpoint()` joins it, and a new save waits for the previous one first. launch() saves
+        this way: written in line a save costs seconds of a loop that runs an iteration in a third of one."""
+        self.wait_for_checkpoint()
         T = self.T
         ep, es = self.ctx.env_get_state()
         extras = dict(ep=ep, es=es, rc=self.ctx.env_get_reward_carry(), actor_hc=self.carry.actor_hc.cpu().numpy(), critic_hc=self.carry.critic_hc.cpu().numpy(),
@@ -551,8 +555,31 @@ class HumanoidWalkingTask:
             cfg["fixed_command"] = list(cfg["fixed_command"])
         state = dict(num_steps=self.iteration, opt_step=self.opt_step, num_samples=self.iteration * self.N * self.T * self.world_size,
                      rank=self.rank, world_size=self.world_size)
-        ckpt_io.save_ckpt(path, self.params.cpu().numpy(), self.opt_m.cpu().numpy(), self.opt_v.cpu().numpy(), self.opt_step, self.H, self.kcfg.depth,
-                          state, cfg, extras, schedule_count=self.opt_step if self.config.use_lr_decay else None, extra_obs=self.extra_obs)
+        args = (path, self.params.cpu().numpy(), self.opt_m.cpu().numpy(), self.opt_v.cpu().numpy(), self.opt_step, self.H, self.kcfg.depth, state, cfg, extras)
+        kw = dict(schedule_count=self.opt_step if self.config.use_lr_decay else None, extra_obs=self.extra_obs)
+        if not background:
+            ckpt_io.save_ckpt(*args, **kw)
+            return
+        import threading
+
+        def write():
+            try:
+                ckpt_io.save_ckpt(*args, **kw)
+            except BaseException as e:      # surfaced by wait_for_checkpoint(): a failed save must not pass silently
+                self._save_error = e
+        self._save_error = None
+        self._save_thread = threading.Thread(target=write, name="kbj-ckpt-writer", daemon=False)
+        self._save_thread.start()
+
+    def wait_for_checkpoint(self):
+        """Join a background save_checkpoint(); re-raises what the writer raised."""
+        th = getattr(self, "_save_thread", None)
+        if th is not None:
+            th.join()
+            self._save_thread = None
+            err, self._save_error = getattr(self, "_save_error", None), None
+            if err is not None:
+                raise err
 
     def load_checkpoint(self, path: str):
         """Resume from save_checkpoint(): the next train_iteration() is bit-identical to the one the saved run would have made."""
@@ -673,6 +700,21 @@ class HumanoidWalkingTask:
             out[f"valid/reward/{name}"] = v
         return out
 
+    def close_validation(self):
+        """Drop the cached validation / view context (its env rows, workspace and lanes). validate() builds it again on demand. Measured on
+        MI355X (tools/validate_cliff.py, 8192 envs): keeping it costs the training iterations nothing (365.2 ms before the first validation,
+        366.1 / 365.3 / 364.8 ms after a validation, a second one and a view), re-creating it costs 0.15 s per validation - so it stays cached."""
+        v = getattr(self, "_valid", None)
+        if v is not None:
+            v[1].close()
+            self._valid = None
+
+    def close(self):
+        """Release the library contexts of this task (training and validation)."""
+        self.wait_for_checkpoint()
+        self.close_validation()
+        self.ctx.close()
+
     def view(self, path: Optional[str] = None, num_envs: int = 4, seconds: Optional[float] = None, seed_offset: int = 7919):
         """`run_mode=view` (reference README.md:66-70; train.py:1783-1784 render_track_body_id / render_length_seconds): the validation
         rollout above on `num_envs` envs with the generalised positions recorded after every control step (kbj_env_get_state), returned
@@ -737,9 +779,15 @@ class HumanoidWalkingTask:
         from .scalars import ScalarLogger
         task = cls(config)
         if getattr(config, "run_mode", "train") == "view":      # README.md:66-70 `python -m train run_mode=view`: no training, play the checkpointed policy
+            # the mode exists to look at the TRAINED policy: without the run directory's checkpoint it would record the freshly initialised
+            # one under a title that says "policy, iteration 0" - a plausible-looking, meaningless rollout. The reference's view mode loads the
+            # run's checkpoint as well (README.md:66-70).
             ck = os.path.join(run_dir, "checkpoints", "ckpt.bin") if run_dir is not None else None
-            if ck and os.path.exists(ck):
-                task.load_checkpoint(ck)
+            if ck is None or not os.path.exists(ck):
+                task.close()
+                raise FileNotFoundError(f"run_mode=view plays the checkpointed policy: {ck or '<run_dir>/checkpoints/ckpt.bin'} does not exist "
+                                        "(pass run_dir= of a finished or running training run; task.view() records the CURRENT parameters of a live task)")
+            task.load_checkpoint(ck)
             out = os.path.join(run_dir if run_dir is not None else ".", "view", f"rollout_{task.iteration}")
             rec = task.view(out)
             if not quiet:
@@ -751,6 +799,7 @@ class HumanoidWalkingTask:
             os.makedirs(os.path.join(run_dir, "checkpoints"), exist_ok=True)
             ckpt_path = os.path.join(run_dir, "checkpoints", "ckpt.bin")
         t0 = last_save = last_valid = time.time()
+        stats = dict(iterations=0, validations=0, validation_seconds=0.0, checkpoints=0, checkpoint_seconds=0.0)
         for it in range(num_iterations):
             task.train_iteration()
             now = time.time()
@@ -760,20 +809,31 @@ class HumanoidWalkingTask:
                 due = (config.valid_every_n_steps and (it + 1) % config.valid_every_n_steps == 0) or \
                       (config.valid_every_n_seconds and now - last_valid >= config.valid_every_n_seconds)
                 if due:
+                    tv = time.time()
                     sc.update(task.validate())
                     last_valid = now
+                    stats["validations"] += 1; stats["validation_seconds"] += time.time() - tv
                 if logger:
                     logger.log(task.iteration, sc)
                 if not quiet:
                     print(f"iter {it + 1}: reward/step {sc['train/reward_per_step']:.4f} loss {sc['train/loss']:.4f} value_loss {sc['train/value_loss']:.4f} "
                           f"entropy {sc['train/entropy']:.3f} clipfrac {sc['train/clip_fraction']:.3f} | {sc['perf/env_steps_per_s']:.3e} env-steps/s")
             if ckpt_path and config.save_every_n_seconds and now - last_save >= config.save_every_n_seconds:
-                task.save_checkpoint(ckpt_path)
+                tc = time.time()
+                task.save_checkpoint(ckpt_path, background=True)     # snapshot now, container written under the next iterations
                 last_save = now
+                stats["checkpoints"] += 1; stats["checkpoint_seconds"] += time.time() - tc
+            stats["iterations"] = it + 1
+        # the loop as its user sees it: training iterations + scalar logging + validations + periodic checkpoints, up to here
+        stats["loop_seconds"] = time.time() - t0
+        stats["env_steps_per_s"] = task.env_steps_per_iteration() * stats["iterations"] / max(stats["loop_seconds"], 1e-9)
         if ckpt_path:
-            task.save_checkpoint(ckpt_path)
+            tc = time.time()
+            task.save_checkpoint(ckpt_path)      # the final one in line: the file is complete when launch() returns
+            stats["final_checkpoint_seconds"] = time.time() - tc
         if logger:
             logger.close()
+        task.loop_stats = stats
         return task
 
 

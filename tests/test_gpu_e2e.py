@@ -141,8 +141,9 @@ def test_training_with_mirror_losses_runs():
 
 @pytest.mark.parametrize("mirror,T", [(False, 6), (True, 6), (False, 5)])
 def test_pipelined_rollout_equals_stepwise_calls(mirror, T):
-    """kbj_rollout runs two env halves as a software pipeline with the critic on side lanes; the trajectory must be bit-identical
-    to driving kbj_policy_step / kbj_env_step / kbj_carry_reset one full-batch call at a time. The rollout alternates the h planes of
+    """kbj_rollout runs the actor -> env chain on the caller's stream with the critic (and the mirror branches) on a side lane; the trajectory
+    must be bit-identical to the strictly serial order (KBJ_ROLLOUT_PIPELINE=0) and to driving kbj_policy_step / kbj_env_step /
+    kbj_carry_reset one full-batch call at a time. The rollout alternates the h planes of
     the carries between the caller's arrays and workspace partners per step (lstm_step_kernel cannot update h in place): an odd T
     ends on the partners and has to be copied home, an even one must not be."""
     import torch
@@ -154,8 +155,10 @@ def test_pipelined_rollout_equals_stepwise_calls(mirror, T):
     cfg = L.default_config(num_envs=N, batch_size=64, rollout_len=T, hidden_size=H, **kw)
     import os
     out = []
-    for mode in ("serial", "side lane (default)", "two lanes", "stepwise"):
-        os.environ["KBJ_ROLLOUT_PIPELINE"] = {"serial": "0", "side lane (default)": "2", "two lanes": "1", "stepwise": "0"}[mode]
+    for mode in ("serial", "side lane (default)", "stepwise"):
+        os.environ.pop("KBJ_ROLLOUT_PIPELINE", None)
+        if mode != "side lane (default)":
+            os.environ["KBJ_ROLLOUT_PIPELINE"] = "0"
         ctx = Bd.Context(m, cfg, 0, torch.cuda.current_stream().cuda_stream)
         params = torch.zeros(ctx.param_count(), device="cuda:0")
         ctx.init_params(9, params)
@@ -180,8 +183,8 @@ def test_pipelined_rollout_equals_stepwise_calls(mirror, T):
         out.append(got)
         ctx.close()
     os.environ.pop("KBJ_ROLLOUT_PIPELINE", None)
-    for a, b, c, d in zip(*out):
-        assert torch.equal(a, d) and torch.equal(b, d) and torch.equal(c, d)
+    for a, b, d in zip(*out):
+        assert torch.equal(a, d) and torch.equal(b, d)
 
 
 def test_reward_components_and_actor_export(tmp_path):

@@ -546,15 +546,77 @@ def test_run_mode_view_records_the_policy_rollout(tmp_path):
     assert np.array_equal(z["qpos"], rec.qpos)                                       # same parameters (from ckpt.bin), same seed: same rollout
     with pytest.raises(ValueError, match="run_mode"):
         HumanoidWalkingTask(_small(run_mode="render"))
-    t.ctx.close(); v.ctx.close()
+    # view mode plays the CHECKPOINTED policy: without the run's ckpt.bin it is an error, not a recording of the random initial policy
+    with pytest.raises(FileNotFoundError, match="ckpt.bin"):
+        HumanoidWalkingTask.launch(_small(render_length_seconds=1.0, run_mode="view"), run_dir=str(tmp_path / "no_such_run"), quiet=True)
+    with pytest.raises(FileNotFoundError, match="ckpt.bin"):
+        HumanoidWalkingTask.launch(_small(render_length_seconds=1.0, run_mode="view"), run_dir=None, quiet=True)
+    assert not os.path.exists(str(tmp_path / "no_such_run" / "view"))
+    t.close(); v.close()
+
+
+def test_launch_loop_with_validation_and_background_checkpoints(tmp_path):
+    """launch() as the reference's user runs it (train.py:1783-1790): scalar logging every iteration, a validation rollout every
+    valid_every_n_steps iterations, ckpt.bin rewritten every save_every_n_seconds - written by a background thread from a snapshot taken in
+    line. The loop's own statistics say what ran; the file on disk at the end is complete and resumes the run bit for bit."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    run = str(tmp_path / "run_1")
+    t = HumanoidWalkingTask.launch(_small(render_length_seconds=0.4, valid_every_n_steps=3, save_every_n_seconds=0.01), num_iterations=7, run_dir=run, quiet=True)
+    st = t.loop_stats
+    assert st["iterations"] == 7 and st["validations"] == 2 and st["checkpoints"] >= 5 and st["env_steps_per_s"] > 0
+    assert st["loop_seconds"] >= st["validation_seconds"] + st["checkpoint_seconds"]
+    assert getattr(t, "_save_thread", None) is None                    # every writer joined
+    ck = os.path.join(run, "checkpoints", "ckpt.bin")
+    assert os.path.exists(ck) and not os.path.exists(ck + ".tmp")
+    t2 = HumanoidWalkingTask.load_task(ck)
+    assert t2.iteration == 7 and torch.equal(t2.params, t.params) and torch.equal(t2.opt_m, t.opt_m)
+    t.rollout(); t2.rollout()
+    assert torch.equal(t.traj.action, t2.traj.action) and torch.equal(t.traj.aux, t2.traj.aux)
+    # a writer that fails is reported by the next wait, not swallowed
+    t.save_checkpoint(str(tmp_path / "no_such_dir" / "ckpt.bin"), background=True)
+    with pytest.raises((FileNotFoundError, OSError)):
+        t.wait_for_checkpoint()
+    t.close(); t2.close()
+
+
+def test_training_iterations_are_not_slower_after_a_validation():
+    """The validation / view rollouts run on a second library context (own env rows, workspace, lanes) that stays cached. Round 4's review
+    suspected that its idle streams slow every later training iteration (DESIGN.md section 10 had measured such a cliff for extra USER
+    streams); measured (tools/validate_cliff.py, profiles/r05a_validate_cliff.json) it does not. This test keeps it that way: at the
+    BASELINE env count, ms per iteration after validate() and after view() within 2 % of before."""
+    import time
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask, launch_config
+    task = HumanoidWalkingTask(launch_config(num_envs=8192, robot="kbot-headless", fixed_command=(0.5, 0.0, 0.0)))
+
+    def leg(k=5):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(k):
+            task.train_iteration()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / k
+    for _ in range(3):
+        task.train_iteration()
+    before = min(leg(), leg())
+    task.validate()
+    after_validate = min(leg(), leg())
+    task.view()
+    after_view = min(leg(), leg())
+    task.close_validation()
+    assert getattr(task, "_valid", None) is None
+    task.validate(num_envs=16, seconds=0.2)          # built again on demand
+    task.close()
+    assert after_validate <= 1.02 * before and after_view <= 1.02 * before, (before, after_validate, after_view)
 
 
 def test_default_schedule_survives_kernel_serialisation():
     """The default schedule under HIP's own serialisation (AMD_SERIALIZE_KERNEL=3: the host waits for every kernel before it enqueues the
     next - a common debugging setting) in a child process: the persistent recurrences, whose workgroups wait for each other INSIDE one
     launch, and the multi-lane update must run to the same kind of result. (This is host-order serialisation. `rocprofv3 --pmc` serialises at
-    the queues, in readiness order: there a kernel that waits for another kernel - the opt-in KBJ_DW_GATE=1 - can be dispatched first and
-    spin to its bound, which is why that switch is not the default; `tools/profile_all.sh` exercises that case.)"""
+    the queues, in readiness order: there a kernel that waits for ANOTHER LAUNCH could be dispatched first and spin to its bound. The schedule
+    contains no such kernel - the gate kernels of rounds 3 / 4 are gone, DESIGN.md section 2 states the invariant - and `tools/profile_all.sh`
+    runs the counter passes through it.)"""
     import subprocess, sys
     code = ("import sys; sys.path.insert(0, %r)\n"
             "import torch\n"
