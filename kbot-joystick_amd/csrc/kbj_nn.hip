@@ -9,6 +9,7 @@
 #include "kbj_gemm.h"
 #include "kbj_nn_kernels.h"
 #include "kbj_lstm_seq.h"
+#include "kbj_lstm_bwd16.h"
 
 using namespace kbj;
 
@@ -38,6 +39,8 @@ struct Sched {
   bool one_stream = false;         // KBJ_ONE_STREAM=1: the whole update on the caller's stream (no lanes)
   bool debug_sync = false;         // KBJ_DEBUG=1: kbj_ppo_grad synchronises and reports device-side errors at the call that caused them
   bool deterministic = false;      // fixed-order reductions instead of fp32 / fp64 atomics (bit-reproducible update)
+  bool bwd16 = true;               // KBJ_BWD16=0: backward recurrences on the 32-row x 32-unit form of rounds 1-4 (lstm_seq_bwd_kernel) instead of 16-row x 64-unit
+                                   // tiles with the partner-major contraction (kbj_lstm_bwd16.h: 620 instead of 907 us per launch in situ)
   int dw_delay_us = 30;            // KBJ_DW_DELAY_US=n (0 = off): pause of the weight-gradient lanes behind both lanes' input gradients (kbj_ppo_grad)
   bool gemm_x3 = false;            // kbj_config.gemm_bf16x3 / KBJ_GEMM_X3=1: the GEMM launches that are eligible (the update's input gradients, weight-gradient
                                    // pairs and critic input projection, the rollout's [x | h] gate GEMMs) on the bf16 matrix cores through the exact three-way
@@ -289,8 +292,26 @@ int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {   // a.c
   }
   return 0;
 }
-int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a) {   // a.counters: zeroed by the caller
-  KbjKernelTimer timer(st, KBJ_KIND_SEQ_BWD, 2.0 * a.T * a.B * 4.0 * H * H);
+template <int H> void seq_bwd16_launch(hipStream_t s, const SeqBwdArgs& a0) {
+  SeqBwdArgs a = a0;
+  a.spin_limit = g_seq_spin_limit;
+  const int grid = (H / BWD16_UNITS) * ((a.B + BWD16_ROWS - 1) / BWD16_ROWS);
+  hipLaunchKernelGGL((lstm_seq_bwd16_kernel<H>), dim3(grid), dim3(BWD16_NTH), 0, s, a);
+}
+// row groups of a backward-recurrence launch (deterministic mode: rows of its per-row-group bias partials)
+int seq_bwd_row_groups(int B, bool tiles16) { return tiles16 ? (B + BWD16_ROWS - 1) / BWD16_ROWS : (B + SEQ_ROWS - 1) / SEQ_ROWS; }
+int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a, bool tiles16 = false) {   // a.counters: zeroed by the caller
+  KbjKernelTimer timer(st, tiles16 ? KBJ_KIND_SEQ_BWD16 : KBJ_KIND_SEQ_BWD, 2.0 * a.T * a.B * 4.0 * H * H);
+  if (tiles16) {
+    switch (H) {
+      case 64: seq_bwd16_launch<64>(st, a); break;
+      case 128: seq_bwd16_launch<128>(st, a); break;
+      case 192: seq_bwd16_launch<192>(st, a); break;
+      case 256: seq_bwd16_launch<256>(st, a); break;
+      default: return kbj_fail(ctx, "lstm_seq_bwd16_kernel is built for hidden sizes 64, 128, 192, 256");
+    }
+    return 0;
+  }
   switch (H) {
     case 64: seq_bwd_launch<64, SEQ_UW>(st, a); break;
     case 128: seq_bwd_launch<128, SEQ_UW>(st, a); break;
@@ -316,6 +337,9 @@ template <int H> hipError_t seq_min_blocks_per_cu(int* out) {
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], lstm_seq_fwd_kernel<H, SEQ_UW, true, H>, threads, 0);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], lstm_seq_fwd_kernel<H, SEQ_UW, true, KBJ_LD_ACTOR>, threads, 0);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], lstm_seq_bwd_kernel<H, SEQ_UW>, threads, 0);
+    int n16 = 0;   // the 16 x 64-tile backward form: same grid size ((B / 16) x (H / 64) = (B / 32) x (H / 32)), same 512 threads
+    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, lstm_seq_bwd16_kernel<H>, BWD16_NTH, 0);
+    n[3] = std::min(n[3], n16);
   } else {
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], lstm_seq_bwd_wide_kernel<H, SEQ_UW>, threads, 0);
     n[0] = n[1] = n[2];
@@ -524,6 +548,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
     sc.fused_critic_head = env_flag("KBJ_FUSED_CRITIC_HEAD", true); sc.rollout_step = env_flag("KBJ_ROLLOUT_STEP", true);
     sc.one_stream = env_flag("KBJ_ONE_STREAM", false); sc.debug_sync = env_flag("KBJ_DEBUG", false);
     sc.deterministic = c.deterministic != 0 || env_flag("KBJ_DETERMINISTIC", false);
+    sc.bwd16 = env_flag("KBJ_BWD16", true) && H <= (size_t)SEQ_FUSED_MAX_H;   // wide layers keep lstm_seq_bwd_wide_kernel
     if (getenv("KBJ_DW_DELAY_US")) sc.dw_delay_us = std::max(0, std::min(1000, atoi(getenv("KBJ_DW_DELAY_US"))));
     sc.gemm_x3 = (c.gemm_bf16x3 != 0 || env_flag("KBJ_GEMM_X3", false)) && !sc.deterministic;   // (the deterministic split-K slabs stay on the exact kernel)
     if (H > (size_t)SEQ_FUSED_MAX_H) sc.fuse_ih = sc.fuse_obs = sc.rollout_step = false;   // wide layers (SEQ_FUSED_MAX_H above)
@@ -1245,7 +1270,6 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     colsum_acc(ctx, side_of(n), t.dOut, R, o.nout, 40, grad_d + o.b_out);
     dh_above[n] = t.dHa; dx_out[n] = t.dHb;
   }
-  const int nrg = (B + SEQ_ROWS - 1) / SEQ_ROWS;
   // INVARIANT of the schedule: no kernel waits for another LAUNCH. The only inter-workgroup waits are those of the persistent recurrences,
   // inside one launch whose grid is resident by construction (kbj_nn_create). Everything else is ordered by stream events, so any
   // serialisation of kernels (rocprofv3 --pmc, AMD_SERIALIZE_KERNEL=3) runs the same schedule to the same results. (Round 3 / 4 carried
@@ -1283,8 +1307,9 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       SeqBwdArgs ba{t.G[l], t.TanhC[l], t.Cm[l], dh_above[n], w.keep, params_d + o.w_hh[l], t.dGl[l], w.seq_counters + SEQ_COUNTER_WORDS * (4 * (D + l) + n), w.seq_err, T, B, grad_d + o.b[l]};
       ba.db_part = det_partials(ctx, ns[n & 1]);   // deterministic mode: per-row-group bias sums, added in order below
       if (w.seq_bstamps && bstamp_sel == 1 + n + 2 * l) ba.stamps = w.seq_bstamps;
-      if (seq_bwd(ctx, ns[n & 1], H, ba)) return -1;
-      if (ba.db_part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, ns[n & 1], ba.db_part, nrg, 4 * H, grad_d + o.b[l]);
+      const bool tiles16 = sc.bwd16;
+      if (seq_bwd(ctx, ns[n & 1], H, ba, tiles16)) return -1;
+      if (ba.db_part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, ns[n & 1], ba.db_part, seq_bwd_row_groups(B, tiles16), 4 * H, grad_d + o.b[l]);
     }
     for (const PendingDW& p : pending_dw) {   // the layer above's weight gradients: behind both lanes' input gradients (recorded below, an iteration ago), then the pause
       const NetOff& o = w.net[p.n & 1];
