@@ -60,6 +60,10 @@ int kbj_env_reset_all(kbj_ctx* ctx, uint32_t seed, float* actor0_d, float* criti
  * (train.py:1091-1105, 1134-1144, 1155-1222, 1258-1269, 1775-1781).
  * action_d [N][20]; aux_t_d [N][72] row of this step (completed); *_next_d rows of step t+1. */
 int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d, float* aux_next_d);
+/* One-shot: the NEXT kbj_env_step of this context also writes the step's state record (KBJ_QSTATE_*: qpos, qvel after the step and the
+ * positions its last forward pass ran on) into qstate_t_d [N][KBJ_QSTATE_SIZE]. kbj_rollout does the same per step for kbj_traj.qstate_d;
+ * this entry serves hosts that drive the steps themselves (user Termination / Observation / Command terms). NULL cancels. */
+int kbj_env_record_state(kbj_ctx* ctx, float* qstate_t_d);
 /* replaces: ksim's reset of the envs a Termination finished, for terminations decided OUTSIDE the step kernel - user-written terms in
  * the reference's protocol (`Termination.__call__(physics_data, curriculum_level) -> {-1, 0, 1}`, train.py:817) evaluated by the host on
  * the post-step record. mask_d [N] float: envs with a non-zero entry are re-initialised exactly as kbj_env_step re-initialises an env its
@@ -145,6 +149,8 @@ typedef struct kbj_traj {
   float* carry0_critic_mirror_hc_d;
   float* carry0_lpf_mirror_d;
   float* reward_comps_d;     /* optional [T][N][12]: unscaled reward terms of the rollout (logging), or NULL */
+  float* qstate_d;           /* optional [T][N][KBJ_QSTATE_SIZE]: qpos / qvel after every step + the positions its last forward pass ran on (the
+                              * fields a ksim Trajectory carries for user reward terms: trajectory.qpos / .qvel / .xpos / .xquat, train.py:262-506), or NULL */
 } kbj_traj;
 /* replaces: ksim's jitted rollout scan (vmap over envs, scan over T). Copies observation row T to row 0,
  * snapshots the carry, then T x (policy_step, env_step, carry_reset), then rewards. */

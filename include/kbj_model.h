@@ -257,6 +257,17 @@ enum {
   KBJ_AUX_SIZE    = 72
 };
 
+/* ---- optional per env-step state record (kbj_traj.qstate_d / kbj_env_record_state): the generalised state a ksim Trajectory step holds
+ * (`trajectory.qpos`, `.qvel`: train.py:262, 286, 301, 488) plus the positions the step's LAST forward pass ran on, from which the body poses
+ * of that pass (`trajectory.xpos`, `.xquat`: train.py:276, 317, 378-383, 419-444 - as in mj_step, the derived quantities a step leaves behind
+ * are those of its last substep's kinematics, one integration behind qpos) follow by forward kinematics over the model blob's tree ---- */
+enum {
+  KBJ_QSTATE_QPOS     = 0,    /* [27] qpos after the step (before any reset) */
+  KBJ_QSTATE_QVEL     = 27,   /* [26] qvel after the step */
+  KBJ_QSTATE_QPOS_KIN = 53,   /* [27] qpos the last substep's forward pass (xpos, xquat, sensors, contacts) was computed from */
+  KBJ_QSTATE_SIZE     = 80
+};
+
 /* reward component order (train.py:1225-1256) */
 enum {
   KBJ_REW_LINVEL = 0, KBJ_REW_ANGVEL, KBJ_REW_ROLL_PITCH, KBJ_REW_BASE_HEIGHT, KBJ_REW_ARM_POS,

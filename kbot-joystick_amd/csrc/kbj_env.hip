@@ -80,9 +80,13 @@ __global__ __launch_bounds__(256) void env_set_command_kernel(int N, int lda, in
 #ifndef KBJ_ENV_NUM_VGPR
 #define KBJ_ENV_NUM_VGPR 84
 #endif
-__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR))) void env_step_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, const PhysConst* __restrict__ pcp, uint32_t seed,
-                                                      float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ action,
-                                                      float* aux_t, float* actor_next, float* critic_next, float* aux_next, int env0) {
+// REC: the form that also writes the per-step state record (kbj_traj.qstate_d / kbj_env_record_state). The default rollout runs the other
+// one, whose code is exactly the kernel without the feature (two more pointers live through the substep loop cost 2 VGPR / 8 SGPR spills);
+// the two are separate __global__ functions so that the hot kernel keeps its name in every profile.
+template <bool REC>
+__device__ __forceinline__ void env_step_body(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, const PhysConst* __restrict__ pcp, uint32_t seed,
+                                              float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ action,
+                                              float* aux_t, float* actor_next, float* critic_next, float* aux_next, int env0, float* qstate_t) {
   __shared__ KbjShared S;
   const int env = env0 + blockIdx.x;   // a launch covers the env range [env0, env0 + gridDim.x)
   PFOR(k, (int)(sizeof(KbjModelLds) / sizeof(float))) reinterpret_cast<float*>(&S.mc)[k] = mc[k];
@@ -95,10 +99,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR
   const PhysConst& pc = S.pc;
   KBJ_STAMP(18);
   task_step(S, *m, *c, pc, rng, action + (size_t)env * KBJ_NU, aux_t + (size_t)env * KBJ_AUX_SIZE, actor_next + (size_t)env * KBJ_LD_OF(KBJ_NOBS_ACTOR + c->extra_obs_actor),
-            critic_next + (size_t)env * KBJ_LD_OF(KBJ_NOBS_CRITIC + c->extra_obs_critic), aux_next + (size_t)env * KBJ_AUX_SIZE);
+            critic_next + (size_t)env * KBJ_LD_OF(KBJ_NOBS_CRITIC + c->extra_obs_critic), aux_next + (size_t)env * KBJ_AUX_SIZE,
+            REC ? qstate_t + (size_t)env * KBJ_QSTATE_SIZE : nullptr);
   if (S.done) PFOR(k, KBJ_EP_SIZE) ep[(size_t)env * KBJ_EP_SIZE + k] = S.ep[k];
   PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
   KBJ_STAMP(19);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR))) void env_step_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, const PhysConst* __restrict__ pcp, uint32_t seed,
+                                                      float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ action,
+                                                      float* aux_t, float* actor_next, float* critic_next, float* aux_next, int env0) {
+  env_step_body<false>(m, c, mc, pcp, seed, ep, es, action, aux_t, actor_next, critic_next, aux_next, env0, nullptr);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(KBJ_ENV_NUM_VGPR))) void env_step_record_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, const PhysConst* __restrict__ pcp, uint32_t seed,
+                                                      float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ action,
+                                                      float* aux_t, float* actor_next, float* critic_next, float* aux_next, int env0, float* qstate_t) {
+  env_step_body<true>(m, c, mc, pcp, seed, ep, es, action, aux_t, actor_next, critic_next, aux_next, env0, qstate_t);
 }
 
 #ifdef KBJ_ENV_STAMPS
@@ -226,10 +241,14 @@ void kbj_nn_drop_prefetch(kbj_ctx* ctx);   // kbj_nn.hip: a pending next-minibat
 
 // one control step of the envs [env0, env0 + count) on stream s; row pointers are those of env 0
 int kbj_env_step_range(kbj_ctx* ctx, hipStream_t s, int env0, int count, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d,
-                       float* aux_next_d) {
+                       float* aux_next_d, float* qstate_t_d) {
   KbjKernelTimer timer(s, KBJ_KIND_ENV_STEP, 0.0);
-  hipLaunchKernelGGL(env_step_kernel, dim3(count), dim3(64), 0, s, ctx->model_d, ctx->cfg_d, ctx->mc_d, (const PhysConst*)ctx->pc_d, ctx->seed, ctx->ep_d, ctx->es_d, action_d, aux_t_d, actor_next_d,
-                     critic_next_d, aux_next_d, env0);
+  if (qstate_t_d)
+    hipLaunchKernelGGL(env_step_record_kernel, dim3(count), dim3(64), 0, s, ctx->model_d, ctx->cfg_d, ctx->mc_d, (const PhysConst*)ctx->pc_d, ctx->seed, ctx->ep_d, ctx->es_d, action_d, aux_t_d,
+                       actor_next_d, critic_next_d, aux_next_d, env0, qstate_t_d);
+  else
+    hipLaunchKernelGGL(env_step_kernel, dim3(count), dim3(64), 0, s, ctx->model_d, ctx->cfg_d, ctx->mc_d, (const PhysConst*)ctx->pc_d, ctx->seed, ctx->ep_d, ctx->es_d, action_d, aux_t_d,
+                       actor_next_d, critic_next_d, aux_next_d, env0);
   KBJ_CHECK_LAUNCH(ctx, "env_step_kernel");
   return 0;
 }
@@ -256,7 +275,15 @@ int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* act
   if (!action_d || !aux_t_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_step: null pointer");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   kbj_nn_drop_prefetch(ctx);
-  return kbj_env_step_range(ctx, ctx->stream, 0, ctx->cfg_h.num_envs, action_d, aux_t_d, actor_next_d, critic_next_d, aux_next_d);
+  float* q = ctx->qstate_next;
+  ctx->qstate_next = nullptr;     // one-shot (kbj_env_record_state)
+  return kbj_env_step_range(ctx, ctx->stream, 0, ctx->cfg_h.num_envs, action_d, aux_t_d, actor_next_d, critic_next_d, aux_next_d, q);
+}
+
+int kbj_env_record_state(kbj_ctx* ctx, float* qstate_t_d) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_env_record_state: null ctx");
+  ctx->qstate_next = qstate_t_d;
+  return 0;
 }
 
 int kbj_env_reset_where(kbj_ctx* ctx, const float* mask_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {

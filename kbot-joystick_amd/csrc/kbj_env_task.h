@@ -256,7 +256,7 @@ KBJ_DEV void task_write_obs(KbjShared& S, const kbj_model& m, const kbj_config& 
 // latency/drop -> push event -> substeps x (PD, forward, integrate) -> termination -> reward inputs ->
 // reset or command switch -> next observation.
 KBJ_DEV void task_step(KbjShared& S, const kbj_model& m, const kbj_config& c, const PhysConst& pc, const Rng& rng, const float* action,
-                       float* aux_t, float* actor_next, float* critic_next, float* aux_next) {
+                       float* aux_t, float* actor_next, float* critic_next, float* aux_next, float* qstate = nullptr) {
   float* es = S.es;
   uint32_t st = f2u(es[KBJ_ES_STEP]);
   bool drop = rng_u01(rng, KBJ_RNG_DROP, st, 0) < c.drop_action_prob;
@@ -281,12 +281,17 @@ KBJ_DEV void task_step(KbjShared& S, const kbj_model& m, const kbj_config& c, co
   KBJ_SYNC();
   int lat = (int)S.ep[KBJ_EP_LATENCY];
   for (int s = 0; s < c.substeps; ++s) {
+    if (qstate && s == c.substeps - 1) PFOR(k, KBJ_NQ) qstate[KBJ_QSTATE_QPOS_KIN + k] = es[KBJ_ES_QPOS + k];   // what the last forward pass's kinematics run on
     task_pd(S, s >= lat ? S.act_eff : es + KBJ_ES_ACT_PREV);
     phys_forward(S, S.mc, pc, s == c.substeps - 1);
     phys_integrate(S, pc);
     KBJ_STAMP(17);
   }
   PFOR(u, NU) { es[KBJ_ES_ACT_PREV + u] = S.act_eff[u]; aux_t[KBJ_AUX_CTRL + u] = S.ctrl[u]; }
+  if (qstate) {   // the state a Trajectory step holds: after the step, before any reset (uniform branch: null unless the caller records)
+    PFOR(k, KBJ_NQ) qstate[KBJ_QSTATE_QPOS + k] = es[KBJ_ES_QPOS + k];
+    PFOR(k, KBJ_NV) qstate[KBJ_QSTATE_QVEL + k] = es[KBJ_ES_QVEL + k];
+  }
   PFOR(w, 1) {
     es[KBJ_ES_TIME] += 1;
     es[KBJ_ES_STEP] = u2f(st + 1u);

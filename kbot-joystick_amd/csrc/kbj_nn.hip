@@ -612,7 +612,7 @@ void kbj_nn_destroy(kbj_ctx* ctx) {
 
 
 int kbj_env_step_range(kbj_ctx* ctx, hipStream_t s, int env0, int count, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d,
-                       float* aux_next_d);   // kbj_env.hip
+                       float* aux_next_d, float* qstate_t_d);   // kbj_env.hip
 
 namespace {
 
@@ -923,7 +923,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
     if (policy_nets(ctx, s, params_d, 0, 1, 0, N, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
     if (policy_nets(ctx, cs, params_d, 1, w.nnets, 0, N, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
     int rc = kbj_env_step_range(ctx, s, 0, N, act, aux_t, tr->actor_obs_d + (size_t)(t + 1) * N * la, tr->critic_obs_d + (size_t)(t + 1) * N * lc,
-                                tr->aux_d + (size_t)(t + 1) * N * lx);
+                                tr->aux_d + (size_t)(t + 1) * N * lx, tr->qstate_d ? tr->qstate_d + (size_t)t * N * KBJ_QSTATE_SIZE : nullptr);
     if (rc) return rc;
     carry_reset_nets(ctx, s, 0, 1, 0, N, carry, aux_t + KBJ_AUX_DONE, KBJ_AUX_SIZE, (t + 1) & 1);   // the planes step t + 1 reads
     if (!serial) {   // the side lane needs this step's done flags and the next critic observation

@@ -31,7 +31,7 @@ class Traj(C.Structure):
                 ("action_d", C.c_void_p), ("logp_d", C.c_void_p), ("value_d", C.c_void_p), ("reward_d", C.c_void_p),
                 ("carry0_actor_hc_d", C.c_void_p), ("carry0_critic_hc_d", C.c_void_p), ("carry0_lpf_d", C.c_void_p),
                 ("carry0_actor_mirror_hc_d", C.c_void_p), ("carry0_critic_mirror_hc_d", C.c_void_p),
-                ("carry0_lpf_mirror_d", C.c_void_p), ("reward_comps_d", C.c_void_p)]
+                ("carry0_lpf_mirror_d", C.c_void_p), ("reward_comps_d", C.c_void_p), ("qstate_d", C.c_void_p)]
 
 
 class PpoVars(C.Structure):
@@ -60,6 +60,7 @@ SIGNATURES = {
     "kbj_synchronize": (_i, [_vp]),
     "kbj_env_reset_all": (_i, [_vp, _u32, _vp, _vp, _vp]),
     "kbj_env_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "kbj_env_record_state": (_i, [_vp, _vp]),
     "kbj_env_reset_where": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "kbj_env_set_command": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "kbj_env_get_state": (_i, [_vp, _vp, _vp]),
@@ -186,7 +187,10 @@ class Context:
     def env_reset_all(self, seed, actor0, critic0, aux0):
         self.call("kbj_env_reset_all", seed, _ptr(actor0), _ptr(critic0), _ptr(aux0))
 
-    def env_step(self, action, aux_t, actor_next, critic_next, aux_next):
+    def env_step(self, action, aux_t, actor_next, critic_next, aux_next, qstate_t=None):
+        """qstate_t: optional [N][QSTATE SIZE] row that receives the step's state record (kbj_env_record_state, one-shot)."""
+        if qstate_t is not None:
+            self.call("kbj_env_record_state", _ptr(qstate_t))
         self.call("kbj_env_step", _ptr(action), _ptr(aux_t), _ptr(actor_next), _ptr(critic_next), _ptr(aux_next))
 
     def env_reset_where(self, mask, actor_next, critic_next, aux_next):

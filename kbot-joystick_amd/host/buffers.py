@@ -35,7 +35,7 @@ class TrajBuffers:
     """One rollout's worth of trajectory arrays ([T(+1)][N][dim], time-major)."""
 
     def __init__(self, T: int, N: int, H: int, depth: int, device, mirror: bool = False, reward_comps: bool = False,
-                 ld_actor: int = L.LD_ACTOR, ld_critic: int = L.LD_CRITIC):
+                 ld_actor: int = L.LD_ACTOR, ld_critic: int = L.LD_CRITIC, record_state: bool = False):
         """ld_actor / ld_critic: row strides of the context's observation rows (layout.obs_widths(kbj_config): 68 / 476 plus user columns)."""
         self.T, self.N = T, N
         z = lambda *s: torch.zeros(*s, device=device)
@@ -52,6 +52,8 @@ class TrajBuffers:
         self.adv = z(T, N)
         self.target = z(T, N)
         self.comps = z(T, N, 12) if reward_comps else None   # unscaled reward terms (train.py:1224-1256 order)
+        # per-step state record (kbj_model.h KBJ_QSTATE_*): what host/trajectory.Trajectory turns into ksim's qpos / qvel / xpos / xquat
+        self.qstate = z(T, N, L.QSTATE["SIZE"]) if record_state else None
         mptr = [None, None, None]
         if mirror:
             self.carry0_actor_mirror_hc = z(depth, 2, N, H)
@@ -60,7 +62,8 @@ class TrajBuffers:
             mptr = [self.carry0_actor_mirror_hc.data_ptr(), self.carry0_critic_mirror_hc.data_ptr(), self.carry0_lpf_mirror.data_ptr()]
         self.c = B.Traj(T, N, self.actor_obs.data_ptr(), self.critic_obs.data_ptr(), self.aux.data_ptr(), self.action.data_ptr(),
                         self.logp.data_ptr(), self.value.data_ptr(), self.reward.data_ptr(), self.carry0_actor_hc.data_ptr(),
-                        self.carry0_critic_hc.data_ptr(), self.carry0_lpf.data_ptr(), *mptr, self.comps.data_ptr() if reward_comps else None)
+                        self.carry0_critic_hc.data_ptr(), self.carry0_lpf.data_ptr(), *mptr, self.comps.data_ptr() if reward_comps else None,
+                        self.qstate.data_ptr() if record_state else None)
 
     @property
     def done(self) -> torch.Tensor:

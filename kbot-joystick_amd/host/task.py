@@ -79,6 +79,10 @@ class HumanoidWalkingTaskConfig:
     terrain_amplitude: float = 0.05         # metres; the surface definition is this build's own
     terrain_wavelength: float = 2.0
     log_reward_components: bool = False     # keep the 12 unscaled reward terms of every rollout for logging (39 MB at 8192 x 100)
+    # keep qpos / qvel of every env-step (kbj_traj.qstate_d, 262 MB at 8192 x 100): the Python reward terms (extra_rewards) then see a
+    # ksim-shaped `host.trajectory.Trajectory` - trajectory.qpos / .qvel / .xpos / .xquat / .obs[...] / .command["unified_command"] as the
+    # reference's reward classes read them (train.py:138-506) - instead of the narrower TrajectoryView of the aux record
+    record_state: bool = False
     # data-parallel exchange: "per_step" = all-reduce the gradient before every optimizer step (the
     # single-GPU-equivalent default); "per_pass" = north_star's "once per update" variant: accumulate the minibatch gradients of
     # a pass locally, ONE all-reduce and ONE optimizer step per pass (fewer, larger steps - a different algorithm). KBJ_ALLREDUCE
@@ -258,7 +262,7 @@ class HumanoidWalkingTask:
             raise ValueError("config.extra_actor_obs / extra_critic_obs reserve network inputs, but no observation term is routed into them "
                              "(extra_observations={name: (term, 'actor' | 'critic' | 'both')})")
         self.traj = TrajBuffers(self.T, self.N, self.H, self.kcfg.depth, self.device, mirror=self.mirror, reward_comps=config.log_reward_components,
-                                ld_actor=self.ld_actor, ld_critic=self.ld_critic)
+                                ld_actor=self.ld_actor, ld_critic=self.ld_critic, record_state=config.record_state)
         self.opt_step = 0
         self.iteration = 0
         self._perm_gen = torch.Generator(device="cpu")
@@ -294,10 +298,22 @@ class HumanoidWalkingTask:
         else:
             self.ctx.rollout(self.params, self.carry.c, self.config.seed, self.iteration * self.T, self.traj.c)
         if self.extra_rewards:
-            from .traj_view import TrajectoryView, apply_extra_rewards
+            from .traj_view import apply_extra_rewards
+            self.extra_reward_means = apply_extra_rewards(self.extra_rewards, self._extra_carries, self.trajectory(), self.traj.reward)
+
+    def trajectory(self):
+        """The last rollout as the Python reward terms see it: with `config.record_state` a ksim-shaped `host.trajectory.Trajectory`
+        (trajectory.qpos / .qvel / .xpos / .xquat / .ctrl / .done / .obs[...] / .command["unified_command"], train.py:138-506), else the
+        `TrajectoryView` of the aux record. User observation terms appear under their names in `.obs` / `.extra_observations`."""
+        extra = {k: v[:self.T] for k, v in self.extra_obs_buffers.items()}
+        if self.config.record_state:
+            from .trajectory import Trajectory
+            view = Trajectory(self.traj, self.T, self.model_blob, extra_observations=extra)
+        else:
+            from .traj_view import TrajectoryView
             view = TrajectoryView(self.traj, self.T)
-            view.extra_observations = {k: v[:self.T] for k, v in self.extra_obs_buffers.items()}
-            self.extra_reward_means = apply_extra_rewards(self.extra_rewards, self._extra_carries, view, self.traj.reward)
+        view.extra_observations = extra
+        return view
 
     def _apply_command(self, ctx, tr, row: int, view, fresh, step_index: int, all_fresh: bool = False):
         """The user's Command term for observation row `row` of `tr` (train.py:724, 768): `initial_command` for the envs whose episode
@@ -371,7 +387,7 @@ class HumanoidWalkingTask:
             self._obs_started = True
         for t in range(T):
             c.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], self.carry.c, self.config.seed, first + t, False, tr.action[t], tr.logp[t], tr.value[t])
-            c.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
+            c.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], tr.qstate[t] if tr.qstate is not None else None)
             view = StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob)
             if self.extra_terminations:
                 user = combine_terminations(self.extra_terminations, view)

@@ -98,6 +98,7 @@ EP = dict(IPOS=0, MASS=72, INERTIA=96, ARMATURE=168, FRICLOSS=194, CAP_POS=220, 
 ES = dict(QPOS=0, QVEL=28, WARM=54, ACT_PREV=80, CMD=100, PUSH=116, PUSH_REM=122, PUSH_NXT=123, TIME=124,
           PGLAG=125, EPISODE=128, STEP=129, SIZE=136)
 RC = dict(TSINGLE=0, AIRTIME=1, CONTACT=3, SIZE=8)
+QSTATE = dict(QPOS=0, QVEL=27, QPOS_KIN=53, SIZE=80)      # kbj_model.h KBJ_QSTATE_*: optional per env-step state record
 # pieces of a packed observation row in the reference's concatenation order (kbj_model.h KBJ_OBS_*; train.py:1367-1374, 1410-1430):
 # name -> (offset, width); the first six are common to the actor and the critic row
 OBS = dict(JPOS=(0, 20), JVEL=(20, 20), PG=(40, 5), GYRO=(45, 3), ZEROCMD=(48, 1), CMD=(49, 16), TOUCH=(65, 2), FEETPOS=(67, 6), BASEPOS=(73, 3),

@@ -629,3 +629,78 @@ def test_default_schedule_survives_kernel_serialisation():
     env.update(AMD_SERIALIZE_KERNEL="3", AMD_SERIALIZE_COPY="3")
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0 and "SERIAL_OK" in out.stdout, (out.stdout[-300:], out.stderr[-600:])
+
+
+def test_reference_reward_classes_on_the_trajectory_reproduce_the_kernel():
+    """f3: with `record_state` the Python reward terms see a ksim-shaped Trajectory (host/trajectory.py). Two real rollouts of the full kbot on
+    the sine terrain (sampler commands, pushes, terminations - the initial policy falls): (a) the recorded qpos / qvel are the env rows after
+    the step; (b) the forward kinematics over the recorded positions reproduce the poses the kernel itself wrote into the aux record;
+    (c) the reference's twelve reward classes, restated in torch with the reference's attribute names (train.py:138-506), reproduce
+    rewards_kernel term by term to 2e-4, carries of the stateful ones included; (d) a user term sees the same object."""
+    import torch
+    from kbot_joystick_amd.host import trajectory as TJ
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    from kbot_joystick_amd.spec import constants, layout as L
+    seen = {}
+
+    class Probe:                      # a user term in ksim's Reward protocol, written against the reference's field names
+        scale = 0.0
+
+        def get_reward(self, trajectory):
+            seen["type"] = type(trajectory).__name__
+            seen["qpos"] = tuple(trajectory.qpos.shape)
+            return -trajectory.qvel[..., 6:].square().sum(dim=-1) * 0 + trajectory.xpos[..., 1, 2] * 0
+    cfg = _small(num_envs=256, batch_size=64, rollout_length_seconds=1.0, robot="kbot", terrain="sine", record_state=True, log_reward_components=True, seed=11)
+    task = HumanoidWalkingTask(cfg, extra_rewards={"probe": Probe()})
+    terms = TJ.reference_rewards(task.model_blob, ctrl_dt=cfg.ctrl_dt)
+    A, Q, T = L.AUX, L.QSTATE, task.T
+    carries, ndone = {}, 0
+    for rollout in range(2):
+        task.rollout()
+        task.ctx.synchronize()
+        tr = task.trajectory()
+        assert isinstance(tr, TJ.Trajectory) and seen == {"type": "Trajectory", "qpos": (T, 256, 27)}
+        aux = task.traj.aux[:T]
+        # (a) the last step's record = the env rows (envs that were not reset by that step)
+        _, es = task.ctx.env_get_state()
+        alive = (aux[T - 1, :, A["DONE"]] == 0).cpu().numpy()
+        assert alive.sum() > 100
+        assert np.array_equal(tr.qpos[T - 1].cpu().numpy()[alive], es[alive, L.ES["QPOS"]:L.ES["QPOS"] + 27])
+        assert np.array_equal(tr.qvel[T - 1].cpu().numpy()[alive], es[alive, L.ES["QVEL"]:L.ES["QVEL"] + 26])
+        assert torch.equal(tr.qvel[..., :6], aux[..., A["QVEL"]:A["QVEL"] + 6]) and torch.equal(tr.qpos[..., 17:27], aux[..., A["ARMQ"]:A["ARMQ"] + 10])
+        # (b) kinematics of the step's last forward pass
+        mb = task.model_blob
+        for body, zc, qc in ((int(mb.base_body), "BASEZ", "BQUAT"), (int(mb.lfoot_body), "LFZ", "LFQUAT"), (int(mb.rfoot_body), "RFZ", "RFQUAT")):
+            assert float((tr.xpos[..., body, 2] - aux[..., A[zc]]).abs().max()) < 2e-6
+            qk = aux[..., A[qc]:A[qc] + 4]
+            sgn = torch.sign((tr.xquat[..., body, :] * qk).sum(-1, keepdim=True))
+            assert float((tr.xquat[..., body, :] - sgn * qk).abs().max()) < 2e-6
+        # (c) the twelve terms
+        total = torch.zeros_like(task.traj.reward)
+        for k, (name, term) in enumerate(terms.items()):
+            if hasattr(term, "get_reward_stateful"):
+                if name not in carries:
+                    carries[name] = term.initial_carry(256, task.device)
+                r, carries[name] = term.get_reward_stateful(tr, carries[name])
+            else:
+                r = term.get_reward(tr)
+            err = float((r - task.traj.comps[..., k]).abs().max())
+            assert err < 2e-4, (rollout, name, constants.REWARD_NAMES[k], err)
+            total += term.scale * r
+        assert float((total - task.traj.reward).abs().max()) < 2e-4
+        ndone += int(tr.done.sum())
+        task.iteration += 1
+    assert ndone > 20                                              # terminations (and the carries' done handling) were exercised
+    # the step-by-step path (user terms) records the same states as the fused rollout
+    t1 = HumanoidWalkingTask(_small(num_envs=64, record_state=True, seed=5))
+    t2 = HumanoidWalkingTask(_small(num_envs=64, record_state=True, seed=5), extra_terminations={"never": lambda state, level: torch.zeros(state.N, device=state.done.device)})
+    t1.rollout(); t2.rollout()
+    assert torch.equal(t1.traj.qstate, t2.traj.qstate) and float(t1.traj.qstate.abs().sum()) > 0
+    # without the record the narrower view is what terms get, and asking for the ksim-shaped one says why it is not there
+    t3 = HumanoidWalkingTask(_small(num_envs=64, seed=5))
+    t3.rollout()
+    assert type(t3.trajectory()).__name__ == "TrajectoryView"
+    with pytest.raises(ValueError, match="record_state"):
+        TJ.Trajectory(t3.traj, t3.T, t3.model_blob)
+    for t in (task, t1, t2, t3):
+        t.close()

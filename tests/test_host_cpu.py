@@ -308,3 +308,77 @@ globalThis.requestAnimationFrame = (f) => { if (frames++ < 120) setImmediate(() 
         (tmp_path / "check.js").write_text(stub + js)
         out = subprocess.run(["node", str(tmp_path / "check.js")], capture_output=True, text=True, timeout=60)
         assert out.returncode == 0 and out.stdout.startswith("OK ") and "command vx" in out.stdout, out.stderr[-400:]
+
+
+def test_reference_reward_classes_on_a_ksim_shaped_trajectory_match_the_oracle(model_full):
+    """host/trajectory.py on the CPU: (a) the torch forward kinematics equal the numpy ones the view recorder uses (themselves pinned to the
+    oracle's xpos / xquat above); (b) the reference's twelve reward classes, restated in torch against `Trajectory` with the reference's
+    attribute names (train.py:138-506), reproduce the ORACLE's reward scan term by term on a synthetic two-rollout record - random poses,
+    commands incl. zero commands and turning, contacts, terminations - whose aux columns are what the env kernel would have written for
+    those states. (The GPU twin, against rewards_kernel on real rollouts: tests/test_gpu_host.py.)"""
+    import types
+    import torch
+    from kbot_joystick_amd.host import trajectory as TJ, view as V
+    from kbot_joystick_amd.spec import layout
+    from oracle import oracle as O
+    m = model_full
+    rng = np.random.default_rng(3)
+    T, N = 40, 24
+    A, Q = L.AUX, L.QSTATE
+    cfg = layout.default_config(num_envs=N)
+    o = O.Oracle(m, cfg, precision="f64")
+    terms = TJ.reference_rewards(m, ctrl_dt=cfg.ctrl_dt)
+    assert list(terms) == list(constants.REWARD_NAMES)
+    assert [t.scale for t in terms.values()] == pytest.approx(list(cfg.reward_scale))
+    carries = {}
+    for rollout in range(2):
+        q = np.tile(np.array(m.qpos0[:L.NQ], np.float64), (T, N, 1))
+        q[..., 7:] += rng.normal(0, 0.3, (T, N, L.NQ - 7))
+        qq = np.array([1.0, 0, 0, 0]) + rng.normal(0, 0.25, (T, N, 4)); q[..., 3:7] = qq / np.linalg.norm(qq, axis=-1, keepdims=True)
+        q[..., :3] += rng.normal(0, 0.1, (T, N, 3))
+        xp, xq = V.forward_kinematics(m, q)
+        xpt, xqt = TJ.forward_kinematics(m, torch.from_numpy(q))
+        assert np.abs(xpt.numpy() - xp).max() < 1e-12 and np.abs(xqt.numpy() - xq).max() < 1e-12          # (a)
+        qs = np.zeros((T, N, Q["SIZE"]), np.float32)
+        qs[..., Q["QPOS_KIN"]:Q["QPOS_KIN"] + L.NQ] = q
+        qpos_after = q + rng.normal(0, 0.01, q.shape)
+        qs[..., Q["QPOS"]:Q["QPOS"] + L.NQ] = qpos_after
+        qvel = rng.normal(0, 0.5, (T, N, L.NV))
+        qs[..., Q["QVEL"]:Q["QVEL"] + L.NV] = qvel
+        aux = np.zeros((T + 1, N, A["SIZE"]), np.float32)
+        a = aux[:T]
+        a[..., A["QVEL"]:A["QVEL"] + 6] = qs[..., Q["QVEL"]:Q["QVEL"] + 6]
+        a[..., A["BQUAT"]:A["BQUAT"] + 4] = xq[..., int(m.base_body), :]
+        a[..., A["LFQUAT"]:A["LFQUAT"] + 4] = xq[..., int(m.lfoot_body), :]
+        a[..., A["RFQUAT"]:A["RFQUAT"] + 4] = xq[..., int(m.rfoot_body), :]
+        a[..., A["BASEZ"]], a[..., A["LFZ"]], a[..., A["RFZ"]] = xp[..., int(m.base_body), 2], xp[..., int(m.lfoot_body), 2], xp[..., int(m.rfoot_body), 2]
+        a[..., A["ARMQ"]:A["ARMQ"] + 10] = qs[..., Q["QPOS"] + 17:Q["QPOS"] + 27]
+        a[..., A["CTRL"]:A["CTRL"] + L.NU] = rng.normal(0, 8, (T, N, L.NU))
+        a[..., A["TOUCH"]:A["TOUCH"] + 2] = rng.uniform(0, 300, (T, N, 2)) * (rng.uniform(size=(T, N, 2)) < 0.6)
+        a[..., A["COMDIST"]] = np.where(rng.uniform(size=(T, N)) < 0.2, -1.0, rng.uniform(0, 0.2, (T, N)))
+        cmd = rng.uniform(-0.5, 0.5, (N, L.NCMD)); cmd[: N // 3, :3] = 0.0; cmd[N // 3: N // 2, 2] = 0.0        # standing envs, straight walkers, turners
+        a[..., A["CMD"]:A["CMD"] + L.NCMD] = cmd[None]
+        a[T // 2:, N - 4:, A["CMD"]:A["CMD"] + 3] = 0.0                                                            # a switch to the zero command mid-rollout
+        a[..., A["DONE"]] = np.where(rng.uniform(size=(T, N)) < 0.05, np.where(rng.uniform(size=(T, N)) < 0.5, -1.0, 1.0), 0.0)
+        rew, comps = o.rewards(aux[:T])
+        fake = types.SimpleNamespace(aux=torch.from_numpy(aux), qstate=torch.from_numpy(qs), action=torch.zeros(T, N, L.NU), reward=torch.zeros(T, N),
+                                     actor_obs=torch.zeros(T + 1, N, L.LD_ACTOR), critic_obs=torch.zeros(T + 1, N, L.LD_CRITIC))
+        tr = TJ.Trajectory(fake, T, m)
+        assert tr.qpos.shape == (T, N, 27) and tr.qvel.shape == (T, N, 26) and tr.xpos.shape == (T, N, 24, 3) and tr.xquat.shape == (T, N, 24, 4)
+        assert tr.done.dtype == torch.bool and tr.obs["left_foot_touch"].shape == (T, N, 1) and tr.command["unified_command"].shape == (T, N, 16)
+        total = torch.zeros(T, N)
+        for k, (name, term) in enumerate(terms.items()):
+            if hasattr(term, "get_reward_stateful"):
+                if name not in carries:
+                    carries[name] = term.initial_carry(N, "cpu")
+                r, carries[name] = term.get_reward_stateful(tr, carries[name])
+            else:
+                r = term.get_reward(tr)
+            assert r.shape == (T, N), name
+            err = float((r.double() - torch.from_numpy(comps[..., k]).double()).abs().max())
+            assert err < 2e-4, (rollout, name, err)
+            total += term.scale * r
+        assert float((total - torch.from_numpy(rew)).abs().max()) < 2e-4
+    with pytest.raises(ValueError, match="record_state"):
+        TJ.Trajectory(types.SimpleNamespace(aux=torch.zeros(2, 1, A["SIZE"]), qstate=None, action=torch.zeros(1, 1, 20), actor_obs=torch.zeros(2, 1, L.LD_ACTOR),
+                                            critic_obs=torch.zeros(2, 1, L.LD_CRITIC)), 1, m)
