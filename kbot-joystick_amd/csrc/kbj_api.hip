@@ -210,7 +210,7 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
       // gemm_x3_kernel<TM, A_KC, B_KC, GEN> as rocprofv3 prints the instantiations the launcher uses (kbj_ctx.h kbj_kind_gemm_x3)
       "kbj::gemm_x3_kernel<2, false, false, false>", "kbj::gemm_x3_kernel<2, false, true, false>", "kbj::gemm_x3_kernel<2, true, false, false>",
       "kbj::gemm_x3_kernel<2, true, true, false>", "kbj::gemm_x3_kernel<2, true, true, true>", "kbj::gemm_x3_kernel<1, true, true, false>",
-      "kbj::gemm_x3_kernel<1, true, true, true>", "kbj::lstm_seq_bwd16_kernel", "kbj::lstm_seq_fwd_x3_kernel"};
+      "kbj::gemm_x3_kernel<1, true, true, true>", "kbj::lstm_seq_bwd16_kernel"};
   for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
     kbj_kernel_stat& st = ctx->kstats[k];
     const int uw = 2;   // wavefront pairs per recurrence workgroup (kbj_nn.hip SEQ_UW), as rocprofv3 prints the template argument
@@ -219,7 +219,7 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
     else if (k == KBJ_KIND_SEQ_FWD || k == KBJ_KIND_SEQ_FWD_FUSED || k == KBJ_KIND_SEQ_FWD_OBS)   // as rocprofv3 prints the template arguments
       snprintf(st.name, sizeof(st.name), "%s<%d, %d, %s, %d>", names[k], hk, uw, k == KBJ_KIND_SEQ_FWD ? "false" : "true",
                k == KBJ_KIND_SEQ_FWD_OBS ? KBJ_LD_ACTOR : hk);
-    else if (k == KBJ_KIND_SEQ_BWD16 || k == KBJ_KIND_SEQ_FWD_X3) snprintf(st.name, sizeof(st.name), "%s<%d>", names[k], hk);
+    else if (k == KBJ_KIND_SEQ_BWD16) snprintf(st.name, sizeof(st.name), "%s<%d>", names[k], hk);
     else if (k == KBJ_KIND_LSTM_STEP || k == KBJ_KIND_LSTM_STEP_OBS)
       snprintf(st.name, sizeof(st.name), "%s<%d, 2, %d>", names[k], hk, k == KBJ_KIND_LSTM_STEP_OBS ? KBJ_LD_ACTOR : hk);
     else snprintf(st.name, sizeof(st.name), "%s", names[k]);

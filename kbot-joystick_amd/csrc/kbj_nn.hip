@@ -10,7 +10,6 @@
 #include "kbj_nn_kernels.h"
 #include "kbj_lstm_seq.h"
 #include "kbj_lstm_bwd16.h"
-#include "kbj_lstm_x3.h"
 
 using namespace kbj;
 
@@ -43,8 +42,6 @@ struct Sched {
   bool bwd16 = true;               // KBJ_BWD16=0: backward recurrences on the 32-row x 32-unit form of rounds 1-4 (lstm_seq_bwd_kernel) instead of 16-row x 64-unit
                                    // tiles with the partner-major contraction (kbj_lstm_bwd16.h: 620 instead of 907 us per launch in situ)
   int dw_delay_us = 30;            // KBJ_DW_DELAY_US=n (0 = off): pause of the weight-gradient lanes behind both lanes' input gradients (kbj_ppo_grad)
-  bool seq_x3 = false;             // with gemm_x3 (KBJ_SEQ_X3=0 keeps the fp32 recurrences): forward recurrences on the bf16 matrix cores through the same split
-                                   // (kbj_lstm_x3.h), their input products as gemm_x3_kernel launches in front of them instead of fused
   bool gemm_x3 = false;            // kbj_config.gemm_bf16x3 / KBJ_GEMM_X3=1: the GEMM launches that are eligible (the update's input gradients, weight-gradient
                                    // pairs and critic input projection, the rollout's [x | h] gate GEMMs) on the bf16 matrix cores through the exact three-way
                                    // operand split (kbj_gemm.h gemm_x3_kernel); not the default, not the headline
@@ -186,10 +183,7 @@ template <class T> int dalloc(kbj_ctx* ctx, NnWs& w, T** p, size_t count) {
 
 thread_local int g_gemm_x3 = 0;     // set by kbj_ppo_grad from the context's schedule for the duration of the call (the wrappers below have no context)
 constexpr int g_fold_sk = 8;        // k slices of the small W_ih0^T Z product of the folded input projections
-#ifndef KBJ_SPLITK_WGS
-#define KBJ_SPLITK_WGS 768
-#endif
-constexpr int g_splitk_wgs = KBJ_SPLITK_WGS;   // target number of workgroups of a split-K weight-gradient GEMM (512 ... 1536 measured flat)
+constexpr int g_splitk_wgs = 768;   // target number of workgroups of a split-K weight-gradient GEMM (512 ... 1536 measured flat)
 constexpr int DETP_ROWS = 512, DETP_COLS = 4 * 512;   // (columns: one gate row of the widest layer, 4 SEQ_MAX_H)
 
 // lane index of a stream of this context (deterministic-mode workspaces are per lane: launches on different lanes overlap)
@@ -201,9 +195,8 @@ float* det_partials(kbj_ctx* ctx, hipStream_t s);
 inline dim3 g1(size_t n, int bs = 256) { return dim3((unsigned)((n + bs - 1) / bs)); }
 
 // y = x W^T + b  (x [M][K] lda, W [N][K])
-void linear_fwd(hipStream_t s, const float* x, int lda, const float* W, int ldw, const float* bias, float* y, int ldy, int M, int N, int K, int beta, int x3 = 0) {
+void linear_fwd(hipStream_t s, const float* x, int lda, const float* W, int ldw, const float* bias, float* y, int ldy, int M, int N, int K, int beta) {
   GemmArgs g{x, W, y, bias, M, N, K, lda, ldw, ldy, beta, 1, nullptr};
-  g.x3 = x3;     // eligible launches only (kbj_gemm.h gemm_x3_form); set by the forward pass of a gemm_bf16x3 context for its gate products
   gemm_launch<true, true>(s, g);
 }
 // dx = dy W   (dy [M][K=nout] , W [K][N])
@@ -284,25 +277,7 @@ template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0
   if constexpr (H <= SEQ_FUSED_MAX_H) hipLaunchKernelGGL((lstm_seq_bwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
   else hipLaunchKernelGGL((lstm_seq_bwd_wide_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
 }
-template <int H> void seq_fwd_x3_launch(hipStream_t s, const SeqFwdArgs& a0) {
-  SeqFwdArgs a = a0;
-  a.spin_limit = g_seq_spin_limit;
-  int grid = (H / (SEQ_UNITS * SEQ_UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
-  if (g_seq_drop > 0 && grid > 1) { --g_seq_drop; --grid; }
-  hipLaunchKernelGGL((lstm_seq_fwd_x3_kernel<H>), dim3(grid), dim3(512), 0, s, a);
-}
 int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {   // a.counters: zeroed by the caller
-  if (ws_of(ctx)->sched.seq_x3 && !a.X) {     // kbj_config.gemm_bf16x3: recurrent product through the three-way bf16 split (kbj_lstm_x3.h)
-    KbjKernelTimer timer(st, KBJ_KIND_SEQ_FWD_X3, 2.0 * a.T * a.B * 4.0 * H * H);
-    switch (H) {
-      case 64: seq_fwd_x3_launch<64>(st, a); break;
-      case 128: seq_fwd_x3_launch<128>(st, a); break;
-      case 192: seq_fwd_x3_launch<192>(st, a); break;
-      case 256: seq_fwd_x3_launch<256>(st, a); break;
-      default: return kbj_fail(ctx, "lstm_seq_fwd_x3_kernel is built for hidden sizes 64, 128, 192, 256");
-    }
-    return 0;
-  }
   KbjKernelTimer timer(st, a.X ? (a.ldx == KBJ_LD_ACTOR ? KBJ_KIND_SEQ_FWD_OBS : KBJ_KIND_SEQ_FWD_FUSED) : KBJ_KIND_SEQ_FWD, 2.0 * a.T * a.B * 4.0 * H * (H + (a.X ? (a.kx ? a.kx : H) : 0)));
   switch (H) {
     case 64: seq_fwd_launch<64, SEQ_UW>(st, a); break;
@@ -362,9 +337,6 @@ template <int H> hipError_t seq_min_blocks_per_cu(int* out) {
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], lstm_seq_fwd_kernel<H, SEQ_UW, true, H>, threads, 0);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], lstm_seq_fwd_kernel<H, SEQ_UW, true, KBJ_LD_ACTOR>, threads, 0);
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], lstm_seq_bwd_kernel<H, SEQ_UW>, threads, 0);
-    int nx3 = 0;   // the split forward form (kbj_config.gemm_bf16x3)
-    if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nx3, lstm_seq_fwd_x3_kernel<H>, 512, 0);
-    n[2] = std::min(n[2], nx3);
     int n16 = 0;   // the 16 x 64-tile backward form: same grid size ((B / 16) x (H / 64) = (B / 32) x (H / 32)), same 512 threads
     if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n16, lstm_seq_bwd16_kernel<H>, BWD16_NTH, 0);
     n[3] = std::min(n[3], n16);
@@ -580,8 +552,6 @@ int kbj_nn_create(kbj_ctx* ctx) {
     if (getenv("KBJ_DW_DELAY_US")) sc.dw_delay_us = std::max(0, std::min(1000, atoi(getenv("KBJ_DW_DELAY_US"))));
     sc.gemm_x3 = (c.gemm_bf16x3 != 0 || env_flag("KBJ_GEMM_X3", false)) && !sc.deterministic;   // (the deterministic split-K slabs stay on the exact kernel)
     if (H > (size_t)SEQ_FUSED_MAX_H) sc.fuse_ih = sc.fuse_obs = sc.rollout_step = false;   // wide layers (SEQ_FUSED_MAX_H above)
-    sc.seq_x3 = sc.gemm_x3 && H <= (size_t)SEQ_FUSED_MAX_H && env_flag("KBJ_SEQ_X3", true);
-    if (sc.seq_x3) sc.fuse_ih = sc.fuse_obs = false;   // the split recurrence holds W_hh only (96 registers as three bf16 pieces): input products are x3 GEMM launches
     if (sc.deterministic) {
       for (int l = 0; l < 4; ++l) if (dalloc(ctx, *w, &w->detp[l], (size_t)DETP_ROWS * DETP_COLS)) return -1;
       if (dalloc(ctx, *w, &w->detd, 2 * 512)) return -1;
@@ -1132,9 +1102,8 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
-      const int x3 = sc.seq_x3 ? 1 : 0;
-      if (sc.fold_actor && (n & 1) == 0 && l == 0) { if (!fuse_obs) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, o.ld_obs, w.beff, t.G[0], 4 * H, R, 4 * H, x3 ? o.ld_obs : o.nin, 0, x3); }
-      else if (!fuse_ih) linear_fwd(ns[n & 1], l == 0 ? t.X0 : t.Hout[l - 1], H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0, x3);
+      if (sc.fold_actor && (n & 1) == 0 && l == 0) { if (!fuse_obs) linear_fwd(ns[0], t.obs, o.ld_obs, w.Weff, o.ld_obs, w.beff, t.G[0], 4 * H, R, 4 * H, o.nin, 0); }
+      else if (!fuse_ih) linear_fwd(ns[n & 1], l == 0 ? t.X0 : t.Hout[l - 1], H, params_d + o.w_ih[l], H, params_d + o.b[l], t.G[l], 4 * H, R, 4 * H, H, 0);
     }
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
