@@ -183,7 +183,10 @@ template <class T> int dalloc(kbj_ctx* ctx, NnWs& w, T** p, size_t count) {
 
 thread_local int g_gemm_x3 = 0;     // set by kbj_ppo_grad from the context's schedule for the duration of the call (the wrappers below have no context)
 constexpr int g_fold_sk = 8;        // k slices of the small W_ih0^T Z product of the folded input projections
-constexpr int g_splitk_wgs = 768;   // target number of workgroups of a split-K weight-gradient GEMM (512 ... 1536 measured flat)
+#ifndef KBJ_SPLITK_WGS
+#define KBJ_SPLITK_WGS 768   // re-swept in round 5 under the four-launches-together schedule: 256 / 384 / 512 / 768 / 1024 -> 6.10 / 6.0 / 5.96 / 5.86 / 5.95 ms per minibatch
+#endif
+constexpr int g_splitk_wgs = KBJ_SPLITK_WGS;   // target number of workgroups of a split-K weight-gradient GEMM (512 ... 1536 measured flat)
 constexpr int DETP_ROWS = 512, DETP_COLS = 4 * 512;   // (columns: one gate row of the widest layer, 4 SEQ_MAX_H)
 
 // lane index of a stream of this context (deterministic-mode workspaces are per lane: launches on different lanes overlap)
