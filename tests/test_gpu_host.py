@@ -272,6 +272,32 @@ def test_bench_launches_its_own_ranks():
     assert bad.returncode != 0 and "does not match WORLD_SIZE" in (bad.stderr + bad.stdout)
 
 
+def test_bench_line_carries_the_child_process_legs():
+    """`bench.py --gpus 1` (the driver's own invocation, at a small size): after the headline is measured the two NON-headline legs run in child
+    processes - `variant_gemm_bf16x3` and `train_loop` (launch() with logging, validation rollouts and background checkpoints) - and a leg that
+    dies costs its own object, never the line."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--envs-per-gpu", "512", "--hidden", "64", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--loop-iterations", "30"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                        # ONE JSON line, whatever the children print
+    rec = json.loads(lines[0])
+    assert rec["value"] > 0 and rec["dtype"] == "f32" and rec["variant"].startswith("headline")
+    v, tl = rec["variant_gemm_bf16x3"], rec["train_loop"]
+    assert v["NOT_THE_HEADLINE"] and v["value"] > 0 and "child" in v["process"]
+    assert tl["value"] > 0 and tl["iterations"] == 30 and tl["validations"] == 1 and tl["vs_headline"] > 0 and tl["checkpoint_bytes"] > 0
+    # a leg that fails (here: an impossible loop length is fine, so break the child through its environment) leaves an error in ITS object only
+    bad = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, KBJ_LIB_NAME="libkbj_does_not_exist.so"))
+    assert bad.returncode != 0                                     # without the library nothing runs at all: the product path fails loudly
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--leg", "variant", "--gpus", "1", "--envs-per-gpu", "512", "--hidden", "64", "--steps", "1",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=600, env=env)
+    assert one.returncode == 0 and json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])["name"] == "gemm_bf16x3"
+
+
 def test_bench_forced_collective_on_one_gpu():
     """`bench.py --gpus 1 --force-collective`: the RCCL leg (backend nccl, world size 1, gradient all-reduce forced) timed beside the run
     without a process group and the overlapped exchange, in one process; the rank count of the line comes from the process group and an
@@ -631,7 +657,8 @@ def test_default_schedule_survives_kernel_serialisation():
     assert out.returncode == 0 and "SERIAL_OK" in out.stdout, (out.stdout[-300:], out.stderr[-600:])
 
 
-def test_reference_reward_classes_on_the_trajectory_reproduce_the_kernel():
+@pytest.mark.parametrize("size", ["256 envs x 50 steps, full kbot on the terrain", "configs[1]: 8192 envs x 100 steps"])
+def test_reference_reward_classes_on_the_trajectory_reproduce_the_kernel(size):
     """f3: with `record_state` the Python reward terms see a ksim-shaped Trajectory (host/trajectory.py). Two real rollouts of the full kbot on
     the sine terrain (sampler commands, pushes, terminations - the initial policy falls): (a) the recorded qpos / qvel are the env rows after
     the step; (b) the forward kinematics over the recorded positions reproduce the poses the kernel itself wrote into the aux record;
@@ -650,7 +677,13 @@ def test_reference_reward_classes_on_the_trajectory_reproduce_the_kernel():
             seen["type"] = type(trajectory).__name__
             seen["qpos"] = tuple(trajectory.qpos.shape)
             return -trajectory.qvel[..., 6:].square().sum(dim=-1) * 0 + trajectory.xpos[..., 1, 2] * 0
-    cfg = _small(num_envs=256, batch_size=64, rollout_length_seconds=1.0, robot="kbot", terrain="sine", record_state=True, log_reward_components=True, seed=11)
+    big = size.startswith("configs[1]")
+    if big:      # the BASELINE workload: kbot-headless, flat ground, fixed command (0.5, 0, 0), 8192 envs x 100 steps
+        from kbot_joystick_amd.host.task import launch_config
+        cfg = launch_config(num_envs=8192, robot="kbot-headless", fixed_command=(0.5, 0.0, 0.0), record_state=True, log_reward_components=True, seed=11)
+    else:
+        cfg = _small(num_envs=256, batch_size=64, rollout_length_seconds=1.0, robot="kbot", terrain="sine", record_state=True, log_reward_components=True, seed=11)
+    NE = cfg.num_envs
     task = HumanoidWalkingTask(cfg, extra_rewards={"probe": Probe()})
     terms = TJ.reference_rewards(task.model_blob, ctrl_dt=cfg.ctrl_dt)
     A, Q, T = L.AUX, L.QSTATE, task.T
@@ -659,7 +692,7 @@ def test_reference_reward_classes_on_the_trajectory_reproduce_the_kernel():
         task.rollout()
         task.ctx.synchronize()
         tr = task.trajectory()
-        assert isinstance(tr, TJ.Trajectory) and seen == {"type": "Trajectory", "qpos": (T, 256, 27)}
+        assert isinstance(tr, TJ.Trajectory) and seen == {"type": "Trajectory", "qpos": (T, NE, 27)}
         aux = task.traj.aux[:T]
         # (a) the last step's record = the env rows (envs that were not reset by that step)
         _, es = task.ctx.env_get_state()
@@ -680,7 +713,7 @@ def test_reference_reward_classes_on_the_trajectory_reproduce_the_kernel():
         for k, (name, term) in enumerate(terms.items()):
             if hasattr(term, "get_reward_stateful"):
                 if name not in carries:
-                    carries[name] = term.initial_carry(256, task.device)
+                    carries[name] = term.initial_carry(NE, task.device)
                 r, carries[name] = term.get_reward_stateful(tr, carries[name])
             else:
                 r = term.get_reward(tr)
@@ -691,6 +724,9 @@ def test_reference_reward_classes_on_the_trajectory_reproduce_the_kernel():
         ndone += int(tr.done.sum())
         task.iteration += 1
     assert ndone > 20                                              # terminations (and the carries' done handling) were exercised
+    if big:
+        task.close()
+        return
     # the step-by-step path (user terms) records the same states as the fused rollout
     t1 = HumanoidWalkingTask(_small(num_envs=64, record_state=True, seed=5))
     t2 = HumanoidWalkingTask(_small(num_envs=64, record_state=True, seed=5), extra_terminations={"never": lambda state, level: torch.zeros(state.N, device=state.done.device)})
