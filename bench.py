@@ -290,6 +290,14 @@ def main():
         sys.exit(f"bench.py needs a HIP device (rank {rank} of {world})")
     if args.share_gpu:
         local_rank = 0
+        # the persistent LSTM recurrences need their whole grid resident (kbj_create checks that per context); ranks that SHARE a GPU share its
+        # CUs, and a grid that is only partly placed spins to its bound launch after launch (fail-stop, but minutes of it): refuse instead
+        grid = (512 // 32) * ((args.hidden + 63) // 64 * 64 // 32)
+        cus = torch.cuda.get_device_properties(0).multi_processor_count
+        if world * 2 * grid > cus // 2:     # (half the CUs: the ranks' GEMM and env workgroups want room too. Measured: 4 ranks x hidden 64 = 256 workgroups on 256
+            # CUs crawls from spin bound to spin bound - killed after 400 s; 2 ranks x hidden 64 run in a minute, tests/test_gpu_host.py)
+            sys.exit(f"bench.py --share-gpu: {world} ranks x 2 concurrent recurrence launches x {grid} workgroups (batch 512, hidden {args.hidden}) do not fit the "
+                     f"{cus} CUs of the one GPU they share beside the ranks' other kernels: rehearse the N-rank flow with --hidden 64 and at most {cus // (4 * 32)} ranks")
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
