@@ -261,6 +261,7 @@ constexpr int SEQ_COUNTER_TOTAL = 2 * MAXD * 4 * SEQ_COUNTER_WORDS;   // all lau
 // fault injection for the tests (KBJ_DEBUG_DROP_SEQ_WG = n at kbj_create): the next n forward-recurrence launches run with one
 // workgroup missing, so its partners' bounded spins expire and the timeout / fail-stop path is exercised on real hardware
 int g_seq_drop = 0;
+int g_seq_drop_bwd = 0;   // the same for the backward recurrences (KBJ_DEBUG_DROP_SEQ_BWD_WG = n)
 unsigned g_seq_spin_limit = SEQ_SPIN_LIMIT;
 template <int H, int UW> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a0) {
   SeqFwdArgs a = a0;
@@ -298,7 +299,8 @@ int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {   // a.c
 template <int H> void seq_bwd16_launch(hipStream_t s, const SeqBwdArgs& a0) {
   SeqBwdArgs a = a0;
   a.spin_limit = g_seq_spin_limit;
-  const int grid = (H / BWD16_UNITS) * ((a.B + BWD16_ROWS - 1) / BWD16_ROWS);
+  int grid = (H / BWD16_UNITS) * ((a.B + BWD16_ROWS - 1) / BWD16_ROWS);
+  if (g_seq_drop_bwd > 0 && grid > 1 && H > BWD16_UNITS) { --g_seq_drop_bwd; --grid; }   // fault injection (a launch without partners has nobody to time out)
   hipLaunchKernelGGL((lstm_seq_bwd16_kernel<H>), dim3(grid), dim3(BWD16_NTH), 0, s, a);
 }
 // row groups of a backward-recurrence launch (deterministic mode: rows of its per-row-group bias partials)
@@ -561,7 +563,8 @@ int kbj_nn_create(kbj_ctx* ctx) {
     }
   }
   g_seq_drop = getenv("KBJ_DEBUG_DROP_SEQ_WG") ? atoi(getenv("KBJ_DEBUG_DROP_SEQ_WG")) : 0;
-  g_seq_spin_limit = g_seq_drop > 0 ? (1u << 15) : SEQ_SPIN_LIMIT;   // an injected fault should not cost the full 2^24-spin bound
+  g_seq_drop_bwd = getenv("KBJ_DEBUG_DROP_SEQ_BWD_WG") ? atoi(getenv("KBJ_DEBUG_DROP_SEQ_BWD_WG")) : 0;
+  g_seq_spin_limit = (g_seq_drop > 0 || g_seq_drop_bwd > 0) ? (1u << 15) : SEQ_SPIN_LIMIT;   // an injected fault should not cost the full 2^24-spin bound
   // Residency of the persistent recurrences: the workgroups of one launch spin on each other, and kbj_ppo_grad keeps TWO launches
   // (actor-type and critic-type net, one per stream; the mirror branches queue behind them on the same two streams) in flight, so
   // 2 x grid workgroups must be resident at once. Every other kernel of the schedule (GEMMs, heads) terminates on its own, so it can

@@ -201,16 +201,19 @@ def test_launch_writes_logs_and_checkpoint(tmp_path):
     task.ctx.close()
 
 
-def test_recurrence_timeout_is_fail_stop(monkeypatch):
-    """Fault injection: the first forward recurrence of the update is launched with one workgroup missing, so its partners' bounded
-    spins expire. The gradient is poisoned on the device, the optimizer step is skipped (parameters and moments unchanged), the
-    error surfaces as KbjError at the iteration's synchronisation point, and the context stays usable and destroyable."""
+@pytest.mark.parametrize("which", ["forward", "backward"])
+def test_recurrence_timeout_is_fail_stop(monkeypatch, which):
+    """Fault injection: the first forward (or backward: lstm_seq_bwd16_kernel, hidden 128 = two partners per row group) recurrence of the
+    update is launched with one workgroup missing, so its partners' bounded spins expire. The gradient is poisoned on the device, the
+    optimizer step is skipped (parameters and moments unchanged), the error surfaces as KbjError at the iteration's synchronisation point,
+    and the context stays usable and destroyable."""
     import torch
     from kbot_joystick_amd.host import binding as B
     from kbot_joystick_amd.host.task import HumanoidWalkingTask
-    monkeypatch.setenv("KBJ_DEBUG_DROP_SEQ_WG", "1")
-    task = HumanoidWalkingTask(_small(num_envs=64, batch_size=64))
-    monkeypatch.delenv("KBJ_DEBUG_DROP_SEQ_WG")
+    var = "KBJ_DEBUG_DROP_SEQ_WG" if which == "forward" else "KBJ_DEBUG_DROP_SEQ_BWD_WG"
+    monkeypatch.setenv(var, "1")
+    task = HumanoidWalkingTask(_small(num_envs=64, batch_size=64, hidden_size=64 if which == "forward" else 128))
+    monkeypatch.delenv(var)
     p0 = task.params.clone()
     with pytest.raises(B.KbjError, match="timed out"):
         task.train_iteration()
