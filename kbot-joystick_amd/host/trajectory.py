@@ -4,7 +4,8 @@ The reference's reward classes read a `ksim.Trajectory` by attribute (`/root/ref
 301-306, 316-334, 377-388, 418-457, 466-478, 487-494, 503-506`): `trajectory.qpos`, `.qvel`, `.xpos[:, body]`, `.xquat[:, body]`, `.ctrl`,
 `.done`, `.obs["left_foot_touch"]`, `.obs["com_distance"]`, `.command["unified_command"]`. `Trajectory` below carries exactly those names
 for one rollout of ALL envs - every field is `[T, N, ...]` where the reference's (vmapped over envs) is `[T, ...]`, so a term written with
-`[..., idx]` / `axis=-1` as the reference's are runs unchanged; `[:, idx]` on the time axis becomes `[..., idx, :]` on the body axis.
+`[..., idx]` / `axis=-1` as the reference's are runs unchanged; `[:, idx]` on the time axis becomes `[..., idx, :]` on the body axis - or the body
+runs unchanged through `per_env(fn)`, which hands it ksim's per-env `[T, ...]` view under `torch.vmap` (as ksim does under `jax.vmap`).
 
 Where the fields come from (nothing here is on the hot path; all of it is torch on the device):
   * `qpos [T,N,27]`, `qvel [T,N,26]`: the per-step state record the env kernel writes when asked to (`kbj_traj.qstate_d`,
@@ -104,7 +105,8 @@ def forward_kinematics(model, qpos: torch.Tensor) -> Tuple[torch.Tensor, torch.T
 
 class Trajectory(TrajectoryView):
     """ksim.Trajectory's field names for one rollout, `[T, N, ...]` on the device (module docstring). Also a `TrajectoryView`: terms written
-    against the older vocabulary (`base_qvel`, `arm_qpos`, ...) keep working."""
+    against the older vocabulary (`base_qvel`, `arm_qpos`, ...) keep working - except for `command` and `done`, which take ksim's form here (a dict
+    keyed "unified_command"; bool, with the signed value in `done_signed`). `per_env(fn)` below gives a term ksim's per-env `[T, ...]` view."""
 
     def __init__(self, traj, T: int, model, extra_observations: Optional[Dict[str, torch.Tensor]] = None):
         super().__init__(traj, T)
@@ -168,6 +170,36 @@ class Trajectory(TrajectoryView):
     @property
     def xquat(self) -> torch.Tensor:
         return self._kinematics()[1]
+
+
+class EnvTrajectory:
+    """One env's slice of a `Trajectory` as ksim hands it to a reward term: every field `[T, ...]` (train.py's `trajectory.xquat[:, 1, :]`,
+    `traj.obs["left_foot_touch"][:, 0]`, `jnp.pad(trajectory.done, ((1, 0),))` index THIS shape). Built by `per_env`."""
+
+    def __init__(self, fields: dict):
+        self.qpos, self.qvel, self.xpos, self.xquat = fields["qpos"], fields["qvel"], fields["xpos"], fields["xquat"]
+        self.ctrl, self.done, self.action, self.reward = fields["ctrl"], fields["done"], fields["action"], fields["reward"]
+        self.obs, self.command = fields["obs"], fields["command"]
+
+
+def per_env(fn):
+    """ksim evaluates a reward term per env under `jax.vmap`: the term sees `[T, ...]` fields. `per_env(fn)(trajectory)` does the same with
+    `torch.vmap` over the env axis of a `[T, N, ...]` Trajectory - a `get_reward` body written exactly as the reference's (time-first indexing,
+    `axis=-1` reductions, `where` instead of Python branches on values, as under jax) runs unchanged and returns `[T, N]`:
+
+        class MyReward:            # body as it would be in train.py, jnp -> torch
+            scale = 0.1
+            def get_reward(self, trajectory):
+                return per_env(self._one)(trajectory)
+            def _one(self, traj):  # traj.qvel is [T, 26], traj.xquat[:, 1, :] the base orientation per step
+                return torch.exp(-traj.qvel[:, 5].abs())
+    """
+    def run(trajectory: "Trajectory") -> torch.Tensor:
+        fields = dict(qpos=trajectory.qpos, qvel=trajectory.qvel, xpos=trajectory.xpos, xquat=trajectory.xquat, ctrl=trajectory.ctrl, done=trajectory.done,
+                      action=trajectory.action, reward=trajectory.reward, obs=dict(trajectory.obs), command=dict(trajectory.command))
+        out = torch.vmap(lambda f: fn(EnvTrajectory(f)), in_dims=1, out_dims=1)(fields)
+        return out
+    return run
 
 
 # ---- the reference's reward classes (train.py:125-506) on `Trajectory`: attribute names, constructor arguments and arithmetic as there ----

@@ -379,6 +379,25 @@ def test_reference_reward_classes_on_a_ksim_shaped_trajectory_match_the_oracle(m
             assert err < 2e-4, (rollout, name, err)
             total += term.scale * r
         assert float((total - torch.from_numpy(rew)).abs().max()) < 2e-4
+    # per_env: reward bodies written time-first, exactly as the reference's (train.py:316-334, 487-494: `trajectory.xquat[:, 1, :]`, `jnp.pad(..., ((1, 0), (0, 0)),
+    # mode="edge")`), evaluated per env under torch.vmap as ksim evaluates them under jax.vmap - bit-equal to the batched classes
+    def xy_orientation(traj):
+        e = TJ.quat_to_euler(traj.xquat[:, 1, :])
+        base_xy_quat = TJ.euler_to_quat(torch.cat([e[:, :2], torch.zeros_like(e[:, 2:])], dim=-1))
+        cmd = traj.command["unified_command"]
+        cmd_quat = TJ.euler_to_quat(torch.stack([cmd[:, 4], cmd[:, 5], torch.zeros_like(cmd[:, 5])], dim=-1))
+        quat_error = 1 - (cmd_quat * base_xy_quat).sum(dim=-1) ** 2
+        is_zero_cmd = torch.linalg.norm(cmd[:, :3], dim=-1) < 1e-3
+        return torch.exp(-quat_error / torch.where(is_zero_cmd, 0.01, 0.03))
+
+    def base_acceleration(traj):
+        base_vel = traj.qvel[:, :6]
+        padded = torch.cat([base_vel[:1], base_vel], dim=0)
+        done_padded = torch.cat([traj.done[:1], traj.done], dim=0)
+        acc = torch.where(done_padded[:-1, None], torch.zeros_like(base_vel), padded[1:] - padded[:-1])
+        return torch.exp(-acc.abs().sum(dim=-1) / 5.0)
+    assert torch.equal(TJ.per_env(xy_orientation)(tr), terms["roll_pitch"].get_reward(tr))
+    assert torch.equal(TJ.per_env(base_acceleration)(tr), terms["base_accel"].get_reward(tr))
     with pytest.raises(ValueError, match="record_state"):
         TJ.Trajectory(types.SimpleNamespace(aux=torch.zeros(2, 1, A["SIZE"]), qstate=None, action=torch.zeros(1, 1, 20), actor_obs=torch.zeros(2, 1, L.LD_ACTOR),
                                             critic_obs=torch.zeros(2, 1, L.LD_CRITIC)), 1, m)
