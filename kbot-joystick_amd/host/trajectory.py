@@ -381,6 +381,39 @@ class TorqueReward(_Reward):                           # train.py:497-506
         return torch.where(_zero_cmd(trajectory), r, torch.ones_like(r))
 
 
+def build_reward(name: str, scale: float, params: Dict[str, float], model) -> _Reward:
+    """One entry of `task.get_rewards()` (host/wiring.RewardSpec: the name, scale and constructor arguments COMPILED into kbj_config, user
+    overrides included) as the executable torch term of the same class the reference builds for that key (train.py:1224-1256)."""
+    base, lfoot, rfoot = int(model.base_body), int(model.lfoot_body), int(model.rfoot_body)
+    p = dict(params)
+    if name == "linvel":
+        return LinearVelocityTrackingReward(scale=scale, **p)
+    if name == "angvel":
+        return AngularVelocityReward(scale=scale, **p)
+    if name == "roll_pitch":
+        return XYOrientationReward(scale=scale, **p)
+    if name == "base_height":
+        return TerrainBaseHeightReward(base_idx=base, foot_left_idx=lfoot, foot_right_idx=rfoot, scale=scale, **p)
+    if name == "arm_pos":
+        idx = list(range(10, 20))                 # the ten arm joints in joint order = the reference's joint_names (train.py:236-247)
+        return ArmPositionReward(idx, [float(model.joint_bias[i]) for i in idx], scale=scale, **p)
+    if name == "single_contact":
+        return SingleFootContactReward(scale=scale, **p)
+    if name == "no_contact_p":
+        return NoContactPenalty(scale=scale)
+    if name == "feet_airtime":
+        return FeetAirtimeReward(scale=scale, **p)
+    if name == "feet_orient":
+        return FeetOrientationReward(foot_left_idx=lfoot, foot_right_idx=rfoot, scale=scale, **p)
+    if name == "com_distance":
+        return COMDistanceReward(scale=scale, **p)
+    if name == "base_accel":
+        return BaseAccelerationReward(scale=scale, **p)
+    if name == "torque":
+        return TorqueReward(scale=scale, **p)
+    raise KeyError(f"unknown reward {name!r}; known: {constants.REWARD_NAMES}")
+
+
 def reference_rewards(model, ctrl_dt: float = 0.02) -> Dict[str, _Reward]:
     """train.py:1224-1256 `get_rewards()`: same keys, order, classes and constructor arguments, built against the model blob instead of the
     mujoco model (body ids and joint order are MuJoCo's: kbj_model.h)."""

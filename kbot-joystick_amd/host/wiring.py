@@ -95,6 +95,14 @@ class RewardSpec:               # train.py:1224-1256
     scale: float
     params: Dict[str, float] = field(default_factory=dict)
 
+    def build(self, model):
+        """This entry as an executable reward term in ksim's protocol (`scale`, `get_reward(trajectory)` / `initial_carry`,
+        `get_reward_stateful`): the class the reference constructs for this key (train.py:1224-1256), restated in torch on
+        `host/trajectory.Trajectory`, with THIS configuration's scale and constructor arguments. The kernel (`rewards_kernel`) remains
+        what the task runs; the built term is what a user edits and passes back as `extra_rewards` (with the built-in scale set to 0)."""
+        from .trajectory import build_reward
+        return build_reward(self.name, self.scale, self.params, model)
+
 
 @dataclass(frozen=True)
 class TerminationSpec:          # train.py:1258-1269

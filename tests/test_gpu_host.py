@@ -741,5 +741,23 @@ def test_reference_reward_classes_on_the_trajectory_reproduce_the_kernel(size):
     assert type(t3.trajectory()).__name__ == "TrajectoryView"
     with pytest.raises(ValueError, match="record_state"):
         TJ.Trajectory(t3.traj, t3.T, t3.model_blob)
-    for t in (task, t1, t2, t3):
+    # get_rewards() entries are executable: an EDITED reward table (reward_scales / reward_params) built into torch terms reproduces the kernel that
+    # runs the same table; and a user replaces a built-in term by zeroing its scale and passing the built (then edited) term as an extra reward
+    edits = dict(reward_scales={"feet_airtime": 2.0, "torque": 0.0}, reward_params={"base_height": {"standard_height": 0.85, "error_scale": 0.05},
+                                                                                     "single_contact": {"grace_period": 0.5}, "linvel": {"error_scale": 0.3}})
+    t4 = HumanoidWalkingTask(_small(num_envs=128, rollout_length_seconds=1.0, record_state=True, log_reward_components=True, seed=9, **edits))
+    built = {k: spec.build(t4.model_blob) for k, spec in t4.get_rewards().items()}
+    assert built["feet_airtime"].scale == 2.0 and built["base_height"].standard_height == pytest.approx(0.85) and built["single_contact"].grace_period == pytest.approx(0.5)
+    t4.rollout(); t4.ctx.synchronize()
+    tr4, total, carries4 = t4.trajectory(), torch.zeros_like(t4.traj.reward), {}
+    for k, (name, term) in enumerate(built.items()):
+        r = term.get_reward_stateful(tr4, term.initial_carry(128, t4.device))[0] if hasattr(term, "get_reward_stateful") else term.get_reward(tr4)
+        assert float((r - t4.traj.comps[..., k]).abs().max()) < 2e-4, name
+        total += term.scale * r
+    assert float((total - t4.traj.reward).abs().max()) < 2e-4
+    swapped = dict(edits, reward_scales=dict(edits["reward_scales"], base_height=0.0))
+    t5 = HumanoidWalkingTask(_small(num_envs=128, rollout_length_seconds=1.0, record_state=True, seed=9, **swapped), extra_rewards={"base_height": built["base_height"]})
+    t5.rollout(); t5.ctx.synchronize()
+    assert float((t5.traj.reward - t4.traj.reward).abs().max()) < 2e-4       # the torch term in place of the kernel's: the same reward
+    for t in (task, t1, t2, t3, t4, t5):
         t.close()
