@@ -388,13 +388,14 @@ class HumanoidWalkingTask:
         for t in range(T):
             c.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], self.carry.c, self.config.seed, first + t, False, tr.action[t], tr.logp[t], tr.value[t])
             c.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], tr.qstate[t] if tr.qstate is not None else None)
-            view = StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob)
+            qs_t = tr.qstate[t] if tr.qstate is not None else None
+            view = StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob, qs_t)
             if self.extra_terminations:
                 user = combine_terminations(self.extra_terminations, view)
                 fire = (user != 0) & (tr.aux[t][:, L.AUX["DONE"]] == 0)          # the kernel's own terminations already reset their envs
                 c.env_reset_where(fire.to(torch.float32), tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
                 tr.aux[t][:, L.AUX["DONE"]] = torch.where(fire, user, tr.aux[t][:, L.AUX["DONE"]])
-                view = StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob)
+                view = StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob, qs_t)
             if self.command_term is not None:
                 update_command(t + 1, view, tr.aux[t][:, L.AUX["DONE"]] != 0)
             if self.extra_observations:

@@ -77,9 +77,10 @@ class StepView:
             cls._joint_tables[key] = (bias, rng)
         return cls._joint_tables[key]
 
-    def __init__(self, aux_t: torch.Tensor, actor_next: torch.Tensor, critic_next: torch.Tensor, aux_next: torch.Tensor, model):
+    def __init__(self, aux_t: torch.Tensor, actor_next: torch.Tensor, critic_next: torch.Tensor, aux_next: torch.Tensor, model, qstate_t: torch.Tensor = None):
         A, O = L.AUX, L.OBS
         self.N = aux_t.shape[0]
+        self._model, self._qstate, self._kin = model, qstate_t, None
         # ---- post-step, pre-reset (what the kernel's own terminations and the reward stack read) ----
         self.base_qvel = aux_t[:, A["QVEL"]:A["QVEL"] + 6]
         self.base_quat = aux_t[:, A["BQUAT"]:A["BQUAT"] + 4]
@@ -111,6 +112,52 @@ class StepView:
         self.base_height = piece("HEIGHT")[:, 0]
         self.com_distance = aux_next[:, A["COMDIST"]]
         self.actor_obs, self.critic_obs = actor_next[:, :L.NOBS_ACTOR], critic_next[:, :L.NOBS_CRITIC]
+
+
+    # ---- ksim's physics_data names (train.py:817-823 reads `state.xpos[body, 2]`): available when the task records the step state
+    # (HumanoidWalkingTaskConfig.record_state -> kbj_env_record_state); [N, ...] here, [...] per env under per_env_state() ----
+    def _need_state(self):
+        if self._qstate is None:
+            raise ValueError("state.qpos / .qvel / .xpos / .xquat need the per-step state record: HumanoidWalkingTaskConfig(record_state=True)")
+        return self._qstate
+
+    @property
+    def qpos(self) -> torch.Tensor:
+        q = self._need_state()
+        return q[:, L.QSTATE["QPOS"]:L.QSTATE["QPOS"] + L.NQ]
+
+    @property
+    def qvel(self) -> torch.Tensor:
+        q = self._need_state()
+        return q[:, L.QSTATE["QVEL"]:L.QSTATE["QVEL"] + L.NV]
+
+    def _kinematics(self):
+        if self._kin is None:
+            from .trajectory import forward_kinematics
+            q = self._need_state()
+            xp, xq = forward_kinematics(self._model, q[:, L.QSTATE["QPOS_KIN"]:L.QSTATE["QPOS_KIN"] + L.NQ])
+            self._kin = (xp.to(torch.float32), xq.to(torch.float32))
+        return self._kin
+
+    @property
+    def xpos(self) -> torch.Tensor:
+        """[N, nbody, 3]: body positions of the step's last forward pass (what the kernel's own terminations read)."""
+        return self._kinematics()[0]
+
+    @property
+    def xquat(self) -> torch.Tensor:
+        return self._kinematics()[1]
+
+
+def per_env_state(fn):
+    """A Termination body written per env, exactly as the reference's (`state.xpos[self.base_idx, 2]`, train.py:817-823), over all envs of a StepView
+    under torch.vmap: `per_env_state(body)(state, curriculum_level) -> [N]`."""
+    import types
+
+    def run(state: "StepView", curriculum_level=1.0) -> torch.Tensor:
+        fields = dict(qpos=state.qpos, qvel=state.qvel, xpos=state.xpos, xquat=state.xquat)
+        return torch.vmap(lambda f: fn(types.SimpleNamespace(**f), curriculum_level), in_dims=0)(fields)
+    return run
 
 
 def combine_terminations(terms: Dict[str, object], view: StepView, curriculum_level: float = 1.0) -> torch.Tensor:

@@ -371,6 +371,37 @@ def test_python_termination_and_observation_terms():
     with pytest.raises(KeyError):
         _small(termination_params={"bad_z": {"nope": 1.0}}).to_kbj(64)
     stock.ctx.close(); user.ctx.close()
+    # with record_state the term can be the reference's body as written (train.py:817-823: `state.xpos[self.base_idx, 2]` per env), evaluated per
+    # env under torch.vmap: the same DONE column as the kernel's own bad-z termination
+    from kbot_joystick_amd.host.traj_view import per_env_state
+
+    class TerrainBadZTermination:
+        def __init__(self, base_idx, foot_left_idx, foot_right_idx, unhealthy_z):
+            self.base_idx, self.foot_left_idx, self.foot_right_idx, self.unhealthy_z = base_idx, foot_left_idx, foot_right_idx, unhealthy_z
+
+        def _one(self, state, curriculum_level):
+            base_z = state.xpos[self.base_idx, 2]
+            left_foot_z = state.xpos[self.foot_left_idx, 2]
+            right_foot_z = state.xpos[self.foot_right_idx, 2]
+            height = base_z - torch.minimum(left_foot_z, right_foot_z)
+            return torch.where(height < self.unhealthy_z, -1, 0)
+
+        def __call__(self, state, curriculum_level):
+            return per_env_state(self._one)(state, curriculum_level)
+    stock2 = HumanoidWalkingTask(_small(**kw))
+    mb = stock2.model_blob
+    ref = HumanoidWalkingTask(_small(termination_params={"bad_z": {"unhealthy_z": float("-inf")}}, record_state=True, **kw),
+                              extra_terminations={"bad_z": TerrainBadZTermination(int(mb.base_body), int(mb.lfoot_body), int(mb.rfoot_body), 0.4)})
+    for it in range(2):
+        stock2.rollout(); ref.rollout()
+        torch.cuda.synchronize()
+        assert torch.equal(stock2.traj.aux, ref.traj.aux) and torch.equal(stock2.traj.action, ref.traj.action), it
+        stock2.iteration += 1; ref.iteration += 1
+    assert int((ref.traj.done < 0).sum()) > 5
+    with pytest.raises(ValueError, match="record_state"):
+        from kbot_joystick_amd.host.traj_view import StepView
+        StepView(stock2.traj.aux[0], stock2.traj.actor_obs[1], stock2.traj.critic_obs[1], stock2.traj.aux[1], mb).xpos
+    stock2.close(); ref.close()
 
 
 def test_python_command_term():
