@@ -77,6 +77,15 @@ int kbj_env_reset_where(kbj_ctx* ctx, const float* mask_d, float* actor_next_d, 
  * their joystick command - in the env state (the next kbj_env_step starts from it; run with command_mode = 1 so the kernel's own
  * switch draw does not replace it) and in the command columns + zero-command flag of the NEXT observation rows and aux record. */
 int kbj_env_set_command(kbj_ctx* ctx, const float* mask_d, const float* cmd_d, float* actor_next_d, float* critic_next_d, float* aux_next_d);
+/* replaces: user-written Reset terms in the reference's protocol (`Reset.__call__(data, curriculum_level, rng) -> data`, train.py:833-844: the in-tree
+ * PlaneXYPositionReset reads `data.qpos` and returns the data with a new one), evaluated by the host on the envs that have just been re-initialised
+ * (by the step kernel's own terminations, kbj_env_reset_where or kbj_env_reset_all), AFTER the built-in resets of train.py:1146-1153 as in the
+ * reference's list order. kbj_env_get_qstate copies every env's generalised positions / velocities into DEVICE arrays (qpos_d [N][27], qvel_d [N][26];
+ * asynchronous, on the context's stream); kbj_env_set_qstate writes them back for the envs with a non-zero mask_d entry (NULL = all), clears their
+ * solver warm start, re-runs the forward pass of the new state (kinematics, sensors, lagged projected gravity) and rewrites their NEXT observation
+ * rows and aux record, exactly as the reset path does for the state it draws itself. Episode counter, randomised parameters and command are untouched. */
+int kbj_env_get_qstate(kbj_ctx* ctx, float* qpos_d, float* qvel_d);
+int kbj_env_set_qstate(kbj_ctx* ctx, const float* mask_d, const float* qpos_d, const float* qvel_d, float* actor_next_d, float* critic_next_d, float* aux_next_d);
 /* state save/restore (checkpointing, tests): ep [N][KBJ_EP_SIZE], es [N][KBJ_ES_SIZE]; synchronous */
 int kbj_env_get_state(kbj_ctx* ctx, float* ep_h, float* es_h);
 int kbj_env_set_state(kbj_ctx* ctx, const float* ep_h, const float* es_h);

@@ -52,6 +52,48 @@ __global__ __launch_bounds__(64) void env_reset_where_kernel(const kbj_model* __
   PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
 }
 
+// user-written Reset terms (train.py:833-844 protocol): the generalised state of every env as device arrays ...
+__global__ __launch_bounds__(256) void env_get_qstate_kernel(int N, const float* __restrict__ es, float* __restrict__ qpos, float* __restrict__ qvel) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, env = i / 64, k = i % 64;
+  if (env >= N) return;
+  if (k < KBJ_NQ) qpos[(size_t)env * KBJ_NQ + k] = es[(size_t)env * KBJ_ES_SIZE + KBJ_ES_QPOS + k];
+  if (k < KBJ_NV) qvel[(size_t)env * KBJ_NV + k] = es[(size_t)env * KBJ_ES_SIZE + KBJ_ES_QVEL + k];
+}
+// ... and back for the masked envs: new positions / velocities, cleared warm start, then what task_reset does behind the state it draws itself -
+// one forward pass (PD on the held action, kinematics, sensors), the lagged projected gravity re-seeded, the next observation rows rewritten
+__global__ __launch_bounds__(64) void env_set_qstate_kernel(const kbj_model* __restrict__ m, const kbj_config* __restrict__ c, const float* __restrict__ mc, const PhysConst* __restrict__ pcp, uint32_t seed,
+                                                            float* __restrict__ ep, float* __restrict__ es, const float* __restrict__ mask, const float* __restrict__ qpos,
+                                                            const float* __restrict__ qvel, float* actor_next, float* critic_next, float* aux_next) {
+  __shared__ KbjShared S;
+  const int env = blockIdx.x;
+  if (mask && mask[env] == 0.0f) return;     // uniform over the workgroup
+  PFOR(k, (int)(sizeof(KbjModelLds) / sizeof(float))) reinterpret_cast<float*>(&S.mc)[k] = mc[k];
+  PFOR(k, (int)(sizeof(PhysConst) / sizeof(float))) reinterpret_cast<float*>(&S.pc)[k] = reinterpret_cast<const float*>(pcp)[k];
+  PFOR(k, KBJ_EP_SIZE) S.ep[k] = ep[(size_t)env * KBJ_EP_SIZE + k];
+  PFOR(k, KBJ_ES_SIZE) S.es[k] = es[(size_t)env * KBJ_ES_SIZE + k];
+  PFOR(k, 12) S.zrow[k] = 0;
+  KBJ_SYNC();
+  PFOR(k, KBJ_NQ) S.es[KBJ_ES_QPOS + k] = qpos[(size_t)env * KBJ_NQ + k];
+  PFOR(k, KBJ_NV) { S.es[KBJ_ES_QVEL + k] = qvel[(size_t)env * KBJ_NV + k]; S.es[KBJ_ES_WARM + k] = 0; }
+  KBJ_SYNC();
+  PFOR(w, 1) {   // a unit base quaternion whatever the term returned
+    float* q = S.es + KBJ_ES_QPOS + 3;
+    const float n = sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    if (!(n > 0)) { q[0] = 1; q[1] = q[2] = q[3] = 0; }
+    else if (fabsf(n - 1.0f) > 1e-6f) { q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n; }     // (a term that leaves the state alone leaves its bits alone)
+    S.pushing = 0;
+  }
+  KBJ_SYNC();
+  Rng rng{seed, (uint32_t)(c->env_id_offset + env)};
+  const PhysConst& pc = S.pc;
+  task_pd(S, S.es + KBJ_ES_ACT_PREV);
+  phys_forward(S, S.mc, pc);
+  PFOR(k, 3) S.es[KBJ_ES_PGLAG + k] = S.pg[k];
+  KBJ_SYNC();
+  task_write_obs(S, *m, *c, rng, actor_next + (size_t)env * KBJ_LD_OF(KBJ_NOBS_ACTOR + c->extra_obs_actor), critic_next + (size_t)env * KBJ_LD_OF(KBJ_NOBS_CRITIC + c->extra_obs_critic), aux_next + (size_t)env * KBJ_AUX_SIZE);
+  PFOR(k, KBJ_ES_SIZE) es[(size_t)env * KBJ_ES_SIZE + k] = S.es[k];
+}
+
 // overwrite the joystick command of the envs whose mask entry is non-zero (mask == nullptr: all envs): the env's state row (the next step's
 // rewards and its command-switch draw start from it) and the command columns of the NEXT observation rows + aux record, zero-command flag
 // included — what task_write_obs wrote there from the kernel's own command. One thread per (env, command slot).
@@ -304,6 +346,25 @@ int kbj_env_set_command(kbj_ctx* ctx, const float* mask_d, const float* cmd_d, f
   hipLaunchKernelGGL(env_set_command_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, N, KBJ_LD_OF(KBJ_NOBS_ACTOR + ctx->cfg_h.extra_obs_actor),
                      KBJ_LD_OF(KBJ_NOBS_CRITIC + ctx->cfg_h.extra_obs_critic), ctx->es_d, mask_d, cmd_d, actor_next_d, critic_next_d, aux_next_d);
   KBJ_CHECK_LAUNCH(ctx, "env_set_command_kernel");
+  return 0;
+}
+
+int kbj_env_get_qstate(kbj_ctx* ctx, float* qpos_d, float* qvel_d) {
+  if (!ctx || !qpos_d || !qvel_d) return kbj_fail(ctx, "kbj_env_get_qstate: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  const int N = ctx->cfg_h.num_envs;
+  hipLaunchKernelGGL(env_get_qstate_kernel, dim3((N * 64 + 255) / 256), dim3(256), 0, ctx->stream, N, ctx->es_d, qpos_d, qvel_d);
+  KBJ_CHECK_LAUNCH(ctx, "env_get_qstate_kernel");
+  return 0;
+}
+
+int kbj_env_set_qstate(kbj_ctx* ctx, const float* mask_d, const float* qpos_d, const float* qvel_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {
+  if (!ctx || !qpos_d || !qvel_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_set_qstate: null argument");
+  KBJ_HIP(ctx, hipSetDevice(ctx->device));
+  kbj_nn_drop_prefetch(ctx);
+  hipLaunchKernelGGL(env_set_qstate_kernel, dim3(ctx->cfg_h.num_envs), dim3(64), 0, ctx->stream, ctx->model_d, ctx->cfg_d, ctx->mc_d, (const PhysConst*)ctx->pc_d, ctx->seed, ctx->ep_d, ctx->es_d,
+                     mask_d, qpos_d, qvel_d, actor_next_d, critic_next_d, aux_next_d);
+  KBJ_CHECK_LAUNCH(ctx, "env_set_qstate_kernel");
   return 0;
 }
 

@@ -63,6 +63,8 @@ SIGNATURES = {
     "kbj_env_record_state": (_i, [_vp, _vp]),
     "kbj_env_reset_where": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "kbj_env_set_command": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "kbj_env_get_qstate": (_i, [_vp, _vp, _vp]),
+    "kbj_env_set_qstate": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "kbj_env_get_state": (_i, [_vp, _vp, _vp]),
     "kbj_env_set_state": (_i, [_vp, _vp, _vp]),
     "kbj_env_get_reward_carry": (_i, [_vp, _vp]),
@@ -199,6 +201,14 @@ class Context:
     def env_set_command(self, mask, cmd, actor_next, critic_next, aux_next):
         """mask None = every env; cmd [N, 16] float32 on the device."""
         self.call("kbj_env_set_command", _ptr(mask) if mask is not None else None, _ptr(cmd), _ptr(actor_next), _ptr(critic_next), _ptr(aux_next))
+
+    def env_get_qstate(self, qpos, qvel):
+        """kbj_env_get_qstate: every env's qpos [N, 27] / qvel [N, 26] into device tensors (asynchronous)."""
+        self.call("kbj_env_get_qstate", _ptr(qpos), _ptr(qvel))
+
+    def env_set_qstate(self, mask, qpos, qvel, actor_next, critic_next, aux_next):
+        """kbj_env_set_qstate: new qpos / qvel for the masked envs (None = all) + their next observation rows rewritten."""
+        self.call("kbj_env_set_qstate", _ptr(mask) if mask is not None else None, _ptr(qpos), _ptr(qvel), _ptr(actor_next), _ptr(critic_next), _ptr(aux_next))
 
     def env_get_state(self):
         import numpy as np

@@ -194,7 +194,7 @@ class HumanoidWalkingTask:
 
     def __init__(self, config: HumanoidWalkingTaskConfig, device: Optional[torch.device] = None, rank: int = 0, world_size: int = 1,
                  extra_rewards: Optional[dict] = None, extra_terminations: Optional[dict] = None, extra_observations: Optional[dict] = None,
-                 command=None):
+                 command=None, extra_resets: Optional[list] = None):
         """extra_rewards: {name: term} of Python reward terms in ksim's Reward protocol (`scale`, `get_reward(trajectory)` or the stateful
         pair), evaluated on `TrajectoryView` after every rollout and added to the built-in stack's reward (host/traj_view.py).
         extra_terminations: {name: term}, `term(state, curriculum_level) -> [N] in {-1, 0, 1}` (train.py:817) on a `StepView` after every
@@ -207,7 +207,11 @@ class HumanoidWalkingTask:
         `command(prev_command, state, curriculum_level, rng) -> [N, 16]` for the running ones, evaluated on the device after every
         control step and written into the env state and the next observation rows by kbj_env_set_command (`rng` is a torch.Generator of
         the task's device, seeded from (seed, step index)). The library then runs with command_mode = 1 so its own switch draw stays off.
-        With any of the three the rollout runs step by step from the host (policy step, env step, user terms, carry reset: the same calls
+        extra_resets: a LIST of terms in the reference's Reset protocol (train.py:833-844: `term(data, curriculum_level, rng) -> data` with
+        `data.qpos` / `data.qvel`), applied in list order - behind the built-in resets of train.py:1146-1153, as further entries of that list would
+        be - to the envs that have just been re-initialised; the result is written back by kbj_env_set_qstate, which also rewrites their next
+        observation rows (host/traj_view.ResetData; `rng` is a torch.Generator seeded from (seed, step index)).
+        With any of these the rollout runs step by step from the host (policy step, env step, user terms, carry reset: the same calls
         kbj_rollout fuses, bit-identical when no user term fires) instead of as one kbj_rollout call."""
         self.extra_rewards = dict(extra_rewards or {})
         self.extra_terminations = dict(extra_terminations or {})
@@ -225,6 +229,8 @@ class HumanoidWalkingTask:
         self._obs_started = False
         self.command_term = command
         self._command_started = False
+        self.extra_resets = list(extra_resets or [])
+        self._resets_started = False
         self.extra_obs_buffers: dict = {}
         self._extra_carries: dict = {}
         self.extra_reward_means: dict = {}
@@ -293,7 +299,7 @@ class HumanoidWalkingTask:
     # ---- the hot path ----
     def rollout(self):
         """T control steps of all envs, trajectory + rewards on the device."""
-        if self.extra_terminations or self.extra_observations or self.command_term is not None:
+        if self.extra_terminations or self.extra_observations or self.command_term is not None or self.extra_resets:
             self._rollout_stepwise()
         else:
             self.ctx.rollout(self.params, self.carry.c, self.config.seed, self.iteration * self.T, self.traj.c)
@@ -328,6 +334,24 @@ class HumanoidWalkingTask:
         if not all_fresh:
             new = torch.where(fresh[:, None], new, term(prev, view, 1.0, g).reshape(n, L.NCMD).to(torch.float32))
         ctx.env_set_command(None, new.contiguous(), tr.actor_obs[row], tr.critic_obs[row], tr.aux[row])
+
+    def _apply_resets(self, ctx, tr, row: int, fresh, step_index: int):
+        """The user's Reset terms (train.py:833-844) for observation row `row` of `tr`: evaluated on every env's (qpos, qvel), kept for the envs
+        whose episode starts there (`fresh` [N] bool, None = all), written back - with the rows of the next observation - by kbj_env_set_qstate."""
+        from .traj_view import ResetData
+        n = tr.aux[row].shape[0]
+        qpos, qvel = torch.empty(n, L.NQ, device=self.device), torch.empty(n, L.NV, device=self.device)
+        ctx.env_get_qstate(qpos, qvel)
+        g = torch.Generator(device=self.device)
+        g.manual_seed((self.config.seed * 2246822519 + step_index * 3266489917 + self.rank) & 0x7FFFFFFFFFFFFFFF)
+        data = ResetData(qpos, qvel)
+        for term in self.extra_resets:
+            data = term(data, 1.0, g)
+        new_q = data.qpos.reshape(n, L.NQ).to(torch.float32).contiguous()
+        new_v = data.qvel.reshape(n, L.NV).to(torch.float32).contiguous()
+        self._reset_keep = (new_q, new_v)          # alive until the kernel has run (stream-ordered)
+        mask = None if fresh is None else fresh.to(torch.float32)
+        ctx.env_set_qstate(mask, new_q, new_v, tr.actor_obs[row], tr.critic_obs[row], tr.aux[row])
 
     def _observe_into_rows(self, tr, row: int, view) -> dict:
         """Evaluate the user's Observation terms (train.py:635, 682, 706 protocol) on `view` and write those routed into the networks behind the
@@ -376,6 +400,9 @@ class HumanoidWalkingTask:
         def update_command(row: int, view, fresh, all_fresh: bool = False):
             self._apply_command(c, tr, row, view, fresh, first + row, all_fresh)
 
+        if self.extra_resets and not self._resets_started:                     # the state env_reset_all drew: every env starts an episode
+            self._apply_resets(c, tr, 0, None, first)
+            self._resets_started = True
         if self.command_term is not None and not self._command_started:      # the rows env_reset_all wrote: every env starts an episode
             view0 = StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob)
             update_command(0, view0, torch.ones(self.N, dtype=torch.bool, device=self.device), all_fresh=True)
@@ -395,6 +422,9 @@ class HumanoidWalkingTask:
                 fire = (user != 0) & (tr.aux[t][:, L.AUX["DONE"]] == 0)          # the kernel's own terminations already reset their envs
                 c.env_reset_where(fire.to(torch.float32), tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
                 tr.aux[t][:, L.AUX["DONE"]] = torch.where(fire, user, tr.aux[t][:, L.AUX["DONE"]])
+                view = StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob, qs_t)
+            if self.extra_resets:                                   # the envs this step finished carry their fresh episode's state: the user's Reset terms on top
+                self._apply_resets(c, tr, t + 1, tr.aux[t][:, L.AUX["DONE"]] != 0, first + t + 1)
                 view = StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob, qs_t)
             if self.command_term is not None:
                 update_command(t + 1, view, tr.aux[t][:, L.AUX["DONE"]] != 0)
@@ -620,6 +650,7 @@ class HumanoidWalkingTask:
         self.iteration = int(st.get("num_steps", 0))
         self._obs_started = self.iteration > 0          # a resumed run's row 0 already carries the user observation columns
         self._command_started = self.iteration > 0      # a resumed run's row 0 already carries the user command term's commands
+        self._resets_started = self.iteration > 0       # ... and its env rows the user Reset terms' state
         x = z["extras"]
         if "es" not in x:
             return            # a model-only checkpoint (e.g. written by the reference): parameters and optimizer only
@@ -686,6 +717,8 @@ class HumanoidWalkingTask:
         seed = self.config.seed + seed_offset
         carry.zero_()
         vctx.env_reset_all(seed, tr.actor_obs[0], tr.critic_obs[0], tr.aux[0])
+        if self.extra_resets:                   # the user's Reset terms shape the validation episodes as they shape the training ones
+            self._apply_resets(vctx, tr, 0, None, seed_offset)
         if self.command_term is not None:       # the user's Command term drives the validation envs as it drives the training ones
             from .traj_view import StepView
             self._apply_command(vctx, tr, 0, StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob),
@@ -699,6 +732,8 @@ class HumanoidWalkingTask:
         for t in range(T):
             vctx.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], carry.c, seed, t, True, tr.action[t], tr.logp[t], tr.value[t])
             vctx.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
+            if self.extra_resets:
+                self._apply_resets(vctx, tr, t + 1, tr.aux[t][:, L.AUX["DONE"]] != 0, seed_offset + t + 1)
             if feeds:
                 self._observe_into_rows(tr, t + 1, StepView(tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1], self.model_blob))
             if self.command_term is not None:

@@ -170,3 +170,29 @@ def combine_terminations(terms: Dict[str, object], view: StepView, curriculum_le
             raise ValueError(f"termination {name!r} returned shape {tuple(v.shape)}, expected {tuple(out.shape)}")
         out = torch.where(out != 0, out, torch.sign(v))
     return out
+
+
+class ResetData:
+    """What a user-written Reset term receives and returns (train.py:833-844: `data.qpos`, `ksim.update_data_field(data, "qpos", qpos_j)`): the
+    generalised positions / velocities of ALL envs as [N, 27] / [N, 26] device tensors ([27] / [26] per env under `per_env_reset`). The task keeps
+    the term's result only for the envs that have just been re-initialised."""
+
+    def __init__(self, qpos: torch.Tensor, qvel: torch.Tensor):
+        self.qpos, self.qvel = qpos, qvel
+
+
+def update_data_field(data: ResetData, name: str, value: torch.Tensor) -> ResetData:
+    """ksim.update_data_field for the two fields a Reset may change: returns a new object (the terms are functional, as in the reference)."""
+    if name not in ("qpos", "qvel"):
+        raise KeyError(f"a Reset term may update 'qpos' or 'qvel', not {name!r}")
+    return ResetData(value if name == "qpos" else data.qpos, value if name == "qvel" else data.qvel)
+
+
+def per_env_reset(fn):
+    """A Reset body written per env as the reference's (`qpos_j.at[0:1].set(new_x)` on a [27] vector), over all envs under torch.vmap. `rng` is the
+    torch.Generator the task passes; draw per-env random numbers OUTSIDE the vmapped body (torch.vmap has no per-example generators) and pass
+    them in through a closure or extra tensors of shape [N, ...] given as `extras`."""
+    def run(data: ResetData, curriculum_level=1.0, rng=None, extras=()):
+        out = torch.vmap(lambda q, v, *x: (lambda d: (d.qpos, d.qvel))(fn(ResetData(q, v), curriculum_level, rng, *x)), in_dims=0)(data.qpos, data.qvel, *extras)
+        return ResetData(out[0], out[1])
+    return run

@@ -792,3 +792,78 @@ def test_reference_reward_classes_on_the_trajectory_reproduce_the_kernel(size):
     assert float((t5.traj.reward - t4.traj.reward).abs().max()) < 2e-4       # the torch term in place of the kernel's: the same reward
     for t in (task, t1, t2, t3, t4, t5):
         t.close()
+
+
+def test_python_reset_terms():
+    """f3: user-written Reset terms in the reference's protocol (train.py:833-844 `Reset.__call__(data, curriculum_level, rng) -> data`) on top of the
+    built-in resets, through kbj_env_get_qstate / kbj_env_set_qstate. (a) A term that returns its data unchanged leaves the run identical to the stock
+    one (state rows, aux record and actions bit for bit; derived critic entries to 1e-6: the forward pass behind the reset is compiled into two
+    kernels). (b) The reference's own PlaneXYPositionReset body, restated per env (`qpos_j.at[0:1].set(new_x)`), moves exactly the envs whose episode
+    starts - their state rows and the base position the critic sees - and nobody else. (c) A term that also sets velocities shows up in qvel."""
+    import torch
+    from kbot_joystick_amd.host.task import HumanoidWalkingTask
+    from kbot_joystick_amd.host.traj_view import ResetData, per_env_reset, update_data_field
+    from kbot_joystick_amd.spec import layout as L
+    kw = dict(num_envs=256, batch_size=64, rollout_length_seconds=1.0, seed=6)
+    stock = HumanoidWalkingTask(_small(**kw))
+    ident = HumanoidWalkingTask(_small(**kw), extra_resets=[lambda data, level, rng: data])
+    for it in range(2):
+        stock.rollout(); ident.rollout()
+        torch.cuda.synchronize()
+        for name in ("aux", "actor_obs", "action", "logp", "reward"):
+            assert torch.equal(getattr(stock.traj, name), getattr(ident.traj, name)), (it, name)
+        assert float((stock.traj.critic_obs - ident.traj.critic_obs).abs().max()) < 1e-6
+        stock.iteration += 1; ident.iteration += 1
+    es, ei = stock.ctx.env_get_state()[1], ident.ctx.env_get_state()[1]
+    assert np.array_equal(es.view(np.uint32), ei.view(np.uint32))
+    assert int((stock.traj.done != 0).sum()) > 20
+
+    class PlaneXYPositionReset:            # train.py:827-844, per env; the two uniform draws come in as extras (torch.vmap has no per-example generator)
+        def __init__(self, x_range, y_range):
+            self.x_range, self.y_range = x_range, y_range
+
+        def _one(self, data, curriculum_level, rng, new_x, new_y):
+            qpos_j = data.qpos
+            qpos_j = torch.cat([new_x, new_y, qpos_j[2:]])          # qpos_j.at[0:1].set(new_x); qpos_j.at[1:2].set(new_y)
+            return update_data_field(data, "qpos", qpos_j)
+
+        def __call__(self, data, curriculum_level, rng):
+            n = data.qpos.shape[0]
+            new_x = (torch.rand(n, 1, generator=rng, device=data.qpos.device) * 2 - 1) * self.x_range
+            new_y = (torch.rand(n, 1, generator=rng, device=data.qpos.device) * 2 - 1) * self.y_range
+            return per_env_reset(self._one)(data, curriculum_level, rng, extras=(new_x, new_y))
+
+    def spin(data, level, rng):            # (c) a second term in the list: fresh episodes start with a yaw rate
+        v = data.qvel.clone(); v[:, 5] = 0.75
+        return ResetData(data.qpos, v)
+    user = HumanoidWalkingTask(_small(**kw), extra_resets=[PlaneXYPositionReset(3.0, 0.5), spin])
+    bp = L.OBS["BASEPOS"][0]
+    seen = 0
+    for it in range(2):
+        user.rollout(); torch.cuda.synchronize()
+        T = user.T
+        done = user.traj.aux[:T, :, L.AUX["DONE"]] != 0
+        nxt = user.traj.critic_obs[1:T + 1, :, bp:bp + 2]           # base xy of the row after each step
+        assert bool((nxt[done][:, 0].abs() <= 3.0).all()) and bool((nxt[done][:, 1].abs() <= 0.5).all())
+        assert float(nxt[done][:, 0].abs().max()) > 0.5             # far outside the built-in reset's +-0.1 m: the term's draw, not the kernel's
+        av = L.OBS["ANGVEL"][0]
+        assert bool((user.traj.critic_obs[1:T + 1, :, av + 2][done] == 0.75).all())      # the critic sees the yaw rate of the fresh state
+        if it == 0:                                                 # row 0 of the first rollout: every env starts an episode
+            assert float(user.traj.critic_obs[0, :, bp].abs().max()) > 0.5 and bool((user.traj.critic_obs[0, :, av + 2] == 0.75).all())
+        seen += int(done.sum())
+        user.iteration += 1
+    assert seen > 20
+    # envs that did not finish keep their own trajectory: a running env's position changes by a step's worth, never by metres
+    run = ~done[:-1] & ~done[1:]
+    step_xy = (user.traj.critic_obs[2:T + 1, :, bp:bp + 2] - user.traj.critic_obs[1:T, :, bp:bp + 2]).norm(dim=-1)
+    assert float(step_xy[run].max()) < 0.2
+    _, es_u = user.ctx.env_get_state()
+    qp = torch.empty(256, 27, device="cuda"); qv = torch.empty(256, 26, device="cuda")
+    user.ctx.env_get_qstate(qp, qv); torch.cuda.synchronize()
+    assert np.array_equal(qp.cpu().numpy(), es_u[:, L.ES["QPOS"]:L.ES["QPOS"] + 27]) and np.array_equal(qv.cpu().numpy(), es_u[:, L.ES["QVEL"]:L.ES["QVEL"] + 26])
+    user.train_iteration(); torch.cuda.synchronize()                # a full iteration (and a validation rollout) with the terms in place
+    assert torch.isfinite(user.params).all() and np.isfinite(list(user.validate(num_envs=64, seconds=0.4).values())).all()
+    with pytest.raises(KeyError):
+        update_data_field(ResetData(qp, qv), "ctrl", qp)
+    for t in (stock, ident, user):
+        t.close()
