@@ -165,6 +165,11 @@ typedef struct kbj_traj {
  * snapshots the carry, then T x (policy_step, env_step, carry_reset), then rewards. */
 int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t seed, uint32_t first_step_index, kbj_traj* traj);
 
+/* replaces: `argmax=True` of sample_action during ksim's validation rollouts (train.py:1564, valid_every_n_steps train.py:1789): the following
+ * kbj_rollout calls of this context act with the distribution's mode (the filtered mean) instead of a sample; the stored log-probs are those of the
+ * mode. 0 restores sampling. (kbj_policy_step takes the flag per call.) */
+int kbj_set_rollout_argmax(kbj_ctx* ctx, int argmax);
+
 /* ---- PPO update, rows a9, a12, a13 ---------------------------------------------------------- */
 /* replaces: ksim GAE (gamma, lam: train.py:1769-1770). done from aux; adv_d/target_d [T][N] */
 int kbj_gae(kbj_ctx* ctx, const kbj_traj* traj, float* adv_d, float* target_d);

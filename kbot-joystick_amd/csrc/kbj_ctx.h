@@ -42,6 +42,7 @@ struct kbj_ctx {
   float* es_d = nullptr;        // [N][KBJ_ES_SIZE]
   float* rcarry_d = nullptr;    // [N][KBJ_RC_SIZE] reward carries
   uint32_t seed = 0;
+  int rollout_argmax = 0;       // kbj_set_rollout_argmax: kbj_rollout acts with the distribution's mode (validation rollouts, train.py:1564)
   float* qstate_next = nullptr; // kbj_env_record_state: where the next kbj_env_step writes its state record (one-shot)
   // NN workspace (kbj_nn.hip)
   void* nn_ws = nullptr;

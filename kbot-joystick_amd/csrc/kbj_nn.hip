@@ -926,7 +926,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
     const float* co = tr->critic_obs_d + (size_t)t * N * lc;
     float* aux_t = tr->aux_d + (size_t)t * N * lx;
     float* act = tr->action_d + (size_t)t * N * KBJ_NU;
-    if (policy_nets(ctx, s, params_d, 0, 1, 0, N, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
+    if (policy_nets(ctx, s, params_d, 0, 1, 0, N, ao, co, carry, seed, first_step_index + (uint32_t)t, ctx->rollout_argmax, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
     if (policy_nets(ctx, cs, params_d, 1, w.nnets, 0, N, ao, co, carry, seed, first_step_index + (uint32_t)t, 0, act, tr->logp_d + (size_t)t * N, tr->value_d + (size_t)t * N, t & 1, weff)) return -1;
     int rc = kbj_env_step_range(ctx, s, 0, N, act, aux_t, tr->actor_obs_d + (size_t)(t + 1) * N * la, tr->critic_obs_d + (size_t)(t + 1) * N * lc,
                                 tr->aux_d + (size_t)(t + 1) * N * lx, tr->qstate_d ? tr->qstate_d + (size_t)t * N * KBJ_QSTATE_SIZE : nullptr);
@@ -1412,6 +1412,12 @@ int kbj_ppo_prefetch(kbj_ctx* ctx, const kbj_traj* traj, const int32_t* env_idx_
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_prefetch, lane));
   w.prefetched_idx = env_idx_d; w.prefetched_traj = traj;
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_prefetch");
+  return 0;
+}
+
+int kbj_set_rollout_argmax(kbj_ctx* ctx, int argmax) {
+  if (!ctx) return kbj_fail(nullptr, "kbj_set_rollout_argmax: null ctx");
+  ctx->rollout_argmax = argmax != 0;
   return 0;
 }
 

@@ -77,6 +77,7 @@ SIGNATURES = {
     "kbj_policy_step": (_i, [_vp, _vp, _vp, _vp, C.POINTER(Carry), _u32, _u32, _i, _vp, _vp, _vp]),
     "kbj_carry_reset": (_i, [_vp, C.POINTER(Carry), _vp, _i]),
     "kbj_rollout": (_i, [_vp, _vp, C.POINTER(Carry), _u32, _u32, C.POINTER(Traj)]),
+    "kbj_set_rollout_argmax": (_i, [_vp, _i]),
     "kbj_gae": (_i, [_vp, C.POINTER(Traj), _vp, _vp]),
     "kbj_ppo_grad": (_i, [_vp, _vp, C.POINTER(Traj), _vp, _i, _vp, _vp, _vp, _vp]),
     "kbj_ppo_forward": (_i, [_vp, _vp, C.POINTER(Traj), _vp, _i, C.POINTER(PpoVars)]),
@@ -258,6 +259,10 @@ class Context:
 
     def rollout(self, params, carry: Carry, seed, first_step_index, traj: Traj):
         self.call("kbj_rollout", _ptr(params), C.byref(carry), seed, first_step_index, C.byref(traj))
+
+    def set_rollout_argmax(self, argmax: bool):
+        """kbj_set_rollout_argmax: the following rollout() calls act with the distribution's mode (validation rollouts)."""
+        self.call("kbj_set_rollout_argmax", int(bool(argmax)))
 
     def gae(self, traj: Traj, adv, target):
         self.call("kbj_gae", C.byref(traj), _ptr(adv), _ptr(target))

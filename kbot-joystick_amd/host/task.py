@@ -697,7 +697,7 @@ class HumanoidWalkingTask:
         return [ckpt_io.load_ckpt(path, part, hidden_size=self.H, depth=self.kcfg.depth)]
 
     # ---- validation (train.py:1564 argmax=True; valid_every_n_steps train.py:1789) ----
-    def validate(self, num_envs: int = 64, seconds: Optional[float] = None, seed_offset: int = 7919, _capture=None) -> dict:
+    def validate(self, num_envs: int = 64, seconds: Optional[float] = None, seed_offset: int = 7919, _capture=None, _stepwise: bool = False) -> dict:
         """Deterministic validation rollout: a separate small env set (its own context, carries and buffers, so training state is
         untouched), actions = the distribution's mode, `render_length_seconds` long. Returns scalar statistics.
         `_capture(ctx, frame)` (view()): called after the reset (frame 0) and after every control step."""
@@ -729,7 +729,15 @@ class HumanoidWalkingTask:
             self._observe_into_rows(tr, 0, StepView(tr.aux[0], tr.actor_obs[0], tr.critic_obs[0], tr.aux[0], self.model_blob))
         if _capture is not None:
             _capture(vctx, 0)
-        for t in range(T):
+        fused = _capture is None and not feeds and self.command_term is None and not self.extra_resets and not _stepwise
+        if fused:
+            # no user term and nothing to capture between the steps: ONE kbj_rollout call in argmax mode (the same kernels, bit-identical to the
+            # step-by-step loop below, ~3 x fewer host calls: 0.05 instead of 0.15 s for 64 envs x 500 steps). kbj_rollout takes its first
+            # observation from row T (the previous rollout's last), so the reset rows move there first.
+            tr.actor_obs[T].copy_(tr.actor_obs[0]); tr.critic_obs[T].copy_(tr.critic_obs[0]); tr.aux[T].copy_(tr.aux[0])
+            vctx.set_rollout_argmax(True)
+            vctx.rollout(self.params, carry.c, seed, 0, tr.c)
+        for t in range(0 if not fused else T, T):
             vctx.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], carry.c, seed, t, True, tr.action[t], tr.logp[t], tr.value[t])
             vctx.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])
             if self.extra_resets:
@@ -742,7 +750,8 @@ class HumanoidWalkingTask:
             vctx.carry_reset(carry.c, tr.aux[t].data_ptr() + 4 * L.AUX["DONE"], L.AUX["SIZE"])
             if _capture is not None:
                 _capture(vctx, t + 1)
-        vctx.rewards(tr.aux, T, tr.reward, tr.comps)
+        if not fused:
+            vctx.rewards(tr.aux, T, tr.reward, tr.comps)
         vctx.synchronize()
         done = tr.done
         fails, succ = float((done < 0).sum()), float((done > 0).sum())
@@ -798,11 +807,8 @@ class HumanoidWalkingTask:
         names = ("loss", "policy_loss", "value_loss", "entropy", "clip_fraction", "approx_kl", "adv_mean", "adv_std", "action_mirror_loss", "value_mirror_loss")
         out = {f"train/{n}": v for n, v in zip(names, m)}
         done = self.traj.done
-        out["train/reward_per_step"] = float(self.traj.reward.mean())
-        out["train/failures_per_step"] = float((done < 0).float().mean())
-        out["train/truncations_per_step"] = float((done > 0).float().mean())
-        out["train/value_mean"] = float(self.traj.value.mean())
-        out["train/action_std_logp"] = float(self.traj.logp.mean())
+        st = torch.stack([self.traj.reward.mean(), (done < 0).float().mean(), (done > 0).float().mean(), self.traj.value.mean(), self.traj.logp.mean()]).cpu().tolist()   # one sync
+        out["train/reward_per_step"], out["train/failures_per_step"], out["train/truncations_per_step"], out["train/value_mean"], out["train/action_std_logp"] = st
         if self.traj.comps is not None:
             for name, v in self.reward_components().items():
                 out[f"reward/{name}"] = v
@@ -855,6 +861,8 @@ class HumanoidWalkingTask:
         for it in range(num_iterations):
             task.train_iteration()
             now = time.time()
+            if it == 0:
+                stats["first_iteration_seconds"] = now - t0      # one-time costs live here: code objects loaded at first launch, pinned staging buffers
             if (it + 1) % log_every == 0:
                 sc = task.scalars()
                 sc["perf/env_steps_per_s"] = task.env_steps_per_iteration() * (it + 1) / (now - t0)
@@ -879,6 +887,9 @@ class HumanoidWalkingTask:
         # the loop as its user sees it: training iterations + scalar logging + validations + periodic checkpoints, up to here
         stats["loop_seconds"] = time.time() - t0
         stats["env_steps_per_s"] = task.env_steps_per_iteration() * stats["iterations"] / max(stats["loop_seconds"], 1e-9)
+        # steady state: everything behind the first iteration (its logging included), as a benchmark's warm-up step is outside its timed region
+        if stats["iterations"] > 1:
+            stats["steady_env_steps_per_s"] = task.env_steps_per_iteration() * (stats["iterations"] - 1) / max(stats["loop_seconds"] - stats["first_iteration_seconds"], 1e-9)
         if ckpt_path:
             tc = time.time()
             task.save_checkpoint(ckpt_path)      # the final one in line: the file is complete when launch() returns

@@ -180,6 +180,9 @@ def test_validation_is_deterministic_and_leaves_training_untouched():
     v1 = task.validate(num_envs=32, seconds=1.0)
     v2 = task.validate(num_envs=32, seconds=1.0)
     assert v1 == v2 and all(np.isfinite(x) for x in v1.values())                     # argmax actions, fixed seed: bit-reproducible
+    # the plain validation is ONE kbj_rollout call in argmax mode (kbj_set_rollout_argmax); the step-by-step loop that view() and the user-term
+    # paths run gives the same numbers, bit for bit
+    assert task.validate(num_envs=32, seconds=1.0, _stepwise=True) == v1
     assert set(f"valid/reward/{n}" for n in constants.REWARD_NAMES) <= set(v1)
     assert torch.equal(p0, task.params) and np.array_equal(es0.view(np.uint32), task.ctx.env_get_state()[1].view(np.uint32))
     sc = task.scalars()
