@@ -870,3 +870,11 @@ def test_python_reset_terms():
         update_data_field(ResetData(qp, qv), "ctrl", qp)
     for t in (stock, ident, user):
         t.close()
+
+
+def test_example_with_all_six_user_term_protocols_runs():
+    """examples/custom_terms.py: a reward (per env on the ksim-shaped Trajectory), a termination (per env on physics_data names), a reset, an observation routed
+    into the critic, and a command term, all written in the reference's protocols, train together."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "custom_terms.py"), "2"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "custom terms ok" in out.stdout, (out.stdout[-1500:], out.stderr[-2500:])
+    assert "iter 2:" in out.stdout
