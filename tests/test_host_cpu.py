@@ -200,7 +200,7 @@ def test_schedule_count_leaf_and_episode_length_rounding(tmp_path):
             blobs = ckpt._read_blobs(tar.extractfile("opt_state_0").read())
         assert len(blobs) == want
         if sched is not None:
-            assert blobs[-1].dtype == np.int32 and int(blobs[-1]) == 17
+            assert blobs[-1].dtype == np.int32 and int(blobs[-1].reshape(-1)[0]) == 17
         z = ckpt.load_ckpt(path, "opt_state")
         assert z["count"] == 17 and z["counts"] == ([17] if sched is None else [17, 17]) and np.array_equal(z["mu"], p)
     assert ckpt.has_member(path, "opt_state_0") and not ckpt.has_member(path, "kbj_es")
