@@ -293,14 +293,6 @@ def main():
         sys.exit(f"bench.py needs a HIP device (rank {rank} of {world})")
     if args.share_gpu:
         local_rank = 0
-        # the persistent LSTM recurrences need their whole grid resident (kbj_create checks that per context); ranks that SHARE a GPU share its
-        # CUs, and a grid that is only partly placed spins to its bound launch after launch (fail-stop, but minutes of it): refuse instead
-        grid = (512 // 32) * ((args.hidden + 63) // 64 * 64 // 32)
-        cus = torch.cuda.get_device_properties(0).multi_processor_count
-        if world * 2 * grid > cus // 2:     # (half the CUs: the ranks' GEMM and env workgroups want room too. Measured: 4 ranks x hidden 64 = 256 workgroups on 256
-            # CUs crawls from spin bound to spin bound - killed after 400 s; 2 ranks x hidden 64 run in a minute, tests/test_gpu_host.py)
-            sys.exit(f"bench.py --share-gpu: {world} ranks x 2 concurrent recurrence launches x {grid} workgroups (batch 512, hidden {args.hidden}) do not fit the "
-                     f"{cus} CUs of the one GPU they share beside the ranks' other kernels: rehearse the N-rank flow with --hidden 64 and at most {cus // (4 * 32)} ranks")
     if torch.cuda.device_count() <= local_rank:
         sys.exit(f"bench.py: rank {rank} needs GPU {local_rank}, only {torch.cuda.device_count()} visible")
     torch.cuda.set_device(local_rank)
@@ -327,6 +319,15 @@ def main():
         return
     cfg = launch_config(gemm_bf16x3=args.gemm_bf16x3, **cfg_kw, **wl)
     task = HumanoidWalkingTask(cfg, device=torch.device("cuda", local_rank), rank=rank, world_size=world)
+    if args.share_gpu and world > 1:
+        # the persistent LSTM recurrences need their whole grid resident; kbj_create checks that per context, but ranks that SHARE a GPU share
+        # its CUs. The numbers come from the library (kbj_recurrence_residency), not from a formula restated here. Half the slots: the ranks'
+        # GEMM and env workgroups want room too (measured: 4 ranks x hidden 64 on 256 CUs could not place their grids, gpurun_out/r05r; since
+        # round 6 that case fails within the 2 s wait bound instead of crawling, but refusing is friendlier).
+        grid, conc, slots = task.ctx.recurrence_residency()
+        if world * conc * grid > slots // 2:
+            sys.exit(f"bench.py --share-gpu: {world} ranks x {conc} concurrent recurrence launches x {grid} workgroups (batch {cfg.batch_size}, hidden {args.hidden}) "
+                     f"do not fit half of the {slots} resident workgroup slots of the one GPU they share: use a smaller --hidden or at most {max(1, slots // (2 * conc * grid))} ranks")
 
     def barrier():
         torch.cuda.synchronize()

@@ -213,6 +213,14 @@ int kbj_stream_wait_actor_grad(kbj_ctx* ctx, void* hip_stream);
  * every rank normalises with the mean / variance of the GLOBAL minibatch - instead of their own minibatch's. NULL restores the default.
  * The pointer is read when kbj_ppo_grad runs (stream-ordered): fill it on the context's stream before the call. */
 int kbj_set_advantage_sums(kbj_ctx* ctx, const double* sums_d);
+/* Residency of the persistent recurrences (no reference counterpart: XLA has no persistent kernels). The T-step LSTM recurrences of
+ * kbj_ppo_grad / kbj_ppo_forward are persistent launches whose workgroups hand tiles to each other, so a launch's whole grid must be resident:
+ * *grid_wgs = workgroups of ONE recurrence launch at this configuration, *concurrent = launches this context keeps in flight at once (2: actor-
+ * and critic-type net; 1 on the one-stream schedule), *slots = workgroups of the worst-fitting recurrence kernel the device holds (occupancy
+ * query x CUs). kbj_create refuses a configuration with concurrent x grid > slots; a host that puts SEVERAL contexts (ranks) on one GPU must keep
+ * the sum over them within slots (bench.py --share-gpu). A grid that cannot be placed fails within the wait bound (2 s, KBJ_SEQ_TIMEOUT_MS) and
+ * every later launch of the call aborts at once: fail-stop in seconds, never a crawl. */
+int kbj_recurrence_residency(kbj_ctx* ctx, int* grid_wgs, int* concurrent, int* slots);
 /* replaces: optax.adamw + global-norm clip (train.py:1059-1077). step is 1-based. grad_scale multiplies the
  * gradient first (1/world_size after an all-reduce sum). */
 int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const float* grad_d, int64_t step, float grad_scale);

@@ -24,7 +24,7 @@ struct kbj_ctx {
   hipStream_t stream2 = nullptr;   // second lane for the critic network inside kbj_ppo_grad
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t side[2] = {nullptr, nullptr};   // per-net side lanes for weight-gradient GEMMs
-  hipEvent_t ev_dx[2] = {nullptr, nullptr};   // per net lane: the layer's input-gradient GEMM is done (the weight-gradient lanes start behind both)
+  hipEvent_t ev_dx[2] = {nullptr, nullptr};   // per net lane: the lane's recurrence launches of a layer (the upper layer's weight-gradient pair on the side lane starts behind their END)
   hipEvent_t ev_side[2] = {nullptr, nullptr};
   hipEvent_t ev_obs = nullptr;                // the critic's gathered observation rows are in place (side lane, ppo_forward_nets)
   hipEvent_t ev_prefetch = nullptr;           // kbj_ppo_prefetch: the next minibatch's head gathers are done

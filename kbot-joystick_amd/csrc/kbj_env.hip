@@ -314,11 +314,12 @@ int kbj_env_reset_all(kbj_ctx* ctx, uint32_t seed, float* actor0_d, float* criti
 
 int kbj_env_step(kbj_ctx* ctx, const float* action_d, float* aux_t_d, float* actor_next_d, float* critic_next_d, float* aux_next_d) {
   if (!ctx) return kbj_fail(nullptr, "kbj_env_step: null ctx");
+  float* q = ctx->qstate_next;
+  ctx->qstate_next = nullptr;     // one-shot (kbj_env_record_state), consumed by THIS call whether it succeeds or not: a call that fails early must not
+                                  // leave the pointer armed for a later step, when the host may have freed or reused the row
   if (!action_d || !aux_t_d || !actor_next_d || !critic_next_d || !aux_next_d) return kbj_fail(ctx, "kbj_env_step: null pointer");
   KBJ_HIP(ctx, hipSetDevice(ctx->device));
   kbj_nn_drop_prefetch(ctx);
-  float* q = ctx->qstate_next;
-  ctx->qstate_next = nullptr;     // one-shot (kbj_env_record_state)
   return kbj_env_step_range(ctx, ctx->stream, 0, ctx->cfg_h.num_envs, action_d, aux_t_d, actor_next_d, critic_next_d, aux_next_d, q);
 }
 

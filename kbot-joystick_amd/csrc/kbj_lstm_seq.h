@@ -35,7 +35,7 @@ constexpr int SEQ_UNITS = 16;  // hidden units per workgroup
 #define SEQ_BSTAMP(k) do { } while (0)
 #define SEQ_BSTAMP_ON 0
 #endif
-constexpr unsigned SEQ_SPIN_LIMIT = 1u << 24;   // default bound of every inter-workgroup spin (args.spin_limit; shorter under fault injection)
+constexpr unsigned SEQ_TIMEOUT_MS = 2000;   // default wall-clock bound of every inter-workgroup wait (args.timeout_ticks on the 100 MHz constant-rate clock; KBJ_SEQ_TIMEOUT_MS; 20 ms under fault injection)
 
 // Register budget of the backward recurrence: at <= 176 allocated VGPRs two of its waves AND two waves of a weight-gradient GEMM
 // workgroup (80) share a SIMD (2 x 176 + 2 x 80 = 512), which is what lets those GEMMs run beside the layer-0 recurrences (DESIGN.md
@@ -56,7 +56,7 @@ struct SeqFwdArgs {
   unsigned* err;       // set to 1 on a spin timeout
   int T, B;
   long long* stamps;   // optional [T][6] shader-clock stamps of workgroup 0 (diagnostics), else null
-  unsigned spin_limit = SEQ_SPIN_LIMIT;
+  unsigned timeout_ticks = SEQ_TIMEOUT_MS * 100000u;   // wall_clock64 ticks (kbj_nn.hip sets it from the device's wall-clock rate)
   // fused input projection (FUSE kernels): gates = x_t W_ih^T + bias + h_{t-1} W_hh^T computed here, G is then output only
   const float* X = nullptr;     // [T][B][H] layer input
   const float* Wih = nullptr;   // [4H][H]
@@ -78,7 +78,7 @@ struct SeqBwdArgs {
   int T, B;
   float* db;             // optional [4H]: bias gradient accumulated with atomics (column sums of dG)
   float* db_part = nullptr;   // deterministic mode: [row groups][4H] per-row-group column sums instead (added to db in order by reduce_rows_kernel)
-  unsigned spin_limit = SEQ_SPIN_LIMIT;
+  unsigned timeout_ticks = SEQ_TIMEOUT_MS * 100000u;   // wall_clock64 ticks (kbj_nn.hip sets it from the device's wall-clock rate)
   long long* stamps = nullptr;   // optional [T][10] shader-clock stamps of workgroup 0 (diagnostics)
 };
 
@@ -88,25 +88,45 @@ struct SeqBwdArgs {
 __device__ __forceinline__ float seq_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float seq_tanh(float x) { float xc = fminf(fmaxf(x, -15.0f), 15.0f); return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * xc)); }
 
-// wait until *ctr >= target: one lane polls the one word (relaxed, agent scope); returns false on timeout
+// wait until every flag >= target; returns false on timeout or abort
 // flags: one word per producer workgroup of the row group (nflags consecutive words = one cache line), each holding the
-// number of steps that producer has published; lanes 0..nflags-1 of wave 0 poll them with sc1 loads until all reach target
-__device__ __forceinline__ bool seq_wait(unsigned* flags, int nflags, unsigned target, unsigned* err, int* lds_flag, unsigned spin_limit) {
+// number of steps that producer has published; lanes 0..nflags-1 of wave 0 poll them with sc1 loads until all reach target.
+// The bound is WALL-CLOCK time (round 6; it was 2^24 polls, i.e. tens of seconds per hand-off and minutes per call when a grid could not be
+// made resident - gpurun_out/r05r): every 256th poll reads the constant-rate counter (s_memrealtime) and the error word, so the fast path is
+// unchanged. A wait gives up when `timeout_ticks` have passed since its first check, or as soon as ANY workgroup of the context has raised the
+// error word (a partner that timed out or a launch that was aborted will never publish): a failing call drains in one bound, not in
+// steps x bound.
+__device__ __forceinline__ bool seq_wait(unsigned* flags, int nflags, unsigned target, unsigned* err, int* lds_flag, unsigned timeout_ticks) {
   if (threadIdx.x < 64) {
     unsigned spins = 0;
+    unsigned long long t0 = 0;
     int ok = 1;
     const int l = threadIdx.x;
     for (;;) {
       bool mine = l >= nflags || __hip_atomic_load(flags + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target;
       if (__all(mine)) break;
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > spin_limit) { ok = 0; if (l == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      if ((++spins & 255u) == 0) {
+        const unsigned long long now = wall_clock64();
+        if (t0 == 0) t0 = now;
+        const bool aborted = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+        if (aborted || now - t0 > timeout_ticks) { ok = 0; if (l == 0) __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+      }
     }
     if (l == 0) *lds_flag = ok;
   }
   __syncthreads();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // no instruction: keeps the payload loads below the poll
   return *lds_flag != 0;
+}
+// a launch of a call whose earlier launch already failed does not start: its partners would only run into their bounds one after the other
+// (uniform per workgroup only if every thread reads the same value: thread 0 decides)
+__device__ __forceinline__ bool seq_aborted(unsigned* err, int* lds_flag) {
+  if (threadIdx.x == 0) *lds_flag = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+  __syncthreads();
+  const bool r = *lds_flag != 0;
+  __syncthreads();
+  return r;
 }
 // payload store: write-through (sc1)
 __device__ __forceinline__ void seq_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -115,6 +135,17 @@ __device__ __forceinline__ void seq_publish(unsigned* my_flag, unsigned steps_do
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(my_flag, steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 store, never a plain one
+}
+// Barrier-free publish (round 6): every wavefront drains its own payload stores and counts itself in on a monotonic LDS counter; the LAST one
+// to arrive for this step (arrivals = waves x steps) stores the flag. The workgroup barrier of seq_publish is gone, and - the point - matrix
+// work issued between the payload stores and this call runs while the write-through stores travel to L2 (~900 cycles per step that were
+// spent with an idle matrix pipe). `arrivals` is zeroed before the first step (a barrier lies between, seq_aborted's).
+__device__ __forceinline__ void seq_publish_nb(unsigned* my_flag, unsigned steps_done, unsigned* arrivals, unsigned nwaves) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if ((threadIdx.x & 63) == 0) {
+    const unsigned old = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (old + 1 == nwaves * steps_done) __hip_atomic_store(my_flag, steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 store, never a plain one
+  }
 }
 // k order of the register-resident products. The A operand of v_mfma_f32_16x16x4_f32 is one float per lane (row = lane & 15,
 // k slot g = lane >> 4); WHICH k a slot holds in a given step is free as long as the B registers (the weight slices) use the same
@@ -232,10 +263,15 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
 #define KBJ_SEQ_XSPLIT_NUM 4   // eighths of the input projection's k-steps issued before the flag poll (the rest hides the tile fetch)
 #endif
   constexpr int XSPLIT = KXK::NB * KBJ_SEQ_XSPLIT_NUM / 8;   // in 16-k blocks
+#ifndef KBJ_SEQ_XPRE_NUM
+#define KBJ_SEQ_XPRE_NUM 1     // eighths of the NEXT step's input projection issued between this step's payload stores and their drain (seq_publish_nb)
+#endif
+  constexpr int XPRE = FUSE ? (KXK::NB * KBJ_SEQ_XPRE_NUM / 8 < XSPLIT ? KXK::NB * KBJ_SEQ_XPRE_NUM / 8 : XSPLIT) : 0;
   __shared__ __attribute__((aligned(16))) float hs[SEQ_ROWS * LDH];
   __shared__ __attribute__((aligned(16))) float xs[FUSE ? SEQ_ROWS * LDX : 4];
   __shared__ float gbuf[4][SEQ_ROWS][UNITS + 4];   // row stride = 4 (mod 8): the accumulator rows of lanes 0-15 / 16-31 (4 rows apart) fall on disjoint banks
   __shared__ int flag;
+  __shared__ unsigned arrivals;                     // seq_publish_nb
   const int tid = threadIdx.x, lane = tid & 63, gate = (tid >> 6) & 3, uh = tid >> 8;
   // XCD-aware mapping (speed only, the protocol is placement independent): workgroups b, b+8, b+16, ... share an XCD,
   // so give each XCD whole row groups and the tile hand-off stays inside one L2
@@ -244,6 +280,8 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
+  if (tid == 0) arrivals = 0;
+  if (seq_aborted(a.err, &flag)) return;
   // W_hh rows of this wave's gate for the 16 units, as B operands: B[k slot g][col] = Whh[gate H + u0 + col][KH::kidx(step, g)]
   float wreg[H / 4];
   {
@@ -298,16 +336,17 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     if (KX == H) xt.to_lds(xs, r0, B); else xt.to_lds_cols(xs, LDX, r0, B, kxv);
     __syncthreads();
   }
+  f32x4m acc0 = {bias_col, bias_col, bias_col, bias_col}, acc1 = acc0;
+  if (XPRE > 0) KXK::template mma<false>(xs, lane, wxreg, acc0, acc1, 0, XPRE);   // step 0's share of what every later step finds done by its predecessor
   for (int t = 0; t < T; ++t) {
     SEQ_STAMP(0);
     float gx[2][4], kp[2];   // this step's own inputs, fetched one step ago (taken over before any load of this step is in flight)
 #pragma unroll
     for (int i = 0; i < 2; ++i) { kp[i] = kpn[i]; for (int k = 0; k < 4; ++k) gx[i][k] = gxn[i][k]; }
-    f32x4m acc0 = {bias_col, bias_col, bias_col, bias_col}, acc1 = acc0;
-    if (FUSE) {   // first half of the input projection: runs while the partners' flags travel
-      KXK::template mma<false>(xs, lane, wxreg, acc0, acc1, 0, XSPLIT);
+    if (FUSE) {   // first part of the input projection: runs while the partners' flags travel (its first XPRE blocks ran under the previous step's drain)
+      KXK::template mma<false>(xs, lane, wxreg, acc0, acc1, XPRE, XSPLIT);
     }
-    if (t > 0) { if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)t, a.err, &flag, a.spin_limit)) return; }
+    if (t > 0) { if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)t, a.err, &flag, a.timeout_ticks)) return; }
     SEQ_STAMP(1);
     SeqTile<H, NTH> tile;
     tile.load(a.Hm + (size_t)t * B * H, H, r0, B);
@@ -357,7 +396,17 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
       if (r0 + row < B) seq_store(a.Hm + ((size_t)(t + 1) * B + r0 + row) * H + u0 + u, hh[i] * kp[i]);  // the hand-off payload
     }
     SEQ_STAMP(4);
+    acc0 = f32x4m{bias_col, bias_col, bias_col, bias_col}; acc1 = acc0;
+    if (XPRE > 0 && t + 1 < T) {   // the next step's input projection starts here: its tile is staged (the barrier above), and these MFMAs run while the payload drains
+      __builtin_amdgcn_sched_barrier(0);
+      KXK::template mma<false>(xs, lane, wxreg, acc0, acc1, 0, XPRE);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#ifdef KBJ_SEQ_OLD_PUBLISH   // A/B: the round-5 hand-off (drain, workgroup barrier, flag)
     seq_publish(a.counters + rg * NUG + ug, (unsigned)(t + 1));
+#else
+    seq_publish_nb(a.counters + rg * NUG + ug, (unsigned)(t + 1), &arrivals, NTH / 64);
+#endif
     SEQ_STAMP(5);
   }
   // BPTT stash of the last step
@@ -392,6 +441,7 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const SeqBwdArgs a) {
   const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
+  if (seq_aborted(a.err, &flag)) return;
   if (SEQ_BSTAMP_ON && a.stamps && tid == 0 && blockIdx.x < 256) a.stamps[T * 10 + 3 * blockIdx.x] = wall_clock64();   // per-workgroup entry / loop start / exit
   constexpr int KW = H / 4;        // k range of one wave inside a gate chunk
   constexpr int KS = KW / 4;       // k-steps per (wave, gate chunk)
@@ -440,7 +490,7 @@ __device__ __forceinline__ void lstm_seq_bwd_body(const SeqBwdArgs a) {
     };
     if (last) prefetch();
     else {
-      if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)(T - 1 - t), a.err, &flag, a.spin_limit)) return;
+      if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)(T - 1 - t), a.err, &flag, a.timeout_ticks)) return;
       SEQ_BSTAMP(1);
       f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
       const float* src = a.dG + (size_t)(t + 1) * B * 4 * H;
@@ -523,15 +573,6 @@ template <int H, int UW>
 __global__ __launch_bounds__(256 * UW) __attribute__((amdgpu_num_vgpr(KBJ_SEQ_BWD_NUM_VGPR))) void lstm_seq_bwd_kernel(SeqBwdArgs a) { lstm_seq_bwd_body<H, UW>(a); }
 template <int H, int UW>
 __global__ __launch_bounds__(256 * UW) void lstm_seq_bwd_wide_kernel(SeqBwdArgs a) { lstm_seq_bwd_body<H, UW>(a); }
-
-// A fixed pause on a lane (one lane of one wavefront sleeping until `ticks` of the constant-rate clock have passed): it waits for NOTHING, so
-// it is safe under any serialisation of kernels. kbj_nn.hip puts it in front of the weight-gradient GEMMs of a layer so that the next
-// layer's recurrences - eligible at the same moment - have their workgroups placed before the GEMM workgroups take the CUs.
-__global__ void seq_delay_kernel(unsigned ticks) {
-  if (threadIdx.x != 0) return;
-  const unsigned long long t0 = wall_clock64();
-  for (unsigned i = 0; i < (1u << 16) && wall_clock64() - t0 < ticks; ++i) __builtin_amdgcn_s_sleep(16);
-}
 
 // ---- one LSTM layer step for MANY independent rows (rollout: 8192 envs, no recurrence inside the launch) ------------------------------
 // Same register-resident weight slices and fused cell as the forward recurrence above, but the loop runs over row groups instead of

@@ -5,6 +5,7 @@
 #include <vector>
 #include <cmath>
 #include <cstdlib>
+#include <algorithm>
 #include "kbj_ctx.h"
 #include "kbj_gemm.h"
 #include "kbj_nn_kernels.h"
@@ -41,7 +42,7 @@ struct Sched {
   bool deterministic = false;      // fixed-order reductions instead of fp32 / fp64 atomics (bit-reproducible update)
   bool bwd16 = true;               // KBJ_BWD16=0: backward recurrences on the 32-row x 32-unit form of rounds 1-4 (lstm_seq_bwd_kernel) instead of 16-row x 64-unit
                                    // tiles with the partner-major contraction (kbj_lstm_bwd16.h: 620 instead of 907 us per launch in situ)
-  int dw_delay_us = 30;            // KBJ_DW_DELAY_US=n (0 = off): pause of the weight-gradient lanes behind both lanes' input gradients (kbj_ppo_grad)
+  bool critic_first = false;       // KBJ_CRITIC_FIRST=1 (A/B, round 6): the actor's first recurrence waits for the critic's input projection, which then has the whole chip
   bool gemm_x3 = false;            // kbj_config.gemm_bf16x3 / KBJ_GEMM_X3=1: the GEMM launches that are eligible (the update's input gradients, weight-gradient
                                    // pairs and critic input projection, the rollout's [x | h] gate GEMMs) on the bf16 matrix cores through the exact three-way
                                    // operand split (kbj_gemm.h gemm_x3_kernel); not the default, not the headline
@@ -95,6 +96,7 @@ struct NnWs {
   const double* ext_adv_sums = nullptr;   // kbj_set_advantage_sums: (sum adv, sum adv^2, count) on the device, used instead of the minibatch's own statistics
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
+  int seq_grid = 0, seq_slots = 0;   // workgroups of one recurrence launch / resident workgroups of the worst-fitting recurrence kernel (kbj_recurrence_residency)
   long long* seq_stamps = nullptr;   // diagnostics (KBJ_SEQ_STAMPS=1): per-step clock stamps of one workgroup
   long long* seq_bstamps = nullptr;  // same for a backward recurrence (KBJ_SEQ_BSTAMPS = 1 + net + 2 * layer)
   std::vector<void*> allocs;
@@ -262,10 +264,10 @@ constexpr int SEQ_COUNTER_TOTAL = 2 * MAXD * 4 * SEQ_COUNTER_WORDS;   // all lau
 // workgroup missing, so its partners' bounded spins expire and the timeout / fail-stop path is exercised on real hardware
 int g_seq_drop = 0;
 int g_seq_drop_bwd = 0;   // the same for the backward recurrences (KBJ_DEBUG_DROP_SEQ_BWD_WG = n)
-unsigned g_seq_spin_limit = SEQ_SPIN_LIMIT;
+unsigned g_seq_timeout_ticks = SEQ_TIMEOUT_MS * 100000u;   // wall_clock64 ticks; set per context in kbj_nn_create
 template <int H, int UW> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a0) {
   SeqFwdArgs a = a0;
-  a.spin_limit = g_seq_spin_limit;
+  a.timeout_ticks = g_seq_timeout_ticks;
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
   if (g_seq_drop > 0 && grid > 1) { --g_seq_drop; --grid; }
   if constexpr (H <= SEQ_FUSED_MAX_H) {
@@ -276,7 +278,7 @@ template <int H, int UW> void seq_fwd_launch(hipStream_t s, const SeqFwdArgs& a0
 }
 template <int H, int UW> void seq_bwd_launch(hipStream_t s, const SeqBwdArgs& a0) {
   SeqBwdArgs a = a0;
-  a.spin_limit = g_seq_spin_limit;
+  a.timeout_ticks = g_seq_timeout_ticks;
   int grid = (H / (SEQ_UNITS * UW)) * ((a.B + SEQ_ROWS - 1) / SEQ_ROWS);
   if constexpr (H <= SEQ_FUSED_MAX_H) hipLaunchKernelGGL((lstm_seq_bwd_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
   else hipLaunchKernelGGL((lstm_seq_bwd_wide_kernel<H, UW>), dim3(grid), dim3(256 * UW), 0, s, a);
@@ -298,7 +300,7 @@ int seq_fwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqFwdArgs& a) {   // a.c
 }
 template <int H> void seq_bwd16_launch(hipStream_t s, const SeqBwdArgs& a0) {
   SeqBwdArgs a = a0;
-  a.spin_limit = g_seq_spin_limit;
+  a.timeout_ticks = g_seq_timeout_ticks;
   int grid = (H / BWD16_UNITS) * ((a.B + BWD16_ROWS - 1) / BWD16_ROWS);
   if (g_seq_drop_bwd > 0 && grid > 1 && H > BWD16_UNITS) { --g_seq_drop_bwd; --grid; }   // fault injection (a launch without partners has nobody to time out)
   hipLaunchKernelGGL((lstm_seq_bwd16_kernel<H>), dim3(grid), dim3(BWD16_NTH), 0, s, a);
@@ -553,8 +555,8 @@ int kbj_nn_create(kbj_ctx* ctx) {
     sc.fused_critic_head = env_flag("KBJ_FUSED_CRITIC_HEAD", true); sc.rollout_step = env_flag("KBJ_ROLLOUT_STEP", true);
     sc.one_stream = env_flag("KBJ_ONE_STREAM", false); sc.debug_sync = env_flag("KBJ_DEBUG", false);
     sc.deterministic = c.deterministic != 0 || env_flag("KBJ_DETERMINISTIC", false);
+    sc.critic_first = env_flag("KBJ_CRITIC_FIRST", false);
     sc.bwd16 = env_flag("KBJ_BWD16", true) && H <= (size_t)SEQ_FUSED_MAX_H;   // wide layers keep lstm_seq_bwd_wide_kernel
-    if (getenv("KBJ_DW_DELAY_US")) sc.dw_delay_us = std::max(0, std::min(1000, atoi(getenv("KBJ_DW_DELAY_US"))));
     sc.gemm_x3 = (c.gemm_bf16x3 != 0 || env_flag("KBJ_GEMM_X3", false)) && !sc.deterministic;   // (the deterministic split-K slabs stay on the exact kernel)
     if (H > (size_t)SEQ_FUSED_MAX_H) sc.fuse_ih = sc.fuse_obs = sc.rollout_step = false;   // wide layers (SEQ_FUSED_MAX_H above)
     if (sc.deterministic) {
@@ -564,7 +566,14 @@ int kbj_nn_create(kbj_ctx* ctx) {
   }
   g_seq_drop = getenv("KBJ_DEBUG_DROP_SEQ_WG") ? atoi(getenv("KBJ_DEBUG_DROP_SEQ_WG")) : 0;
   g_seq_drop_bwd = getenv("KBJ_DEBUG_DROP_SEQ_BWD_WG") ? atoi(getenv("KBJ_DEBUG_DROP_SEQ_BWD_WG")) : 0;
-  g_seq_spin_limit = (g_seq_drop > 0 || g_seq_drop_bwd > 0) ? (1u << 15) : SEQ_SPIN_LIMIT;   // an injected fault should not cost the full 2^24-spin bound
+  {   // wall-clock bound of the recurrences' inter-workgroup waits (kbj_lstm_seq.h seq_wait): 2 s by default, KBJ_SEQ_TIMEOUT_MS=n overrides,
+      // 20 ms under fault injection
+    int wall_khz = 0;
+    if (hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, ctx->device) != hipSuccess || wall_khz <= 0) wall_khz = 100000;
+    long ms = (g_seq_drop > 0 || g_seq_drop_bwd > 0) ? 20 : (long)SEQ_TIMEOUT_MS;
+    if (getenv("KBJ_SEQ_TIMEOUT_MS")) ms = std::max(1, std::min(30000, atoi(getenv("KBJ_SEQ_TIMEOUT_MS"))));
+    g_seq_timeout_ticks = (unsigned)std::min<long long>(0xFFFFFFFFll, (long long)ms * wall_khz);
+  }
   // Residency of the persistent recurrences: the workgroups of one launch spin on each other, and kbj_ppo_grad keeps TWO launches
   // (actor-type and critic-type net, one per stream; the mirror branches queue behind them on the same two streams) in flight, so
   // 2 x grid workgroups must be resident at once. Every other kernel of the schedule (GEMMs, heads) terminates on its own, so it can
@@ -591,6 +600,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
     }
     if (oe != hipSuccess || per_cu < 1) return kbj_fail(ctx, "kbj_create: occupancy query of the persistent LSTM kernels failed");
     const long slots = (long)per_cu * cus;
+    w->seq_grid = grid; w->seq_slots = (int)slots;
     char msg[320];
     if (grid > SEQ_COUNTER_WORDS) {
       snprintf(msg, sizeof(msg), "kbj_create: a persistent LSTM launch would need %d workgroups (batch_size / 32 x hidden_size / 32), the hand-off "
@@ -1097,6 +1107,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
       // the copy behind the projection, under the recurrences (beside it the two would share HBM: 175 instead of 144 us for the GEMM)
       KBJ_HIP(ctx, hipEventRecord(ctx->ev_obs, ns[1]));
       KBJ_HIP(ctx, hipStreamWaitEvent(ctx->side[1], ctx->ev_obs, 0));
+      if (sc.critic_first) KBJ_HIP(ctx, hipStreamWaitEvent(ns[0], ctx->ev_obs, 0));
       if (grad) gather(ctx->side[1], tr->critic_obs_d, w.net[1].ld_obs, w.net[1].ld_obs, w.tb[1].obs, w.net[1].ld_obs);   // the forward-only pass never reads the copy
       KBJ_HIP(ctx, hipEventRecord(ctx->ev_obs, ctx->side[1]));
       continue;
@@ -1292,20 +1303,22 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     hipLaunchKernelGGL(outer_acc_kernel, g1((size_t)4 * H * H), dim3(256), 0, st, grad_d + oa.w_ih[0], grad_d + oa.b[0], params_d + oa.b_in, 4 * H, H);
   };
   bool bias_done[2] = {false, false};
-  // A layer's weight-gradient GEMMs start BEHIND its input-gradient GEMM, not beside it: the input gradient is on the net's critical chain
-  // (the next layer's recurrence reads it) and ran at 0.73 ms next to the low-priority weight gradients against 0.29 ms alone; the weight
-  // gradients lose nothing, they overlap the next layer's recurrence either way (368.6 -> 365.6 ms per iteration, three alternations on one box).
-  // KBJ_DW_DELAY_US=n (default 30, 0 = off): the weight-gradient lanes additionally wait (stream events only) until BOTH lanes' input
-  // gradients are done - i.e. until both next-layer recurrences are eligible and nothing new is being dispatched - then pause n microseconds
-  // (seq_delay_kernel: waits for nothing) and only then start: the recurrences' workgroups are placed in that window. Without it both become
-  // eligible in the same microsecond, GEMM workgroups (72 KB of LDS each, two per CU) take the CUs, and the recurrence - which advances at the
-  // pace of its last workgroup to enter - stands still for 0.2-0.7 ms. 365.9 / 365.4 / 364.7 ms per iteration without, 363.0 / 362.0 / 363.8
-  // with 20 us, 362.2 / 362.9 / 363.4 with 60 us (alternating runs on one box).
-  const int dw_delay_us = sc.dw_delay_us;
-  static const unsigned wall_khz = [&] { int k = 0; hipDeviceGetAttribute(&k, hipDeviceAttributeWallClockRate, ctx->device); return (unsigned)(k > 0 ? k : 100000); }();
+  // WHERE A LAYER'S WEIGHT-GRADIENT PAIR RUNS (round 6: explicit stream order, no pause kernel). The input gradient of layer l is on the
+  // net's critical chain (the recurrence of layer l - 1 reads it) and the recurrences take whole CUs (250 registers x 2 wavefronts per SIMD):
+  // a weight-gradient GEMM that is eligible at the same moment as a recurrence races it for the CUs, and a recurrence advances at the pace of
+  // its last workgroup to be placed (+4 % per iteration when that race is lost). So the pair of layer l > 0 is ORDERED BEHIND THE END of the
+  // net's layer l - 1 recurrence: on the net's own lane behind its layer-0 work when l - 1 is the last layer (nothing else is left for that
+  // lane to do, and a cross-lane hop costs 15-20 us each way), else on the net's side lane behind an event recorded after the recurrence
+  // launch. Rounds 4-5 reached the same order through a 30 us sleep kernel that in practice waited for a wave slot until the recurrences
+  // retired (KBJ_DW_DELAY_US, seq_delay_kernel: deleted) - an accident of occupancy, not an order. No launch's start depends on another
+  // launch's occupancy any more.
   struct PendingDW { int n, l; };
   std::vector<PendingDW> pending_dw;
-  const bool dw_delay = dw_delay_us > 0 && !one_stream;
+  auto launch_dw_pair = [&](hipStream_t st, int n, int l) {
+    const NetOff& o = w.net[n & 1];
+    TrainBufs& t = w.tb[n];
+    linear_bwd_weight2(ctx, st, t.dGl[l], 4 * H, t.Hm[l], l == 0 ? t.X0 : t.Hout[l - 1], H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
+  };
   for (int l = D - 1; l >= 0; --l) {
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
@@ -1317,16 +1330,16 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       if (seq_bwd(ctx, ns[n & 1], H, ba, tiles16)) return -1;
       if (ba.db_part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, ns[n & 1], ba.db_part, seq_bwd_row_groups(B, tiles16), 4 * H, grad_d + o.b[l]);
     }
-    for (const PendingDW& p : pending_dw) {   // the layer above's weight gradients: behind both lanes' input gradients (recorded below, an iteration ago), then the pause
-      const NetOff& o = w.net[p.n & 1];
-      TrainBufs& t = w.tb[p.n];
+    // the layer above's weight gradients, behind THIS layer's recurrence of the same net
+    const bool tail_on_own_lane = l == 0 && !w.mirror && fold_actor;   // (the own_lane case below: the pair follows the net's layer-0 work on its lane)
+    for (const PendingDW& p : pending_dw) {
+      if (one_stream) { launch_dw_pair(ns[p.n & 1], p.n, p.l); continue; }   // one lane: stream order is the order
+      if (tail_on_own_lane && ((p.n & 1) == 0 || fold_critic)) continue;      // issued in the net loop below
       hipStream_t ws = side_of(p.n);
+      hipEventRecord(ctx->ev_dx[p.n & 1], ns[p.n & 1]);   // behind the recurrence launch(es) above on that lane
       hipStreamWaitEvent(ws, ctx->ev_dx[p.n & 1], 0);
-      if (w.nnets > 1) hipStreamWaitEvent(ws, ctx->ev_dx[(p.n & 1) ^ 1], 0);
-      hipLaunchKernelGGL(seq_delay_kernel, dim3(1), dim3(64), 0, ws, (unsigned)((unsigned long long)dw_delay_us * wall_khz / 1000u));
-      linear_bwd_weight2(ctx, ws, t.dGl[p.l], 4 * H, t.Hm[p.l], p.l == 0 ? t.X0 : t.Hout[p.l - 1], H, grad_d + o.w_hh[p.l], grad_d + o.w_ih[p.l], H, 4 * H, H, R);
+      launch_dw_pair(ws, p.n, p.l);
     }
-    pending_dw.clear();
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
       TrainBufs& t = w.tb[n];
@@ -1359,19 +1372,21 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
         gemm_launch<true, true>(ws, g2a);
         // (365.3 / 364.5 / 363.6 -> 364.8 / 363.8 / 362.9 ms per iteration: the critic's pair no longer waits for the last low-priority GEMM)
         if (own_lane && n < 2) { fold_bias_terms(n, ws); bias_done[n] = true; }   // right here, on the net's own lane: not behind the side lane's join at the end
+        if (own_lane && !one_stream)   // the upper layers' pairs of this net: last on its own lane (two lanes in the tail instead of four: measured equal)
+          for (const PendingDW& p : pending_dw) if (p.n == n && p.l > l) launch_dw_pair(s, p.n, p.l);
         continue;
       }
       // the input gradient as ONE product on the net's own lane, behind the recurrence (it is the next layer's input)
       linear_bwd_input(s, t.dGl[l], 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
-      if (dw_delay && l > 0) {   // the side lane picks the weight gradients up behind the next layer's recurrence launches (above)
-        hipEventRecord(ctx->ev_dx[n & 1], s);
-        pending_dw.push_back(PendingDW{n, l});
-      } else {
+      if (l > 0) pending_dw.push_back(PendingDW{n, l});   // issued in the next pass of the layer loop, behind layer l - 1's recurrence
+      else {
         fork_side(n);   // the weight gradients start behind the input gradient
-        linear_bwd_weight2(ctx, ws, t.dGl[l], 4 * H, t.Hm[l], l == 0 ? t.X0 : t.Hout[l - 1], H, grad_d + o.w_hh[l], grad_d + o.w_ih[l], H, 4 * H, H, R);
+        launch_dw_pair(ws, n, l);
       }
       std::swap(dh_above[n], dx_out[n]);
     }
+    // what was pending when this pass began has been issued; what this pass pushed stays for the next
+    pending_dw.erase(std::remove_if(pending_dw.begin(), pending_dw.end(), [&](const PendingDW& p) { return p.l > l; }), pending_dw.end());
   }
   for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
@@ -1412,6 +1427,13 @@ int kbj_ppo_prefetch(kbj_ctx* ctx, const kbj_traj* traj, const int32_t* env_idx_
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_prefetch, lane));
   w.prefetched_idx = env_idx_d; w.prefetched_traj = traj;
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_prefetch");
+  return 0;
+}
+
+int kbj_recurrence_residency(kbj_ctx* ctx, int* grid_wgs, int* concurrent, int* slots) {
+  if (!ctx || !ctx->nn_ws || !grid_wgs || !concurrent || !slots) return kbj_fail(ctx, "kbj_recurrence_residency: null argument");
+  const NnWs& w = *ws_of(ctx);
+  *grid_wgs = w.seq_grid; *concurrent = w.sched.one_stream ? 1 : 2; *slots = w.seq_slots;
   return 0;
 }
 

@@ -78,6 +78,7 @@ SIGNATURES = {
     "kbj_carry_reset": (_i, [_vp, C.POINTER(Carry), _vp, _i]),
     "kbj_rollout": (_i, [_vp, _vp, C.POINTER(Carry), _u32, _u32, C.POINTER(Traj)]),
     "kbj_set_rollout_argmax": (_i, [_vp, _i]),
+    "kbj_recurrence_residency": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_i)]),
     "kbj_gae": (_i, [_vp, C.POINTER(Traj), _vp, _vp]),
     "kbj_ppo_grad": (_i, [_vp, _vp, C.POINTER(Traj), _vp, _i, _vp, _vp, _vp, _vp]),
     "kbj_ppo_forward": (_i, [_vp, _vp, C.POINTER(Traj), _vp, _i, C.POINTER(PpoVars)]),
@@ -263,6 +264,12 @@ class Context:
     def set_rollout_argmax(self, argmax: bool):
         """kbj_set_rollout_argmax: the following rollout() calls act with the distribution's mode (validation rollouts)."""
         self.call("kbj_set_rollout_argmax", int(bool(argmax)))
+
+    def recurrence_residency(self):
+        """kbj_recurrence_residency: (workgroups of one persistent recurrence launch, launches in flight at once, resident workgroup slots)."""
+        g, c, s = _i(0), _i(0), _i(0)
+        self.call("kbj_recurrence_residency", C.byref(g), C.byref(c), C.byref(s))
+        return g.value, c.value, s.value
 
     def gae(self, traj: Traj, adv, target):
         self.call("kbj_gae", C.byref(traj), _ptr(adv), _ptr(target))

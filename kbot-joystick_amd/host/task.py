@@ -347,8 +347,18 @@ class HumanoidWalkingTask:
         data = ResetData(qpos, qvel)
         for term in self.extra_resets:
             data = term(data, 1.0, g)
-        new_q = data.qpos.reshape(n, L.NQ).to(torch.float32).contiguous()
-        new_v = data.qvel.reshape(n, L.NV).to(torch.float32).contiguous()
+            # a Reset term returns the data it was given with fields replaced (train.py:833-844): same shapes, finite numbers. Checked here, by name,
+            # on the host (this is the step-wise path of user terms, not the fused rollout): the kernel would carry a NaN into the observation
+            # rows without a word, and a broadcastable wrong shape would only surface as a reshape error further down.
+            for field, width in (("qpos", L.NQ), ("qvel", L.NV)):
+                v = getattr(data, field, None)
+                if not torch.is_tensor(v) or tuple(v.shape) != (n, width):
+                    raise B.KbjError(f"Reset term {type(term).__name__} returned {field} of shape {tuple(v.shape) if torch.is_tensor(v) else type(v).__name__}, "
+                                     f"expected ({n}, {width})")
+                if not bool(torch.isfinite(v).all()):
+                    raise B.KbjError(f"Reset term {type(term).__name__} returned non-finite values in {field}")
+        new_q = data.qpos.to(torch.float32).contiguous()
+        new_v = data.qvel.to(torch.float32).contiguous()
         self._reset_keep = (new_q, new_v)          # alive until the kernel has run (stream-ordered)
         mask = None if fresh is None else fresh.to(torch.float32)
         ctx.env_set_qstate(mask, new_q, new_v, tr.actor_obs[row], tr.critic_obs[row], tr.aux[row])
@@ -700,6 +710,8 @@ class HumanoidWalkingTask:
     def validate(self, num_envs: int = 64, seconds: Optional[float] = None, seed_offset: int = 7919, _capture=None, _stepwise: bool = False) -> dict:
         """Deterministic validation rollout: a separate small env set (its own context, carries and buffers, so training state is
         untouched), actions = the distribution's mode, `render_length_seconds` long. Returns scalar statistics.
+        User Reset / Command / Observation terms are applied as in training; user TERMINATION terms (`extra_terminations`) are NOT - validation
+        episodes end by the built-in terminations (bad z, tilt, episode length) only, on the fused and on the step-wise path alike.
         `_capture(ctx, frame)` (view()): called after the reset (frame 0) and after every control step."""
         seconds = self.config.render_length_seconds if seconds is None else seconds
         T = max(1, int(round(seconds / self.config.ctrl_dt)))
@@ -736,7 +748,10 @@ class HumanoidWalkingTask:
             # observation from row T (the previous rollout's last), so the reset rows move there first.
             tr.actor_obs[T].copy_(tr.actor_obs[0]); tr.critic_obs[T].copy_(tr.critic_obs[0]); tr.aux[T].copy_(tr.aux[0])
             vctx.set_rollout_argmax(True)
-            vctx.rollout(self.params, carry.c, seed, 0, tr.c)
+            try:
+                vctx.rollout(self.params, carry.c, seed, 0, tr.c)
+            finally:
+                vctx.set_rollout_argmax(False)      # the cached context samples again whatever happened (the flag is context state, not a call argument)
         for t in range(0 if not fused else T, T):
             vctx.policy_step(self.params, tr.actor_obs[t], tr.critic_obs[t], carry.c, seed, t, True, tr.action[t], tr.logp[t], tr.value[t])
             vctx.env_step(tr.action[t], tr.aux[t], tr.actor_obs[t + 1], tr.critic_obs[t + 1], tr.aux[t + 1])

@@ -24,7 +24,6 @@ SWITCHES = {
     "KBJ_ROLLOUT_STEP=0": {"KBJ_ROLLOUT_STEP": "0"},
     "KBJ_DETERMINISTIC=1": {"KBJ_DETERMINISTIC": "1"},
     "KBJ_DEBUG=1": {"KBJ_DEBUG": "1"},
-    "KBJ_DW_DELAY_US=0": {"KBJ_DW_DELAY_US": "0"},
     "KBJ_BWD16=0": {"KBJ_BWD16": "0"},           # backward recurrences on the 32 x 32-tile form everywhere (round 4's kernel)
     "KBJ_BWD16=0+DET": {"KBJ_BWD16": "0", "KBJ_DETERMINISTIC": "1"},
     "KBJ_GEMM_X3=1": {"KBJ_GEMM_X3": "1"},       # = kbj_config.gemm_bf16x3: the backward pass's large GEMMs through the exact three-way bf16 split

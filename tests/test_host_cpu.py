@@ -319,6 +319,7 @@ def test_reference_reward_classes_on_a_ksim_shaped_trajectory_match_the_oracle(m
     import types
     import torch
     from kbot_joystick_amd.host import trajectory as TJ, view as V
+    from examples import reference_rewards as RR          # the reference's reward classes: example material, not product code
     from kbot_joystick_amd.spec import layout
     from oracle import oracle as O
     m = model_full
@@ -327,7 +328,7 @@ def test_reference_reward_classes_on_a_ksim_shaped_trajectory_match_the_oracle(m
     A, Q = L.AUX, L.QSTATE
     cfg = layout.default_config(num_envs=N)
     o = O.Oracle(m, cfg, precision="f64")
-    terms = TJ.reference_rewards(m, ctrl_dt=cfg.ctrl_dt)
+    terms = RR.reference_rewards(m, ctrl_dt=cfg.ctrl_dt)
     assert list(terms) == list(constants.REWARD_NAMES)
     assert [t.scale for t in terms.values()] == pytest.approx(list(cfg.reward_scale))
     carries = {}
