@@ -57,6 +57,19 @@ def cpu_baseline(repeats: int = 3):
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count() or 1
+    # The CPU time this process may actually use: a container's cgroup quota is NOT visible in the affinity mask. Round 5's sweep on the GPU
+    # box ran 16 / 32 threads at 4.46 / 8.13 s per probe: the box gives a one-GPU job the CPU time of about 16 cores (cpu.max), so 32 busy
+    # threads are 2x oversubscribed - OpenMP's and torch's workers spin at their barriers while their partners wait for a time slice. The
+    # sweep therefore stops at the quota (when one is set), and the line reports it.
+    quota = None
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: None if t.split()[0] == "max" else float(t.split()[0]) / float(t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: None if int(t) <= 0 else int(t) / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))):
+        try:
+            quota = parse(open(path).read().strip())
+            break
+        except (OSError, ValueError, IndexError, ZeroDivisionError):
+            continue
+    budget_cores = usable if quota is None else max(1, min(usable, int(quota + 0.5)))
     model = compiler.load_model("kbot-headless")
 
     def set_threads(n):
@@ -82,7 +95,7 @@ def cpu_baseline(repeats: int = 3):
         time budget is spent; every point is printed as it is measured (a silent sweep looks hung)"""
         sweep, spent = {}, 0.0
         for n in candidates:
-            if n > usable and sweep:
+            if n > budget_cores and sweep:
                 break
             set_threads(n)
             if not sweep:
@@ -104,22 +117,27 @@ def cpu_baseline(repeats: int = 3):
     t1 = float(np.median(ts1))
     del tr
     # ---- large sample: 2048 envs, batch 512 ----
-    sweep_l = sweep_threads(make(2048, 20, 512), (16, 32, 64, 128, 256), "2048 envs x 20 steps, batch 512", 60.0)
+    sweep_l = sweep_threads(make(2048, 20, 512), (8, 16, 32, 64, 128, 256), "2048 envs x 20 steps, batch 512", 60.0)
     best_l = min(sweep_l, key=sweep_l.get)
     set_threads(best_l)
-    trl = make(2048, 100, 512)
-    t_large = timed(trl)              # one full iteration (its pools are warm from the probe at the same setting)
-    print(f"bench.py: cpu_baseline large sample: 2048 envs x 100 steps at {best_l} threads -> {t_large:.2f} s", file=sys.stderr, flush=True)
+    T_large = 50                      # 2048 envs x 50 steps per timed iteration: ~10 s each at the round-5 rate, three of them = the bounded sample
+    trl = make(2048, T_large, 512)
+    trl.train_iteration()             # warm-up at the chosen setting (its own buffers)
+    tsl = [timed(trl) for _ in range(repeats)]
+    t_large = float(np.median(tsl))
+    print(f"bench.py: cpu_baseline large sample: 2048 envs x {T_large} steps at {best_l} threads -> median of {repeats} = {t_large:.2f} s "
+          f"(runs {', '.join('%.2f' % t for t in tsl)})", file=sys.stderr, flush=True)
     del trl
     set_threads(best_s)
     tr0 = make(4, 64)
     tr0.train_iteration()
     t0 = float(np.median([timed(tr0) for _ in range(3)]))
-    return dict(value=2048 * 100 / t_large, unit="env-steps/s", cores=best_l, kind="port", host_cores=os.cpu_count(), usable_cores=usable,
-                samples=1,
-                sample=f"SINGLE SAMPLE (one timed iteration, ~20 s of CPU work; BASELINE.md section 3's median-of-3 applies to small_sample): "
-                       f"oracle full iteration (rollout + GAE + 3 passes) on 2048 envs x 100 steps, batch 512, hidden 256: one iteration = {t_large:.2f} s at the best "
-                       f"of the thread sweep ({best_l} threads; this process may use {usable} of the host's {os.cpu_count()} cores)",
+    return dict(value=2048 * T_large / t_large, unit="env-steps/s", cores=best_l, kind="port", host_cores=os.cpu_count(), usable_cores=usable,
+                cgroup_cpu_quota_cores=quota, samples=repeats,
+                sample=f"oracle full iteration (rollout + GAE + 3 passes) on 2048 envs x {T_large} steps, batch 512, hidden 256: median of {repeats} iterations = "
+                       f"{t_large:.2f} s (runs {', '.join('%.2f' % t for t in tsl)}) at the best of the thread sweep ({best_l} threads; the affinity mask shows "
+                       f"{usable} of the host's {os.cpu_count()} cores, the cgroup CPU quota is {'none' if quota is None else '%.1f cores' % quota}: the sweep stops "
+                       f"at the quota, more busy threads than that only oversubscribe it - round 5's 32-thread point was 1.8x slower than 16 for that reason)",
                 thread_sweep_probe="2048 envs x 20 steps, batch 512: seconds per iteration by thread count (stops at the first setting > 1.3x the best or after 60 s)",
                 thread_sweep_seconds_per_iteration={str(k): v for k, v in sweep_l.items()},
                 small_sample=dict(value=256 * 100 / t1, unit="env-steps/s", cores=best_s,

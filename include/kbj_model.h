@@ -132,7 +132,9 @@ typedef struct kbj_config {
   int32_t depth;             /* LSTM layers per net, 1..KBJ_MAX_DEPTH (train.py:82-85: 2) */
   int32_t batch_size;        /* envs per minibatch */
   int32_t num_passes;
-  int32_t command_mode;      /* 0 = UnifiedCommand sampler (train.py:710-785); 1 = fixed command */
+  int32_t command_mode;      /* 0 = UnifiedCommand sampler (train.py:710-785); 1 = fixed command; 2 = the sampler (and PlaneXYPositionReset,
+                                train.py:834-836) with jax.random's own key handling below the call key: split / uniform / bernoulli / randint as jax
+                                0.6.0 derives them from a threefry key (csrc/kbj_env_core.h "jax.random key handling"; UNVERIFIED against a live JAX) */
   int32_t enable_randomizers;
   int32_t enable_pushes;
   int32_t enable_noise;

@@ -56,6 +56,7 @@ int kbj_check_config(const kbj_config* cfg, char* why, size_t why_bytes) {
   };
   if (!cfg) return fail("null config");
   if (cfg->num_envs <= 0 || cfg->substeps <= 0 || cfg->rollout_len <= 0) return fail("bad config sizes");
+  if (cfg->command_mode < 0 || cfg->command_mode > 2) return fail("command_mode must be 0 (UnifiedCommand sampler), 1 (fixed command) or 2 (the sampler with jax.random's key handling)");
   if (cfg->solver_newton != 1) return fail("only the Newton solver is implemented on the GPU (solver_newton = 1)");
   if (cfg->hidden_size < 1 || cfg->hidden_size > 512 || cfg->depth < 1 || cfg->depth > KBJ_MAX_DEPTH)
     return fail("hidden_size must be in 1..512 (multiples of 64 run unpadded; above 256 on the wide, untuned schedule) and depth in 1..4 (train.py:78-85 defaults 128 / 2, launch 256 / 2)");

@@ -311,4 +311,37 @@ KBJ_DEV float rng_normal(const Rng& r, int stream, uint32_t a, uint32_t b) {  //
   return sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
 }
 
+
+// ---- jax.random key handling (a25; kbj_config.command_mode == 2) -------------------------------------------------------------------
+// The in-tree samplers of the reference (UnifiedCommand train.py:725-752, 782-785; PlaneXYPositionReset train.py:834-836) are written against
+// jax.random: `split`, `uniform`, `bernoulli`, `randint` on threefry2x32 keys. In this mode the kernels derive those draws FROM THE KEY THE
+// SAMPLER IS CALLED WITH exactly as jax 0.6.0 does by default (requirements.lock:72; jax_threefry_partitionable = True since jax 0.5):
+//   split(key, n)[i]              = threefry2x32(key, counter (0, i))                                   (both output words = the new key)
+//   random_bits(key, 32, shape)[i] = x0 ^ x1 of threefry2x32(key, counter (0, i))   (shape () = index 0)
+//   uniform(key, shape, lo, hi)   = max(lo, u * (hi - lo) + lo), u = bitcast((bits >> 9) | 0x3F800000) - 1    (mantissa fill; mul and add round separately)
+//   bernoulli(key, p, shape)      = uniform(key, shape) < p
+//   randint(key, (), 0, span)     = ((hi % span) * (2^32 % span) + lo % span) % span with hi, lo = random_bits of split(key)[0], [1]
+// What stays this build's own is the tree ABOVE the call (how ksim's engine derives the per-env, per-step key it passes in: un-vendored): the
+// call key is threefry(seed ^ stream, env; counters) as everywhere else. Pinned offline by the public known answers of jax.random (split and
+// uniform of PRNGKey(0), tests/test_oracle_task.py) on the Python restatement oracle/jax_random.py, which the C++ oracle and these kernels
+// are compared with; against a live JAX the mode is UNVERIFIED (no JAX in the image).
+struct JaxKey { uint32_t k0, k1; };
+#ifdef KBJ_EMU
+KBJ_DEV float mul_add_2r(float a, float b, float c) { volatile float p = a * b; return p + c; }
+#else
+KBJ_DEV float mul_add_2r(float a, float b, float c) { return __fadd_rn(__fmul_rn(a, b), c); }   // never contracted into one fma
+#endif
+KBJ_DEV JaxKey jax_split(const JaxKey& k, uint32_t i) { JaxKey o; threefry2x32(k.k0, k.k1, 0u, i, o.k0, o.k1); return o; }
+KBJ_DEV uint32_t jax_bits(const JaxKey& k, uint32_t i) { uint32_t a, b; threefry2x32(k.k0, k.k1, 0u, i, a, b); return a ^ b; }
+KBJ_DEV float jax_u01(const JaxKey& k, uint32_t i) { union { float f; uint32_t u; } x; x.u = (jax_bits(k, i) >> 9) | 0x3F800000u; return x.f - 1.0f; }
+KBJ_DEV float jax_uniform(const JaxKey& k, uint32_t i, float lo, float hi) { return fmaxf(lo, mul_add_2r(jax_u01(k, i), hi - lo, lo)); }
+KBJ_DEV uint32_t jax_randint(const JaxKey& k, uint32_t span) {
+  const JaxKey k1 = jax_split(k, 0), k2 = jax_split(k, 1);
+  const uint32_t hb = jax_bits(k1, 0), lb = jax_bits(k2, 0);
+  uint32_t mult = 65536u % span;
+  mult = (mult * mult) % span;
+  return ((hb % span) * mult + lb % span) % span;
+}
+KBJ_DEV JaxKey jax_call_key(const Rng& r, int stream, uint32_t a, uint32_t b) { JaxKey k; rng_bits(r, stream, a, b, k.k0, k.k1); return k; }
+
 }  // namespace kbj

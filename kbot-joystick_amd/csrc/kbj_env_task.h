@@ -53,9 +53,32 @@ KBJ_DEV void task_randomize(KbjShared& S, const kbj_model& m, const kbj_config& 
   KBJ_SYNC();
 }
 
+// one of the six command templates (train.py:741-763)
+KBJ_DEV void task_command_template(int mode, float vx, float vy, float wz, float bh, float rx, float ry, const float* arms, float* cmd) {
+  for (int k = 0; k < KBJ_NCMD; ++k) cmd[k] = 0;
+  if (mode == 0) cmd[0] = vx;
+  else if (mode == 1) cmd[1] = vy;
+  else if (mode == 2) cmd[2] = wz;
+  else if (mode == 3) { cmd[0] = vx; cmd[1] = vy; cmd[2] = wz; for (int j = 0; j < 10; ++j) cmd[6 + j] = arms[j]; }
+  else if (mode == 4) { cmd[3] = bh; cmd[4] = rx; cmd[5] = ry; for (int j = 0; j < 10; ++j) cmd[6 + j] = arms[j]; }
+}
+// UnifiedCommand.initial_command with jax.random's key handling (command_mode == 2; kbj_env_core.h): `rng` is the key the method is called with
+KBJ_DEV void task_sample_command_jax(const kbj_model& m, const kbj_config& c, const JaxKey& rng, float* cmd) {
+  JaxKey ks[9];   // rng_a .. rng_i = jax.random.split(rng, 9)   (train.py:725)
+  for (uint32_t i = 0; i < 9; ++i) ks[i] = jax_split(rng, i);
+  const float vx = jax_uniform(ks[1], 0, c.vx_lo, c.vx_hi), vy = jax_uniform(ks[2], 0, c.vy_lo, c.vy_hi), wz = jax_uniform(ks[3], 0, c.wz_lo, c.wz_hi);
+  const float bh = jax_uniform(ks[4], 0, c.bh_lo, c.bh_hi), rx = jax_uniform(ks[5], 0, c.rx_lo, c.rx_hi), ry = jax_uniform(ks[6], 0, c.ry_lo, c.ry_hi);
+  float arms[10];
+  for (uint32_t j = 0; j < 10; ++j) {   // uniform(rng_h, (10,), lo, hi) * bernoulli(rng_h, shape=(10,)): the SAME key, hence the same bits (train.py:734-738)
+    const float lo = m.dof_range[16 + j][0], hi = m.dof_range[16 + j][1];
+    arms[j] = jax_uniform(ks[7], j, lo, hi) * (jax_u01(ks[7], j) < 0.5f ? 1.0f : 0.0f);
+  }
+  task_command_template((int)jax_randint(ks[0], 6u), vx, vy, wz, bh, rx, ry, arms, cmd);   // mode = randint(rng_a, (), 0, 6)   (train.py:752)
+}
 // UnifiedCommand.initial_command (train.py:724-766); one lane
 KBJ_DEV void task_sample_command(const kbj_model& m, const kbj_config& c, const Rng& rng, uint32_t a, uint32_t off, float* cmd) {
   if (c.command_mode == 1) { for (int k = 0; k < KBJ_NCMD; ++k) cmd[k] = c.fixed_command[k]; return; }
+  if (c.command_mode == 2) { task_sample_command_jax(m, c, jax_call_key(rng, KBJ_RNG_COMMAND, a, off), cmd); return; }
   float vx = rng_uniform(rng, KBJ_RNG_COMMAND, a, off + 2, c.vx_lo, c.vx_hi), vy = rng_uniform(rng, KBJ_RNG_COMMAND, a, off + 3, c.vy_lo, c.vy_hi);
   float wz = rng_uniform(rng, KBJ_RNG_COMMAND, a, off + 4, c.wz_lo, c.wz_hi), bh = rng_uniform(rng, KBJ_RNG_COMMAND, a, off + 5, c.bh_lo, c.bh_hi);
   float rx = rng_uniform(rng, KBJ_RNG_COMMAND, a, off + 6, c.rx_lo, c.rx_hi), ry = rng_uniform(rng, KBJ_RNG_COMMAND, a, off + 7, c.ry_lo, c.ry_hi);
@@ -68,13 +91,7 @@ KBJ_DEV void task_sample_command(const kbj_model& m, const kbj_config& c, const 
   }
   uint32_t b0, b1;
   rng_bits(rng, KBJ_RNG_COMMAND, a, off + 1, b0, b1);
-  int mode = (int)(b0 % 6u);
-  for (int k = 0; k < KBJ_NCMD; ++k) cmd[k] = 0;
-  if (mode == 0) cmd[0] = vx;
-  else if (mode == 1) cmd[1] = vy;
-  else if (mode == 2) cmd[2] = wz;
-  else if (mode == 3) { cmd[0] = vx; cmd[1] = vy; cmd[2] = wz; for (int j = 0; j < 10; ++j) cmd[6 + j] = arms[j]; }
-  else if (mode == 4) { cmd[3] = bh; cmd[4] = rx; cmd[5] = ry; for (int j = 0; j < 10; ++j) cmd[6 + j] = arms[j]; }
+  task_command_template((int)(b0 % 6u), vx, vy, wz, bh, rx, ry, arms, cmd);
 }
 
 // PositionActuators (train.py:1097-1105): tau = kp (a + bias - q) - kd qdot, clipped to the randomised soft limit
@@ -109,6 +126,11 @@ KBJ_DEV void task_reset(KbjShared& S, const kbj_model& m, const kbj_config& c, c
     es[KBJ_ES_QPOS + 3] = cosf(yaw / 2); es[KBJ_ES_QPOS + 4] = 0; es[KBJ_ES_QPOS + 5] = 0; es[KBJ_ES_QPOS + 6] = sinf(yaw / 2);
     es[KBJ_ES_QPOS + 0] = rng_uniform(rng, KBJ_RNG_RESET, e, 43, -c.reset_xy_range, c.reset_xy_range);
     es[KBJ_ES_QPOS + 1] = rng_uniform(rng, KBJ_RNG_RESET, e, 44, -c.reset_xy_range, c.reset_xy_range);
+    if (c.command_mode == 2) {   // PlaneXYPositionReset with jax.random's key handling: keyx, keyy = split(rng); uniform(key, (1,), -r, r)   (train.py:834-836)
+      const JaxKey k = jax_call_key(rng, KBJ_RNG_RESET, e, 43);
+      es[KBJ_ES_QPOS + 0] = jax_uniform(jax_split(k, 0), 0, -c.reset_xy_range, c.reset_xy_range);
+      es[KBJ_ES_QPOS + 1] = jax_uniform(jax_split(k, 1), 0, -c.reset_xy_range, c.reset_xy_range);
+    }
     es[KBJ_ES_QPOS + 2] = m.qpos0[2];
     if (pc.tamp != 0) {  // stand on the highest of five terrain samples under the robot (centre, +-0.15 m in x and y)
       const float sx[5] = {0, 0.15f, -0.15f, 0, 0}, sy[5] = {0, 0, 0, 0.15f, -0.15f};
@@ -315,6 +337,10 @@ KBJ_DEV void task_step(KbjShared& S, const kbj_model& m, const kbj_config& c, co
   else {
     PFOR(w, 1) {  // UnifiedCommand.__call__ (train.py:768-785)
       if (c.command_mode == 0 && rng_u01(rng, KBJ_RNG_COMMAND, st + 1, 0) < c.switch_prob) task_sample_command(m, c, rng, st + 1, 0, es + KBJ_ES_CMD);
+      if (c.command_mode == 2) {   // the same with jax.random's key handling: rng_a, rng_b = split(rng); bernoulli(rng_a, switch_prob); initial_command(rng_b)
+        const JaxKey k = jax_call_key(rng, KBJ_RNG_COMMAND, st + 1, 0);
+        if (jax_u01(jax_split(k, 0), 0) < c.switch_prob) task_sample_command_jax(m, c, jax_split(k, 1), es + KBJ_ES_CMD);
+      }
     }
     KBJ_SYNC();
   }

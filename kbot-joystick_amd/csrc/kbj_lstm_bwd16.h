@@ -23,9 +23,6 @@ constexpr int BWD16_ROWS = 16, BWD16_UNITS = 64, BWD16_NTH = 512;
 #ifndef KBJ_BWD16_OWN_SPLIT
 #define KBJ_BWD16_OWN_SPLIT 4   // 16-k blocks (of 8) of the own chunk's contraction issued BEFORE the flag poll; the rest hides the partner chunks' flight
 #endif
-#ifndef KBJ_BWD16_OWN_PRE
-#define KBJ_BWD16_OWN_PRE 2     // of those, the blocks issued already at the END of the producing step, between its payload stores and their drain (round 6:
-#endif                          // the write-through stores' way to L2, ~900 cycles per step, used to pass with an idle matrix pipe; seq_publish_nb)
 
 template <int H>
 __global__ __launch_bounds__(BWD16_NTH) void lstm_seq_bwd16_kernel(SeqBwdArgs a) {
@@ -39,7 +36,6 @@ __global__ __launch_bounds__(BWD16_NTH) void lstm_seq_bwd16_kernel(SeqBwdArgs a)
   __shared__ __attribute__((aligned(16))) float cbuf[2][ROWS * LDC];      // chunk buffers: own chunk in [0], partner chunks alternate [1], [0], [1]
   __shared__ float pbuf[2][ROWS][UNITS + 4];                               // the two k halves' partial sums of dh
   __shared__ int flag;
-  __shared__ unsigned arrivals;                                             // seq_publish_nb
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nt = wave & 3, kh = wave >> 2;
   // XCD-aware mapping (speed only): workgroups b, b + 8, ... share an XCD, so give each XCD whole row groups
   const int nblk = gridDim.x;
@@ -48,7 +44,6 @@ __global__ __launch_bounds__(BWD16_NTH) void lstm_seq_bwd16_kernel(SeqBwdArgs a)
   const int r0 = rg * ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
   const bool full = r0 + ROWS <= B;
-  if (tid == 0) arrivals = 0;
   if (seq_aborted(a.err, &flag)) return;
   // B operands. Chunk j of this workgroup = partner (ug + j) % NUG (own chunk first); k-step s of the wave's half: local k = KHALF kh + KK::kidx(s, g),
   // i.e. gate = local k / 64, unit = local k % 64 of that partner; column = this wave's unit tile.
@@ -117,8 +112,6 @@ __global__ __launch_bounds__(BWD16_NTH) void lstm_seq_bwd16_kernel(SeqBwdArgs a)
     }
   };
   constexpr int OWN_SPLIT = NUG > 1 ? KBJ_BWD16_OWN_SPLIT : KK::NB;
-  constexpr int OWN_PRE = KBJ_BWD16_OWN_PRE < OWN_SPLIT ? KBJ_BWD16_OWN_PRE : OWN_SPLIT;
-  f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
   for (int t = T - 1; t >= 0; --t) {
     float dhm[2] = {0.0f, 0.0f};
     float act[2][4], tc[2], cprev[2], dha[2], kp[2];
@@ -129,9 +122,9 @@ __global__ __launch_bounds__(BWD16_NTH) void lstm_seq_bwd16_kernel(SeqBwdArgs a)
     };
     if (t == T - 1) prefetch();
     else {
-      // the own chunk of dG_{t+1} sits in cbuf[0] (written by the cell of the previous iteration, made visible by the barrier behind it; its first
-      // OWN_PRE blocks were contracted there, under the payload's drain)
-      mma(cbuf[0], wreg[0], acc0, acc1, OWN_PRE, OWN_SPLIT);
+      // the own chunk of dG_{t+1} sits in cbuf[0] (written by the cell of the previous iteration, made visible by its publish barrier)
+      f32x4m acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      mma(cbuf[0], wreg[0], acc0, acc1, 0, OWN_SPLIT);
       Chunk ch[NUG > 1 ? NUG - 1 : 1];
       if (NUG > 1) {
         if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)(T - 1 - t), a.err, &flag, a.timeout_ticks)) return;
@@ -174,19 +167,7 @@ __global__ __launch_bounds__(BWD16_NTH) void lstm_seq_bwd16_kernel(SeqBwdArgs a)
       }
       dcm[i] = dc * fg;
     }
-#ifdef KBJ_SEQ_OLD_PUBLISH   // A/B: the round-5 hand-off (drain, workgroup barrier - which also publishes cbuf[0] inside the workgroup -, flag)
-    acc0 = f32x4m{0, 0, 0, 0}; acc1 = acc0;
-    seq_publish(a.counters + rg * NUG + ug, (unsigned)(T - t));
-    continue;
-#endif
-    __syncthreads();                                               // cbuf[0] is complete (and every wavefront's payload stores are issued)
-    acc0 = f32x4m{0, 0, 0, 0}; acc1 = acc0;
-    if (OWN_PRE > 0 && t > 0) {                                    // the next step's contraction starts on the own chunk while the payload travels to L2
-      __builtin_amdgcn_sched_barrier(0);
-      mma(cbuf[0], wreg[0], acc0, acc1, 0, OWN_PRE);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    seq_publish_nb(a.counters + rg * NUG + ug, (unsigned)(T - t), &arrivals, NTH / 64);    // drain, last wavefront to arrive stores the flag
+    seq_publish(a.counters + rg * NUG + ug, (unsigned)(T - t));    // drain, barrier (also publishes cbuf[0] inside the workgroup), flag
   }
   // bias gradient = column sums of dG over all rows and steps: this workgroup's 16 rows through cbuf[0] (the own-chunk layout), one atomic per column
   if (a.db || a.db_part) {

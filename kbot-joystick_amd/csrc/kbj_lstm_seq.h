@@ -97,6 +97,10 @@ __device__ __forceinline__ float seq_tanh(float x) { float xc = fminf(fmaxf(x, -
 // error word (a partner that timed out or a launch that was aborted will never publish): a failing call drains in one bound, not in
 // steps x bound.
 __device__ __forceinline__ bool seq_wait(unsigned* flags, int nflags, unsigned target, unsigned* err, int* lds_flag, unsigned timeout_ticks) {
+#ifdef KBJ_EXPERIMENT_NOWAIT   // TIMING EXPERIMENT ONLY (wrong results): what a step costs when the partners' flags never have to be waited for
+  __syncthreads();
+  return true;
+#endif
   if (threadIdx.x < 64) {
     unsigned spins = 0;
     unsigned long long t0 = 0;
@@ -132,20 +136,11 @@ __device__ __forceinline__ bool seq_aborted(unsigned* err, int* lds_flag) {
 __device__ __forceinline__ void seq_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // every storing wave drains its (payload) stores, the workgroup meets, one lane signals
 __device__ __forceinline__ void seq_publish(unsigned* my_flag, unsigned steps_done) {
+#ifndef KBJ_EXPERIMENT_NODRAIN   // TIMING EXPERIMENT ONLY (wrong results): the flag without the payload's drain in front of it
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
   __syncthreads();
   if (threadIdx.x == 0) __hip_atomic_store(my_flag, steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 store, never a plain one
-}
-// Barrier-free publish (round 6): every wavefront drains its own payload stores and counts itself in on a monotonic LDS counter; the LAST one
-// to arrive for this step (arrivals = waves x steps) stores the flag. The workgroup barrier of seq_publish is gone, and - the point - matrix
-// work issued between the payload stores and this call runs while the write-through stores travel to L2 (~900 cycles per step that were
-// spent with an idle matrix pipe). `arrivals` is zeroed before the first step (a barrier lies between, seq_aborted's).
-__device__ __forceinline__ void seq_publish_nb(unsigned* my_flag, unsigned steps_done, unsigned* arrivals, unsigned nwaves) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if ((threadIdx.x & 63) == 0) {
-    const unsigned old = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (old + 1 == nwaves * steps_done) __hip_atomic_store(my_flag, steps_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sc1 store, never a plain one
-  }
 }
 // k order of the register-resident products. The A operand of v_mfma_f32_16x16x4_f32 is one float per lane (row = lane & 15,
 // k slot g = lane >> 4); WHICH k a slot holds in a given step is free as long as the B registers (the weight slices) use the same
@@ -263,15 +258,10 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
 #define KBJ_SEQ_XSPLIT_NUM 4   // eighths of the input projection's k-steps issued before the flag poll (the rest hides the tile fetch)
 #endif
   constexpr int XSPLIT = KXK::NB * KBJ_SEQ_XSPLIT_NUM / 8;   // in 16-k blocks
-#ifndef KBJ_SEQ_XPRE_NUM
-#define KBJ_SEQ_XPRE_NUM 1     // eighths of the NEXT step's input projection issued between this step's payload stores and their drain (seq_publish_nb)
-#endif
-  constexpr int XPRE = FUSE ? (KXK::NB * KBJ_SEQ_XPRE_NUM / 8 < XSPLIT ? KXK::NB * KBJ_SEQ_XPRE_NUM / 8 : XSPLIT) : 0;
   __shared__ __attribute__((aligned(16))) float hs[SEQ_ROWS * LDH];
   __shared__ __attribute__((aligned(16))) float xs[FUSE ? SEQ_ROWS * LDX : 4];
   __shared__ float gbuf[4][SEQ_ROWS][UNITS + 4];   // row stride = 4 (mod 8): the accumulator rows of lanes 0-15 / 16-31 (4 rows apart) fall on disjoint banks
   __shared__ int flag;
-  __shared__ unsigned arrivals;                     // seq_publish_nb
   const int tid = threadIdx.x, lane = tid & 63, gate = (tid >> 6) & 3, uh = tid >> 8;
   // XCD-aware mapping (speed only, the protocol is placement independent): workgroups b, b+8, b+16, ... share an XCD,
   // so give each XCD whole row groups and the tile hand-off stays inside one L2
@@ -280,7 +270,6 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * SEQ_ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
-  if (tid == 0) arrivals = 0;
   if (seq_aborted(a.err, &flag)) return;
   // W_hh rows of this wave's gate for the 16 units, as B operands: B[k slot g][col] = Whh[gate H + u0 + col][KH::kidx(step, g)]
   float wreg[H / 4];
@@ -336,15 +325,14 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
     if (KX == H) xt.to_lds(xs, r0, B); else xt.to_lds_cols(xs, LDX, r0, B, kxv);
     __syncthreads();
   }
-  f32x4m acc0 = {bias_col, bias_col, bias_col, bias_col}, acc1 = acc0;
-  if (XPRE > 0) KXK::template mma<false>(xs, lane, wxreg, acc0, acc1, 0, XPRE);   // step 0's share of what every later step finds done by its predecessor
   for (int t = 0; t < T; ++t) {
     SEQ_STAMP(0);
     float gx[2][4], kp[2];   // this step's own inputs, fetched one step ago (taken over before any load of this step is in flight)
 #pragma unroll
     for (int i = 0; i < 2; ++i) { kp[i] = kpn[i]; for (int k = 0; k < 4; ++k) gx[i][k] = gxn[i][k]; }
-    if (FUSE) {   // first part of the input projection: runs while the partners' flags travel (its first XPRE blocks ran under the previous step's drain)
-      KXK::template mma<false>(xs, lane, wxreg, acc0, acc1, XPRE, XSPLIT);
+    f32x4m acc0 = {bias_col, bias_col, bias_col, bias_col}, acc1 = acc0;
+    if (FUSE) {   // first half of the input projection: runs while the partners' flags travel
+      KXK::template mma<false>(xs, lane, wxreg, acc0, acc1, 0, XSPLIT);
     }
     if (t > 0) { if (!seq_wait(a.counters + rg * NUG, NUG, (unsigned)t, a.err, &flag, a.timeout_ticks)) return; }
     SEQ_STAMP(1);
@@ -396,17 +384,7 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
       if (r0 + row < B) seq_store(a.Hm + ((size_t)(t + 1) * B + r0 + row) * H + u0 + u, hh[i] * kp[i]);  // the hand-off payload
     }
     SEQ_STAMP(4);
-    acc0 = f32x4m{bias_col, bias_col, bias_col, bias_col}; acc1 = acc0;
-    if (XPRE > 0 && t + 1 < T) {   // the next step's input projection starts here: its tile is staged (the barrier above), and these MFMAs run while the payload drains
-      __builtin_amdgcn_sched_barrier(0);
-      KXK::template mma<false>(xs, lane, wxreg, acc0, acc1, 0, XPRE);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#ifdef KBJ_SEQ_OLD_PUBLISH   // A/B: the round-5 hand-off (drain, workgroup barrier, flag)
     seq_publish(a.counters + rg * NUG + ug, (unsigned)(t + 1));
-#else
-    seq_publish_nb(a.counters + rg * NUG + ug, (unsigned)(t + 1), &arrivals, NTH / 64);
-#endif
     SEQ_STAMP(5);
   }
   // BPTT stash of the last step

@@ -75,6 +75,11 @@ class HumanoidWalkingTaskConfig:
     robot: str = "kbot"                # train.py:1080 loads robot/kbot; BASELINE configs use kbot-headless
     seed: int = 0
     fixed_command: Optional[tuple] = None   # BASELINE configs[1]: flat-ground fixed joystick velocity command
+    # a25: the in-tree samplers (UnifiedCommand train.py:725-752, 782-785; PlaneXYPositionReset train.py:834-836) derive their draws from the key
+    # they are called with exactly as jax.random does (split = threefry over a counter, uniform = mantissa fill, bernoulli, randint:
+    # kbj_config.command_mode = 2). The key each call RECEIVES is still this build's own (ksim's split tree is un-vendored), and no JAX is in the
+    # image to produce fixtures: pinned by jax.random's public known answers only, UNVERIFIED against a live JAX. Off by default.
+    jax_random_keys: bool = False
     terrain: str = "flat"                   # "flat" | "sine" (train.py:1081 loads the "sine" scene; BASELINE configs[4])
     terrain_amplitude: float = 0.05         # metres; the surface definition is this build's own
     terrain_wavelength: float = 2.0
@@ -142,7 +147,11 @@ class HumanoidWalkingTaskConfig:
             raise ValueError(f"unknown terrain {self.terrain!r} (flat | sine)")
         if self.terrain == "sine":
             kw.update(terrain_amp=self.terrain_amplitude, terrain_wavelength=self.terrain_wavelength)
+        if self.jax_random_keys:
+            kw.update(command_mode=2)           # (a fixed command below overrides the sampler, not the reset's key handling... which command_mode 1 switches off too)
         if self.fixed_command is not None:
+            if self.jax_random_keys:
+                raise ValueError("jax_random_keys selects the UnifiedCommand SAMPLER with jax.random's key handling; it cannot be combined with fixed_command")
             cmd = list(self.fixed_command) + [0.0] * (L.NCMD - len(self.fixed_command))
             kw.update(command_mode=1, fixed_command=cmd)
         for k, (lo, hi) in (self.command_ranges or {}).items():

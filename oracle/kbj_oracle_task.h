@@ -6,6 +6,7 @@
 // (b-vm/ksim@e88d8bc, requirements.lock:100) follow the definitions frozen in DESIGN.md "Spec decisions".
 // PARITY WITH THE JAX REFERENCE IS UNPINNED.
 #pragma once
+#include <cstring>
 #include "kbj_oracle_physics.h"
 
 namespace kbjo {
@@ -172,9 +173,43 @@ template <class R> struct Env {
     for (int k = KBJ_EP_MU + 1; k < KBJ_EP_SIZE; ++k) ep[k] = 0;
   }
 
+  // ---- jax.random's key handling for the in-tree samplers (command_mode == 2; the jax 0.6.0 default, threefry "partitionable"): see the
+  // statement in kbot-joystick_amd/csrc/kbj_env_core.h and the Python restatement oracle/jax_random.py that pins both against jax.random's
+  // public known answers. Written here on its own (uint32 arithmetic; the float steps with separate roundings: -ffp-contract=off).
+  struct JKey { uint32_t a, b; };
+  static JKey jsplit(JKey k, uint32_t i) { JKey o; threefry2x32(k.a, k.b, 0u, i, o.a, o.b); return o; }
+  static uint32_t jbits(JKey k, uint32_t i) { uint32_t x, y; threefry2x32(k.a, k.b, 0u, i, x, y); return x ^ y; }
+  static float ju01(JKey k, uint32_t i) { uint32_t w = (jbits(k, i) >> 9) | 0x3F800000u; float f; std::memcpy(&f, &w, 4); return f - 1.0f; }
+  static float juniform(JKey k, uint32_t i, float lo, float hi) { float p = ju01(k, i) * (hi - lo); p = p + lo; return std::fmax(lo, p); }
+  static uint32_t jrandint(JKey k, uint32_t span) {
+    uint32_t hb = jbits(jsplit(k, 0), 0), lb = jbits(jsplit(k, 1), 0), mult = 65536u % span;
+    mult = (mult * mult) % span;
+    return ((hb % span) * mult + lb % span) % span;
+  }
+  JKey call_key(int stream, uint32_t a, uint32_t b) const { JKey k; rng.bits(stream, a, b, k.a, k.b); return k; }
+  void sample_command_jax(JKey key, float* cmd) {   // train.py:724-766 with `rng` = key
+    JKey ks[9];
+    for (uint32_t i = 0; i < 9; ++i) ks[i] = jsplit(key, i);
+    float vx = juniform(ks[1], 0, c->vx_lo, c->vx_hi), vy = juniform(ks[2], 0, c->vy_lo, c->vy_hi), wz = juniform(ks[3], 0, c->wz_lo, c->wz_hi);
+    float bh = juniform(ks[4], 0, c->bh_lo, c->bh_hi), rx = juniform(ks[5], 0, c->rx_lo, c->rx_hi), ry = juniform(ks[6], 0, c->ry_lo, c->ry_hi);
+    float arms[10];
+    for (uint32_t j = 0; j < 10; ++j) arms[j] = juniform(ks[7], j, m->dof_range[16 + j][0], m->dof_range[16 + j][1]) * (ju01(ks[7], j) < 0.5f ? 1.0f : 0.0f);
+    int mode = (int)jrandint(ks[0], 6u);
+    for (int k = 0; k < KBJ_NCMD; ++k) cmd[k] = 0;
+    switch (mode) {
+      case 0: cmd[0] = vx; break;
+      case 1: cmd[1] = vy; break;
+      case 2: cmd[2] = wz; break;
+      case 3: cmd[0] = vx; cmd[1] = vy; cmd[2] = wz; for (int j = 0; j < 10; ++j) cmd[6 + j] = arms[j]; break;
+      case 4: cmd[3] = bh; cmd[4] = rx; cmd[5] = ry; for (int j = 0; j < 10; ++j) cmd[6 + j] = arms[j]; break;
+      default: break;
+    }
+  }
+
   // UnifiedCommand.initial_command (train.py:724-766); `off` separates reset-time draws from switch draws
   void sample_command(uint32_t a, uint32_t off, float* cmd) {
     if (c->command_mode == 1) { for (int k = 0; k < KBJ_NCMD; ++k) cmd[k] = c->fixed_command[k]; return; }
+    if (c->command_mode == 2) { sample_command_jax(call_key(KBJ_RNG_COMMAND, a, off), cmd); return; }
     auto U = [&](uint32_t idx, float lo, float hi) { return rng.uf(KBJ_RNG_COMMAND, a, off + idx, lo, hi); };
     float vx = U(2, c->vx_lo, c->vx_hi), vy = U(3, c->vy_lo, c->vy_hi), wz = U(4, c->wz_lo, c->wz_hi);
     float bh = U(5, c->bh_lo, c->bh_hi), rx = U(6, c->rx_lo, c->rx_hi), ry = U(7, c->ry_lo, c->ry_hi);
@@ -212,6 +247,11 @@ template <class R> struct Env {
     float yaw = U(42, 3.14159265358979323846f);
     qpos[3] = (R)std::cos(yaw / 2); qpos[4] = 0; qpos[5] = 0; qpos[6] = (R)std::sin(yaw / 2);
     qpos[0] = (R)U(43, c->reset_xy_range); qpos[1] = (R)U(44, c->reset_xy_range);
+    if (c->command_mode == 2) {   // PlaneXYPositionReset (train.py:834-836) with jax.random's key handling
+      JKey k = call_key(KBJ_RNG_RESET, e, 43);
+      qpos[0] = (R)juniform(jsplit(k, 0), 0, -c->reset_xy_range, c->reset_xy_range);
+      qpos[1] = (R)juniform(jsplit(k, 1), 0, -c->reset_xy_range, c->reset_xy_range);
+    }
     if (phy.terrain_amp != 0) {  // stand on the highest of five terrain samples under the robot (centre, +-0.15 m in x and y)
       const R sx[5] = {0, (R)0.15, (R)-0.15, 0, 0}, sy[5] = {0, 0, 0, (R)0.15, (R)-0.15};
       R hmax = 0, nn[3];
@@ -373,6 +413,10 @@ template <class R> struct Env {
     else {
       // UnifiedCommand.__call__ (train.py:768-785)
       if (c->command_mode == 0 && rng.uniform(KBJ_RNG_COMMAND, st + 1, 0) < c->switch_prob) sample_command(st + 1, 0, es + KBJ_ES_CMD);
+      if (c->command_mode == 2) {   // rng_a, rng_b = split(rng); bernoulli(rng_a, switch_prob); initial_command(rng_b)
+        JKey k = call_key(KBJ_RNG_COMMAND, st + 1, 0);
+        if (ju01(jsplit(k, 0), 0) < c->switch_prob) sample_command_jax(jsplit(k, 1), es + KBJ_ES_CMD);
+      }
       store_state();
     }
     write_obs(actor_next, critic_next, aux_next);

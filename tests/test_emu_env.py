@@ -36,10 +36,13 @@ def test_reset_matches_oracle(which):
     assert np.abs(x0 - x1).max() < 1e-5
 
 
-def test_teacher_forced_steps_match_oracle(model):
+@pytest.mark.parametrize("command_mode", [0, 2])
+def test_teacher_forced_steps_match_oracle(model, command_mode):
+    """command_mode 2: the sampler (and PlaneXYPositionReset) on jax.random's key handling (a25) - the kernel body's integer key derivation and
+    two-rounding uniforms against the oracle's, bit for bit (the command block below), with a switch probability that exercises the branch."""
     emu = H.emu_lib()
     N = 48
-    cfg = L.default_config(num_envs=N)
+    cfg = L.default_config(num_envs=N, command_mode=command_mode, **(dict(switch_prob=0.2) if command_mode == 2 else {}))
     o = O.Oracle(model, cfg, seed=11, precision="f32")
     a0, c0, x0 = o.reset_all()
     ep, es = np.zeros_like(o.ep), np.zeros_like(o.es)

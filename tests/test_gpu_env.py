@@ -46,13 +46,15 @@ def test_reset_matches_oracle(which):
     ctx.close()
 
 
-@pytest.mark.parametrize("N,steps,command", [(128, 30, "sampler"), (8192, 12, "sampler"), (8192, 6, "fixed")])
+@pytest.mark.parametrize("N,steps,command", [(128, 30, "sampler"), (8192, 12, "sampler"), (8192, 6, "fixed"), (256, 20, "sampler on jax.random keys")])
 def test_teacher_forced_steps_match_oracle(model, N, steps, command):
     """One control step from the identical state, HIP vs the oracle: discrete results exact, continuous state within the measured
     tolerances (tests/helpers.TOL) and, at the BASELINE env count, within 2x the oracle's OWN fp32-vs-fp64 spread on the same
     env-steps. command = "fixed": BASELINE configs[1] (command_mode 1, (0.5, 0, 0)) - what bench.py times."""
     from oracle import oracle as O
     kw = dict(command_mode=1, fixed_command=[0.5] + [0.0] * 15) if command == "fixed" else {}
+    if command == "sampler on jax.random keys":      # a25: kbj_config.command_mode = 2 (the command block and the reset's x, y are compared bit for bit below)
+        kw = dict(command_mode=2, switch_prob=0.2)
     cfg = L.default_config(num_envs=N, batch_size=min(512, N), **kw)
     ctx, torch = _ctx(model, cfg)
     a, c, x = _obs(torch, N)

@@ -124,6 +124,10 @@ def test_reward_and_command_overrides_reach_kbj_config():
         launch_config(reward_params={"torque": {"standard_height": 1.0}}).to_kbj(4096)
     with pytest.raises(ValueError):
         launch_config(allreduce="sometimes").to_kbj(4096)
+    # a25: the samplers on jax.random's key handling = kbj_config.command_mode 2; the library's host-side check accepts 0..2 only
+    assert launch_config().to_kbj(4096).command_mode == 0 and launch_config(jax_random_keys=True).to_kbj(4096).command_mode == 2
+    with pytest.raises(ValueError):
+        launch_config(jax_random_keys=True, fixed_command=(0.5, 0.0, 0.0)).to_kbj(4096)
 
 
 def test_oracle_rewards_follow_the_config(model):

@@ -103,3 +103,63 @@ def test_episode_bookkeeping(model):
     assert (o.es[:, L.ES["TIME"]] == 1).all()               # new episode has advanced one step
     assert (o.es[:, L.ES["EPISODE"]].view(np.uint32) == 2).all()
     assert (o.es[:, L.ES["STEP"]].view(np.uint32) == 6).all()
+
+
+# ---- a25: jax.random's key handling (kbj_config.command_mode = 2) ------------------------------------------------------------------
+def test_jax_random_restatement_reproduces_jax_known_answers():
+    """oracle/jax_random.py against the PUBLIC known answers of jax.random (jax is not in the image; these constants are the ones jax's own
+    documentation and test-suite print for PRNGKey(0)): both key-derivation modes of `split`, and `uniform` in the original mode. The
+    partitionable mode's `split` is one threefry block per key - its first value is also the Random123 known answer for key 0, counter 0."""
+    from oracle import jax_random as JR
+    k0 = JR.PRNGKey(0)
+    assert JR.split(k0, 2, partitionable=False) == [(4146024105, 967050713), (2718843009, 1272950319)]
+    assert JR.split(k0, 2, partitionable=True) == [(1797259609, 2579123966), (928981903, 3453687069)]
+    assert JR.threefry2x32(k0, 0, 0) == (0x6B200159, 0x99BA4EFE)                      # Random123 KAT
+    assert float(JR.uniform(k0, 1, partitionable=False)[0]) == float(np.float32(0.41845703))
+    # mantissa fill: 23 random bits -> [0, 1), never 1; randint's double-draw formula stays in range and is exactly uniform over a multiple of the span
+    u = JR.uniform(JR.PRNGKey(7), 4096)
+    assert u.min() >= 0.0 and u.max() < 1.0 and abs(float(u.mean()) - 0.5) < 0.02
+    draws = [JR.randint(k, 0, 6) for k in JR.split(JR.PRNGKey(3), 600)]
+    assert min(draws) == 0 and max(draws) == 5 and all(abs(draws.count(v) - 100) < 40 for v in range(6))
+
+
+def test_command_mode_2_is_the_reference_sampler_on_jax_random_keys(model):
+    """kbj_config.command_mode = 2: the C++ oracle's commands equal `UnifiedCommand.initial_command` / `__call__` written in jax.random's
+    vocabulary (oracle/jax_random.unified_command*, a line-by-line restatement of train.py:724-785) on the per-call key this build derives
+    (threefry(seed ^ stream, env; step, offset)) - bit for bit, at reset and through the switch draws of the following steps."""
+    from oracle import jax_random as JR
+    N, seed = 64, 9
+    cfg = L.default_config(num_envs=N, command_mode=2, switch_prob=0.25, enable_pushes=0)
+    o = O.Oracle(model, cfg, seed=seed, precision="f32")
+    a, c, x = o.reset_all()
+    ranges = dict(vx=(cfg.vx_lo, cfg.vx_hi), vy=(cfg.vy_lo, cfg.vy_hi), wz=(cfg.wz_lo, cfg.wz_hi), bh=(cfg.bh_lo, cfg.bh_hi), rx=(cfg.rx_lo, cfg.rx_hi),
+                  ry=(cfg.ry_lo, cfg.ry_hi))
+    lo = [model.dof_range[16 + j][0] for j in range(10)]; hi = [model.dof_range[16 + j][1] for j in range(10)]
+    STREAM = 4                                                   # KBJ_RNG_COMMAND (include/kbj_model.h)
+
+    def call_key(env, a_, b_):
+        return O.threefry((seed ^ (STREAM * 0x9E3779B9)) & 0xFFFFFFFF, env, a_, b_)
+    cmd = o.es[:, L.ES["CMD"]:L.ES["CMD"] + 16].copy()
+    for e in range(N):
+        want = JR.unified_command(call_key(e, 0, 32), ranges, lo, hi)
+        assert np.array_equal(want.view(np.uint32) & 0x7FFFFFFF, cmd[e].view(np.uint32) & 0x7FFFFFFF), (e, want, cmd[e])   # (-0.0 == 0.0: arms * mask)
+    act = np.tile(np.array(model.joint_bias, np.float32), (N, 1))
+    switched = 0
+    for t in range(6):
+        prev = o.es[:, L.ES["CMD"]:L.ES["CMD"] + 16].copy()
+        step0 = o.es[:, L.ES["STEP"]].view(np.uint32).copy()
+        aux = x.copy()
+        a, c, x = o.step(act, aux)
+        now = o.es[:, L.ES["CMD"]:L.ES["CMD"] + 16]
+        for e in range(N):
+            if aux[e, A["DONE"]] != 0:
+                continue                                             # a reset draws initial_command afresh (checked above)
+            want = JR.unified_command_call(call_key(e, int(step0[e]) + 1, 0), prev[e], cfg.switch_prob, ranges, lo, hi)
+            assert np.array_equal(want.view(np.uint32) & 0x7FFFFFFF, now[e].view(np.uint32) & 0x7FFFFFFF), (t, e)
+            switched += int(not np.array_equal(prev[e], now[e]))
+    assert switched > 20                                             # the switch branch was exercised (p = 0.25 over 6 x 64 draws)
+    # PlaneXYPositionReset (train.py:834-836): keyx, keyy = split(rng); uniform(key, (1,), -r, r)
+    o2 = O.Oracle(model, cfg, seed=seed, precision="f32"); o2.reset_all()
+    for e in range(8):
+        kx, ky = JR.split(O.threefry((seed ^ (1 * 0x9E3779B9)) & 0xFFFFFFFF, e, 1, 43), 2)          # KBJ_RNG_RESET = 1, episode 1, slot 43
+        assert o2.es[e, 0] == JR.uniform(kx, 1, -cfg.reset_xy_range, cfg.reset_xy_range)[0] and o2.es[e, 1] == JR.uniform(ky, 1, -cfg.reset_xy_range, cfg.reset_xy_range)[0]

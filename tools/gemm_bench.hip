@@ -223,6 +223,45 @@ template <bool A_KC, bool B_KC> void compare_x3(const char* name, int M, int N, 
   row("exact fp32 MFMA (kbj_gemm.h)", ex); row("bf16 x3, 6 products (product kernel)", x6); row("bf16 x3 split, 9 products", x9);
 }
 
+
+// ---- mode 11: the update's TAIL - the four paired weight-gradient launches of a minibatch, together on four streams as kbj_ppo_grad queues them -------
+// (critic layer 0: dG0^T [Hm | obs476], actor layer 0: dG0^T [Hm | obs68], critic / actor layer 1: dG1^T [Hm | X]; R = 51200 samples, H = 256.)
+// Prints the time of the four together and their joint rate for a tile configuration <MT, NT, WM, WN> and a split-K workgroup target.
+struct TailProblem { const float* dG; const float* Hm; const float* X; int nx, ldx; float* dW; float* Z; };
+template <int MT, int NT, int WM, int WN>
+double tail4(const char* name, const TailProblem (&pr)[4], hipStream_t (&st)[4], int wg_target, int reps, bool report = true) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  const int R = 51200, H = 256, M = 4 * H;
+  GemmArgs g[4]; int wgs[4]; double flops = 0;
+  for (int p = 0; p < 4; ++p) {
+    const int N = H + pr[p].nx;
+    const int tiles = ((M + BM - 1) / BM) * (H / BN + (pr[p].nx + BN - 1) / BN);
+    int sk = std::max(2, std::min(256, wg_target / std::max(1, tiles)));
+    sk = std::max(2, std::min(sk, (R + 255) / 256));
+    g[p] = GemmArgs{pr[p].dG, pr[p].Hm, pr[p].dW, nullptr, M, N, R, M, H, H, 1, sk, nullptr};
+    g[p].B2 = pr[p].X; g[p].C2 = pr[p].Z; g[p].n1 = H; g[p].ldb2 = pr[p].ldx; g[p].ldc2 = pr[p].ldx;
+    wgs[p] = (tiles * sk + 7) / 8 * 8;
+    flops += 2.0 * M * N * R;
+  }
+  auto go = [&]() { for (int p = 0; p < 4; ++p) gemm_launch_tile<MT, NT, false, false, WM, WN>(st[p], g[p], wgs[p]); };
+  static_assert(256 % BN == 0, "the column split (n1 = H = 256) must fall on a tile boundary");
+  go();
+  CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1[4]; CK(hipEventCreate(&e0));
+  for (int p = 0; p < 4; ++p) CK(hipEventCreate(&e1[p]));
+  CK(hipEventRecord(e0, st[0]));
+  for (int p = 1; p < 4; ++p) CK(hipStreamWaitEvent(st[p], e0, 0));
+  for (int r = 0; r < reps; ++r) go();
+  for (int p = 0; p < 4; ++p) CK(hipEventRecord(e1[p], st[p]));
+  CK(hipDeviceSynchronize());
+  float ms = 0;
+  for (int p = 0; p < 4; ++p) { float m; CK(hipEventElapsedTime(&m, e0, e1[p])); ms = std::max(ms, m); }
+  const double us = ms * 1e3 / reps;
+  if (report) printf("tail4 %-34s tile %3d x %3d, %d waves, target %4d wgs (sk %d/%d/%d/%d, %d wgs)  %8.1f us  %6.1f TF together\n", name, BM, BN, WM * WN, wg_target,
+                     g[0].splitk, g[1].splitk, g[2].splitk, g[3].splitk, wgs[0] + wgs[1] + wgs[2] + wgs[3], us, flops / (us * 1e-6) / 1e12);
+  return us;
+}
+
 int main(int argc, char** argv) {
   const int only = argc > 1 ? atoi(argv[1]) : 0;   // 1..4: that shape alone, without the checks (for counter passes)
   size_t big = (size_t)51200 * 1024;
@@ -289,6 +328,28 @@ int main(int argc, char** argv) {
     }
     printf(bad ? "X3 RANGE TEST FAILED (%d)\n" : "X3 RANGE TEST PASSED\n", bad);
     return bad ? 1 : 0;
+  }
+  if (only == 11) {   // the update's tail: four paired weight-gradient launches together, by tile configuration and split-K target
+    const size_t R = 51200, H = 256;
+    auto dalloc = [&](size_t n) { float* p; CK(hipMalloc(&p, n * 4)); CK(hipMemcpy(p, h.data(), std::min(n, big) * 4, hipMemcpyHostToDevice)); return p; };
+    TailProblem pr[4];
+    const int nx[4] = {475, 65, 256, 256}, ldx[4] = {476, 68, 256, 256};
+    for (int p = 0; p < 4; ++p) {
+      pr[p].dG = dalloc(R * 4 * H); pr[p].Hm = dalloc(R * H); pr[p].X = dalloc(R * ldx[p]); pr[p].nx = nx[p]; pr[p].ldx = ldx[p];
+      float *w, *z; CK(hipMalloc(&w, 4 * H * H * 4)); CK(hipMalloc(&z, 4 * H * 512 * 4)); CK(hipMemset(w, 0, 4 * H * H * 4)); CK(hipMemset(z, 0, 4 * H * 512 * 4));
+      pr[p].dW = w; pr[p].Z = z;
+    }
+    hipStream_t st[4];
+    for (int p = 0; p < 4; ++p) CK(hipStreamCreateWithFlags(&st[p], hipStreamNonBlocking));
+    const int reps = 5;
+    for (int pass = 0; pass < 2; ++pass) {
+      for (int tgt : {512, 768, 1024}) tail4<2, 1, 2, 4>("128x128 on 8 waves (product)", pr, st, tgt, reps);
+      for (int tgt : {512, 768, 1024}) tail4<2, 2, 2, 2>("128x128 on 4 waves (64x64 each)", pr, st, tgt, reps);
+      for (int tgt : {256, 384, 512, 768}) tail4<2, 2, 4, 2>("256x128 on 8 waves (64x64 each)", pr, st, tgt, reps);
+      for (int tgt : {256, 384, 512, 768}) tail4<2, 2, 2, 4>("128x256 on 8 waves (64x64 each)", pr, st, tgt, reps);
+      for (int tgt : {256, 384, 512, 768}) tail4<4, 1, 2, 4>("256x128 on 8 waves (128x32 each)", pr, st, tgt, reps);
+    }
+    return 0;
   }
   if (only == 7) {   // tile-count quantisation of the 128 x 128 kernel on the input-gradient shape: 512 slots (2 workgroups per CU)
     // (M <= 51200: the operand buffers hold 51200 x 1024 floats)
