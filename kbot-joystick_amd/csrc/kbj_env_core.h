@@ -329,7 +329,11 @@ struct JaxKey { uint32_t k0, k1; };
 #ifdef KBJ_EMU
 KBJ_DEV float mul_add_2r(float a, float b, float c) { volatile float p = a * b; return p + c; }
 #else
-KBJ_DEV float mul_add_2r(float a, float b, float c) { return __fadd_rn(__fmul_rn(a, b), c); }   // never contracted into one fma
+KBJ_DEV float mul_add_2r(float a, float b, float c) {   // never contracted into one fma (HIP's __fmul_rn / __fadd_rn are plain operators: they would be)
+#pragma clang fp contract(off)
+  const float p = a * b;
+  return p + c;
+}
 #endif
 KBJ_DEV JaxKey jax_split(const JaxKey& k, uint32_t i) { JaxKey o; threefry2x32(k.k0, k.k1, 0u, i, o.k0, o.k1); return o; }
 KBJ_DEV uint32_t jax_bits(const JaxKey& k, uint32_t i) { uint32_t a, b; threefry2x32(k.k0, k.k1, 0u, i, a, b); return a ^ b; }

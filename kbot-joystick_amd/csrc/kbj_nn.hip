@@ -42,6 +42,10 @@ struct Sched {
   bool deterministic = false;      // fixed-order reductions instead of fp32 / fp64 atomics (bit-reproducible update)
   bool bwd16 = true;               // KBJ_BWD16=0: backward recurrences on the 32-row x 32-unit form of rounds 1-4 (lstm_seq_bwd_kernel) instead of 16-row x 64-unit
                                    // tiles with the partner-major contraction (kbj_lstm_bwd16.h: 620 instead of 907 us per launch in situ)
+  bool critic_on_caller = true;    // KBJ_CRITIC_LANE=2nd: the critic's chain on the context's SECOND stream (rounds 1-5). Default (round 6): the critic - the longer
+                                   // chain, the one a minibatch waits for - runs on the caller's stream, so that nothing between the optimizer step and the
+                                   // critic's first kernel, nor between its last kernel and the next optimizer step, crosses a queue (a cross-queue event wait
+                                   // costs 10-25 us on this runtime); the actor's chain, which has ~0.3 ms of slack, takes the second stream and the hops
   bool gemm_x3 = false;            // kbj_config.gemm_bf16x3 / KBJ_GEMM_X3=1: the GEMM launches that are eligible (the update's input gradients, weight-gradient
                                    // pairs and critic input projection, the rollout's [x | h] gate GEMMs) on the bf16 matrix cores through the exact three-way
                                    // operand split (kbj_gemm.h gemm_x3_kernel); not the default, not the headline
@@ -95,6 +99,8 @@ struct NnWs {
   const double* ext_adv_sums = nullptr;   // kbj_set_advantage_sums: (sum adv, sum adv^2, count) on the device, used instead of the minibatch's own statistics
   unsigned* seq_counters = nullptr;  // per row-group arrival counters of the persistent LSTM kernels
   unsigned* seq_err = nullptr;       // spin-timeout flag
+  bool counters_clean = false;       // the hand-off counters were cleared at the tail of the last kbj_ppo_grad (per lane, behind its last recurrence): the next call skips its own clear
+  bool sumsq_clean = false;          // stats[10] (the gradient's sum of squares) has been zeroed by kbj_ppo_grad's own clear and not used since: kbj_adamw_step skips its memset
   int seq_grid = 0, seq_slots = 0;   // workgroups of one recurrence launch / resident workgroups of the worst-fitting recurrence kernel (kbj_recurrence_residency)
   long long* seq_stamps = nullptr;   // diagnostics (KBJ_SEQ_STAMPS=1): per-step clock stamps of one workgroup
   long long* seq_bstamps = nullptr;  // same for a backward recurrence (KBJ_SEQ_BSTAMPS = 1 + net + 2 * layer)
@@ -554,6 +560,7 @@ int kbj_nn_create(kbj_ctx* ctx) {
     sc.fused_critic_head = env_flag("KBJ_FUSED_CRITIC_HEAD", true); sc.rollout_step = env_flag("KBJ_ROLLOUT_STEP", true);
     sc.one_stream = env_flag("KBJ_ONE_STREAM", false); sc.debug_sync = env_flag("KBJ_DEBUG", false);
     sc.deterministic = c.deterministic != 0 || env_flag("KBJ_DETERMINISTIC", false);
+    { const char* cl = getenv("KBJ_CRITIC_LANE"); sc.critic_on_caller = !(cl && std::string(cl) == "2nd"); }
     sc.bwd16 = env_flag("KBJ_BWD16", true) && H <= (size_t)SEQ_FUSED_MAX_H;   // wide layers keep lstm_seq_bwd_wide_kernel
     sc.gemm_x3 = (c.gemm_bf16x3 != 0 || env_flag("KBJ_GEMM_X3", false)) && !sc.deterministic;   // (the deterministic split-K slabs stay on the exact kernel)
     if (H > (size_t)SEQ_FUSED_MAX_H) sc.fuse_ih = sc.fuse_obs = sc.rollout_step = false;   // wide layers (SEQ_FUSED_MAX_H above)
@@ -1007,10 +1014,14 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
   NnWs& w = *ws_of(ctx);
   const Sched& sc = w.sched;
   const int T = tr->T, N = tr->N, H = w.H, B = w.B, R = T * B, D = w.D;
-  hipStream_t s = ctx->stream;
-  ns[0] = ctx->stream; ns[1] = sc.one_stream ? ctx->stream : ctx->stream2;
+  // lanes: ns[0] = actor-type nets, ns[1] = critic-type nets; one of them is the caller's stream (Sched::critic_on_caller), the other the context's second
+  ns[0] = (sc.one_stream || !sc.critic_on_caller) ? ctx->stream : ctx->stream2;
+  ns[1] = (sc.one_stream || sc.critic_on_caller) ? ctx->stream : ctx->stream2;
+  hipStream_t s = ns[0];   // "s" below = the actor's lane
   // hand-off counters of all eight (sixteen with the mirror branches) recurrence launches of this call: one clear, ahead of both lanes
-  KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, SEQ_COUNTER_TOTAL * sizeof(unsigned), s));
+  // (kbj_ppo_grad leaves them cleared: each lane clears its nets' blocks behind its last recurrence, off the head of the next minibatch's chain)
+  if (!w.counters_clean) KBJ_HIP(ctx, hipMemsetAsync(w.seq_counters, 0, SEQ_COUNTER_TOTAL * sizeof(unsigned), ctx->stream));
+  w.counters_clean = false;
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_fork, 0));
   // (first on the actor's lane, ahead of the gathers: the two small launches depend on the parameters only, and behind the gathers they
@@ -1058,6 +1069,10 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     hipLaunchKernelGGL(gather_small_kernel, g1((size_t)R * (KBJ_NU + 4)), dim3(256), 0, sm, gs, idx, T, N, B, 0, KBJ_NU + 4);
     if (grad) {
       KBJ_HIP(ctx, hipMemsetAsync(w.stats, 0, 16 * sizeof(double), sm));
+#ifndef KBJ_NO_TAIL_CLEAN
+      w.sumsq_clean = true;
+#endif
+      // (ordered in front of the end of this call on every lane: both net lanes wait for ev_small, the caller's stream joins them)
       if (w.ext_adv_sums) {   // global-batch statistics from the caller (all-reduced over the data-parallel ranks)
         KBJ_HIP(ctx, hipMemcpyAsync(w.stats, w.ext_adv_sums, 2 * sizeof(double), hipMemcpyDeviceToDevice, sm));
         KBJ_HIP(ctx, hipMemcpyAsync(w.stats + 11, w.ext_adv_sums + 2, sizeof(double), hipMemcpyDeviceToDevice, sm));
@@ -1072,9 +1087,9 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     }
     if (!sc.one_stream) KBJ_HIP(ctx, hipEventRecord(ctx->ev_small, sm));
   }
-  // the critic's lane needs keep / carries (gathered above on the caller's stream) before its first recurrence - not before its input
+  // the critic's lane needs keep / carries (gathered above on the actor's lane) before its first recurrence - not before its input
   // projection, which only reads its own gather: the wait sits in front of the recurrences below
-  KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream));
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ns[0]));
   if (w.mirror)   // mirrored observation rows: actor's on the caller's stream, critic's behind its gather
     for (int k = 0; k < 2; ++k)
       hipLaunchKernelGGL(mirror_rows_kernel, g1((size_t)R * w.net[k].ld_obs), dim3(256), 0, ns[k], w.tb[k].obs, w.tb[2 + k].obs, (size_t)R, w.net[k].ld_obs, w.mtab[k]);
@@ -1111,7 +1126,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
     }
     linear_fwd(ns[n & 1], w.tb[n].obs, o.ld_obs, w.WinP[n & 1], o.ld_obs, params_d + o.b_in, w.tb[n].X0, H, R, H, o.ld_obs, 0);
   }
-  if (!sc.one_stream) KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream2, ctx->ev_join, 0));   // keep / carries gathered on the caller's stream
+  if (!sc.one_stream) KBJ_HIP(ctx, hipStreamWaitEvent(ns[1], ctx->ev_join, 0));   // keep / carries gathered on the actor's lane
   for (int l = 0; l < D; ++l) {
     for (int n = 0; n < w.nnets; ++n) {
       const NetOff& o = w.net[n & 1];
@@ -1156,7 +1171,7 @@ int kbj_ppo_forward(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, con
   const int T = tr->T, H = w.H, R = T * B, D = w.D;
   hipStream_t ns[2];
   if (ppo_forward_nets(ctx, params_d, tr, env_idx_d, nullptr, nullptr, nullptr, false, ns)) return -1;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = ns[0];   // the actor's lane
   for (int n = 0; n < 2; ++n) {
     const NetOff& o = w.net[n];
     linear_fwd(ns[n], w.tb[n].Hout[D - 1], H, params_d + o.w_out, H, params_d + o.b_out, w.tb[n].Out, 40, R, o.nout, H, 0);
@@ -1172,7 +1187,7 @@ int kbj_ppo_forward(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, con
     KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
     KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   }
-  hipLaunchKernelGGL(poison_vars_kernel, dim3(1), dim3(1), 0, s, w.seq_err, out->logp_d, out->value_d);   // a recurrence timed out: no silent garbage
+  hipLaunchKernelGGL(poison_vars_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, out->logp_d, out->value_d);   // a recurrence timed out: no silent garbage
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_forward");
   if (w.sched.debug_sync) return kbj_synchronize(ctx);
   return 0;
@@ -1206,6 +1221,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   hipStream_t ns[2];
   struct X3Scope { X3Scope(int v) { g_gemm_x3 = v; } ~X3Scope() { g_gemm_x3 = 0; } } x3scope(sc.gemm_x3 ? 1 : 0);   // backward-pass GEMMs only
   if (ppo_forward_nets(ctx, params_d, tr, env_idx_d, adv_d, target_d, grad_d, true, ns)) return -1;
+  s = ns[0];   // from here on "s" = the actor's lane (the caller's stream or the context's second one, Sched::critic_on_caller)
   static const int bstamp_sel = getenv("KBJ_SEQ_BSTAMPS") ? atoi(getenv("KBJ_SEQ_BSTAMPS")) : 0;   // diagnostics build only
   // Without the mirror branches the critic's one-output head, the value half of the loss and the head's backward are ONE kernel on the
   // critic's lane (critic_head_kernel: ~30 us instead of two degenerate GEMMs and three small kernels, ~220 us, on the longer chain).
@@ -1385,6 +1401,13 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     // what was pending when this pass began has been issued; what this pass pushed stays for the next
     pending_dw.erase(std::remove_if(pending_dw.begin(), pending_dw.end(), [&](const PendingDW& p) { return p.l > l; }), pending_dw.end());
   }
+  // every recurrence of this call has been launched: each lane clears the counter blocks of ITS nets behind them (stream order), so the next
+  // kbj_ppo_grad / kbj_ppo_forward starts without a clear on its chain
+  for (int k = 0; k < (one_stream ? 1 : 2); ++k)
+    hipLaunchKernelGGL(seq_counters_clear_kernel, dim3(2 * MAXD * 4), dim3(SEQ_COUNTER_WORDS), 0, ns[k], w.seq_counters, one_stream ? -1 : k);
+#ifndef KBJ_NO_TAIL_CLEAN   // A/B
+  w.counters_clean = true;
+#endif
   for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
     TrainBufs& t = w.tb[n];
@@ -1398,10 +1421,12 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // The actor's slice grad[0, nactor) is final here, ~0.5 ms before the critic's (shorter chain: folded layer 0, no 475-wide projection).
   // A data-parallel host may start its all-reduce now, under the critic's tail (kbj_stream_wait_actor_grad). A hand-off timeout seen so far
   // poisons the actor slice; the check behind the join below covers everything later through the critic's slice.
-  if (fold_actor && !bias_done[0]) fold_bias_terms(0, ctx->stream);
-  hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d);
-  KBJ_HIP(ctx, hipEventRecord(ctx->ev_actor_grad, ctx->stream));
+  if (fold_actor && !bias_done[0]) fold_bias_terms(0, ns[0]);
+  hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ns[0], w.seq_err, grad_d);
+  KBJ_HIP(ctx, hipEventRecord(ctx->ev_actor_grad, ns[0]));
   if (fold_actor && fold_critic && !bias_done[1]) fold_bias_terms(1, ns[1]);   // on the critic's own lane (its side lane has joined it above), beside the actor's
+  // join: the lane that is NOT the caller's stream into the caller's stream. With the critic on the caller's stream (default) the wait is for an
+  // event that was recorded long ago - the actor's lane finishes first - so the tail of a minibatch crosses no queue either.
   KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
   KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   // a recurrence that timed out left a truncated gradient: poison it so that every data-parallel rank skips the optimizer step
@@ -1468,7 +1493,10 @@ int kbj_adamw_step(kbj_ctx* ctx, float* params_d, float* m_d, float* v_d, const 
   const kbj_config& c = ctx->cfg_h;
   hipStream_t s = ctx->stream;
   double* sumsq = w.stats + 10;
-  KBJ_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double), s));
+  // one launch less on the chain between the last gradient GEMM and the next minibatch's first kernel: the accumulator is already zero when this
+  // step follows a kbj_ppo_grad (whose clear of the statistics block covers it); any other caller (several steps in a row, per-pass accumulation) clears it here
+  if (!w.sumsq_clean) KBJ_HIP(ctx, hipMemsetAsync(sumsq, 0, sizeof(double), s));
+  w.sumsq_clean = false;
   double* part = w.sched.deterministic ? w.detd : nullptr;
   hipLaunchKernelGGL(sumsq_kernel, dim3(512), dim3(256), 0, s, grad_d, w.unparams, grad_scale, sumsq, part);
   if (part) hipLaunchKernelGGL(reduce_double_kernel, dim3(1), dim3(64), 0, s, part, 512, 1, sumsq);

@@ -572,6 +572,12 @@ struct AdamParams { float lr, b1, b2, eps, wd, max_norm, bc1, bc2, gscale; };
 // hand-off timeout flag of the persistent recurrences (kbj_lstm_seq.h), which also poisons the gradient (poison_grad_kernel) so that
 // after the data-parallel all-reduce EVERY rank skips the step instead of applying a truncated gradient. Both are reported by
 // kbj_synchronize.
+// hand-off counters [phase][net][SEQ_COUNTER_WORDS words]: clear the blocks of the nets of one lane (net & 1 == lane; lane < 0: all)
+__global__ void seq_counters_clear_kernel(unsigned* __restrict__ counters, int lane) {
+  const int net = blockIdx.x & 3;
+  if (lane >= 0 && (net & 1) != lane) return;
+  counters[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = 0u;
+}
 __global__ void poison_grad_kernel(const unsigned* __restrict__ err, float* __restrict__ g) {
   if (err[0]) g[0] = __int_as_float(0x7FC00000);
 }
