@@ -128,7 +128,11 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   {
     int lo = 0, hi = 0;
     KBJ_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    KBJ_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi));
+    // (round 6: by default the critic's chain runs on the CALLER's stream and stream2 carries the actor's - kbj_nn.hip Sched::critic_on_caller;
+    // KBJ_STREAM2_PRIO=normal|high, A/B: which priority the actor's lane should then have)
+    int prio = hi;
+    if (const char* e = getenv("KBJ_STREAM2_PRIO")) prio = std::string(e) == "normal" ? (lo + hi) / 2 : hi;
+    KBJ_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio));
   }
   // The side lanes carry work that hangs off the critical chain of the update (weight-gradient GEMMs, bias sums) and the critic of the
   // rollout: lowest queue priority, so that when a dX GEMM of the chain and a dW GEMM compete for CUs the chain's workgroups go first.
