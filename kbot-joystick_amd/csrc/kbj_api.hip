@@ -122,17 +122,17 @@ int kbj_create(kbj_ctx** out, const void* model_blob, size_t model_bytes, const 
   KBJ_TRY(hipMemset(ctx->rcarry_d, 0, N * KBJ_RC_SIZE * sizeof(float)));
   KBJ_TRY(hipEventCreate(&ctx->ev0));
   KBJ_TRY(hipEventCreate(&ctx->ev1));
-  // stream2 carries the critic-type nets of the update. The critic's chain is the longer one (a 475-wide input projection in front of
-  // layer 0 that the actor folds away; the actor's chain ends ~0.4 ms earlier), and since the two lanes stopped waiting for each other
-  // at the loss it decides the length of a minibatch: its lane gets the highest queue priority (6.66 -> 6.61 ms per minibatch).
+  // stream2 = the SECOND net lane of the update. Rounds 1-5 (KBJ_CRITIC_LANE=2nd): it carries the critic-type nets - the longer chain (a 475-wide
+  // input projection in front of layer 0 that the actor folds away), which decides the length of a minibatch - at the highest queue priority
+  // (6.66 -> 6.61 ms per minibatch then). Round 6 (default): the critic's chain runs on the CALLER's stream (kbj_nn.hip Sched::critic_on_caller: no
+  // queue hop between the optimizer step and the chain's two ends), stream2 carries the actor's chain and gets the normal priority - it has
+  // ~0.3 ms of slack and should not take CUs from the critic where they compete (measured: normal 354.7 / high 355.3 ms, then 350.7 / 350.9).
   {
     int lo = 0, hi = 0;
     KBJ_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    // (round 6: by default the critic's chain runs on the CALLER's stream and stream2 carries the actor's - kbj_nn.hip Sched::critic_on_caller;
-    // KBJ_STREAM2_PRIO=normal|high, A/B: which priority the actor's lane should then have)
-    int prio = hi;
-    if (const char* e = getenv("KBJ_STREAM2_PRIO")) prio = std::string(e) == "normal" ? (lo + hi) / 2 : hi;
-    KBJ_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, prio));
+    const char* cl = getenv("KBJ_CRITIC_LANE");
+    const bool critic_on_stream2 = cl && std::string(cl) == "2nd";
+    KBJ_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, critic_on_stream2 ? hi : (lo + hi) / 2));
   }
   // The side lanes carry work that hangs off the critical chain of the update (weight-gradient GEMMs, bias sums) and the critic of the
   // rollout: lowest queue priority, so that when a dX GEMM of the chain and a dW GEMM compete for CUs the chain's workgroups go first.

@@ -1117,9 +1117,12 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
       g.a_idx = idx; g.a_B = B; g.a_N = N;
       g.x3 = sc.gemm_x3 ? 1 : 0;
       gemm_launch<true, true>(ns[1], g);
-      // the copy behind the projection, under the recurrences (beside it the two would share HBM: 175 instead of 144 us for the GEMM)
-      KBJ_HIP(ctx, hipEventRecord(ctx->ev_obs, ns[1]));
-      KBJ_HIP(ctx, hipStreamWaitEvent(ctx->side[1], ctx->ev_obs, 0));
+      // the copy under the recurrences, on the critic's side lane. It starts behind the ACTOR lane's head (ev_join: the folded-weight preparation
+      // and, without a prefetch hint, the head gathers - about when the projection ends; beside it the two would share HBM: 175 instead of 144 us
+      // for the GEMM) and behind the side-lane gathers (ev_small), so that ev_obs implies both and the critic's lane - the chain a minibatch
+      // waits for - carries ONE event wait in front of its loss instead of a record and two waits (each costs the queue ~7 us, round 6)
+      KBJ_HIP(ctx, hipStreamWaitEvent(ctx->side[1], ctx->ev_join, 0));
+      KBJ_HIP(ctx, hipStreamWaitEvent(ctx->side[1], ctx->ev_small, 0));
       if (grad) gather(ctx->side[1], tr->critic_obs_d, w.net[1].ld_obs, w.net[1].ld_obs, w.tb[1].obs, w.net[1].ld_obs);   // the forward-only pass never reads the copy
       KBJ_HIP(ctx, hipEventRecord(ctx->ev_obs, ctx->side[1]));
       continue;
@@ -1146,8 +1149,11 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
       if (seq_fwd(ctx, ns[n & 1], H, fa)) return -1;
     }
   }
-  if (!sc.one_stream) for (int k = 0; k < 2; ++k) KBJ_HIP(ctx, hipStreamWaitEvent(ns[k], ctx->ev_small, 0));   // the side-lane gathers / clears above
-  if (gather_late) KBJ_HIP(ctx, hipStreamWaitEvent(ns[1], ctx->ev_obs, 0));   // the critic's gathered rows (its backward pass reads them on this lane or its side lane)
+  if (!sc.one_stream) {
+    KBJ_HIP(ctx, hipStreamWaitEvent(ns[0], ctx->ev_small, 0));   // the side-lane gathers / clears above
+    // the critic's lane: its gathered rows (read by its backward pass) - an event that implies ev_small (above) - or ev_small itself
+    KBJ_HIP(ctx, hipStreamWaitEvent(ns[1], gather_late ? ctx->ev_obs : ctx->ev_small, 0));
+  }
   return 0;
 }
 
@@ -1270,8 +1276,10 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
                        w.dvalue, w.dvalue_m, w.stats + 2, one_stream ? 3 : 2);
   }
   // the metrics line is nobody's input: a side lane computes it once both halves of the loss are in (it joins the caller's stream at the end)
+  // (the critic lane's record doubles as the fork of its side lane below when nothing is launched on it in between - the fused head: one packet)
+  const bool critic_fork_recorded = !one_stream && fused_critic_head;
   if (!one_stream) {
-    hipEvent_t ea = ctx->ev_pool[ctx->ev_next++ & 31], eb = ctx->ev_pool[ctx->ev_next++ & 31];
+    hipEvent_t ea = ctx->ev_pool[ctx->ev_next++ & 31], eb = critic_fork_recorded ? ctx->ev_side[1] : ctx->ev_pool[ctx->ev_next++ & 31];
     hipEventRecord(ea, ns[0]); hipEventRecord(eb, ns[1]);
     hipStreamWaitEvent(ctx->side[0], ea, 0); hipStreamWaitEvent(ctx->side[0], eb, 0);
   }
@@ -1295,7 +1303,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     const NetOff& o = w.net[n & 1];
     TrainBufs& t = w.tb[n];
     if (!(n == 1 && fused_critic_head)) linear_bwd_input(ns[n & 1], t.dOut, 40, params_d + o.w_out, H, t.dHa, H, R, H, o.nout, 0);
-    fork_side(n);
+    if (n == 1 && critic_fork_recorded) hipStreamWaitEvent(ctx->side[1], ctx->ev_side[1], 0);   // recorded with the metrics fork above
+    else fork_side(n);
     linear_bwd_weight(ctx, side_of(n), t.dOut, 40, t.Hout[D - 1], H, grad_d + o.w_out, H, o.nout, H, R);
     colsum_acc(ctx, side_of(n), t.dOut, R, o.nout, 40, grad_d + o.b_out);
     dh_above[n] = t.dHa; dx_out[n] = t.dHb;
@@ -1401,13 +1410,6 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     // what was pending when this pass began has been issued; what this pass pushed stays for the next
     pending_dw.erase(std::remove_if(pending_dw.begin(), pending_dw.end(), [&](const PendingDW& p) { return p.l > l; }), pending_dw.end());
   }
-  // every recurrence of this call has been launched: each lane clears the counter blocks of ITS nets behind them (stream order), so the next
-  // kbj_ppo_grad / kbj_ppo_forward starts without a clear on its chain
-  for (int k = 0; k < (one_stream ? 1 : 2); ++k)
-    hipLaunchKernelGGL(seq_counters_clear_kernel, dim3(2 * MAXD * 4), dim3(SEQ_COUNTER_WORDS), 0, ns[k], w.seq_counters, one_stream ? -1 : k);
-#ifndef KBJ_NO_TAIL_CLEAN   // A/B
-  w.counters_clean = true;
-#endif
   for (int n = 0; n < w.nnets; ++n) {
     const NetOff& o = w.net[n & 1];
     TrainBufs& t = w.tb[n];
@@ -1416,21 +1418,38 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       linear_bwd_weight(ctx, s, dh_above[n], H, t.obs, o.ld_obs, grad_d + o.w_in, o.nin, H, o.nin, R);
       colsum_acc(ctx, s, dh_above[n], R, H, H, grad_d + o.b_in);
     }
-    if (!one_stream) { hipEventRecord(ctx->ev_side[n & 1], ctx->side[n & 1]); hipStreamWaitEvent(s, ctx->ev_side[n & 1], 0); }
+    if (!one_stream) {
+      // join of the net's side lane (output-projection gradients, bias sums). The critic's side lane joins the ACTOR's lane when nothing on the
+      // critic's own lane reads what it wrote any more (bias terms done): the actor's lane is joined into the caller's stream below, so the
+      // critic's chain - on the caller's stream by default - ends with ONE event wait, for an event that fired long before
+      hipStream_t joiner = ((n & 1) == 1 && sc.critic_on_caller && bias_done[1]) ? ns[0] : s;
+      hipEventRecord(ctx->ev_side[n & 1], ctx->side[n & 1]); hipStreamWaitEvent(joiner, ctx->ev_side[n & 1], 0);
+    }
   }
-  // The actor's slice grad[0, nactor) is final here, ~0.5 ms before the critic's (shorter chain: folded layer 0, no 475-wide projection).
-  // A data-parallel host may start its all-reduce now, under the critic's tail (kbj_stream_wait_actor_grad). A hand-off timeout seen so far
-  // poisons the actor slice; the check behind the join below covers everything later through the critic's slice.
+  // Each lane ends with ONE small kernel behind its last gradient GEMM: it clears the hand-off counter blocks of the lane's nets (every recurrence
+  // of the call has run: the next kbj_ppo_grad / kbj_ppo_forward starts without a clear on its chain) and poisons the lane's slice of the gradient
+  // when a recurrence timed out (a truncated gradient: every data-parallel rank must skip the optimizer step; one NaN marker per slice is
+  // enough, the norm covers the whole vector).
+  // The actor's slice grad[0, nactor) is final here, ~0.4 ms before the critic's (shorter chain: folded layer 0, no 475-wide projection).
+  // A data-parallel host may start its all-reduce now, under the critic's tail (kbj_stream_wait_actor_grad).
   if (fold_actor && !bias_done[0]) fold_bias_terms(0, ns[0]);
-  hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ns[0], w.seq_err, grad_d);
-  KBJ_HIP(ctx, hipEventRecord(ctx->ev_actor_grad, ns[0]));
-  if (fold_actor && fold_critic && !bias_done[1]) fold_bias_terms(1, ns[1]);   // on the critic's own lane (its side lane has joined it above), beside the actor's
-  // join: the lane that is NOT the caller's stream into the caller's stream. With the critic on the caller's stream (default) the wait is for an
-  // event that was recorded long ago - the actor's lane finishes first - so the tail of a minibatch crosses no queue either.
-  KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
-  KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-  // a recurrence that timed out left a truncated gradient: poison it so that every data-parallel rank skips the optimizer step
-  hipLaunchKernelGGL(poison_grad_kernel, dim3(1), dim3(1), 0, ctx->stream, w.seq_err, grad_d + w.nactor);
+  if (one_stream) {
+    if (fold_actor && fold_critic && !bias_done[1]) fold_bias_terms(1, ns[1]);
+    hipLaunchKernelGGL(lane_tail_kernel, dim3(2 * MAXD * 4), dim3(SEQ_COUNTER_WORDS), 0, ctx->stream, w.seq_counters, -1, w.seq_err, grad_d, grad_d + w.nactor);
+    KBJ_HIP(ctx, hipEventRecord(ctx->ev_actor_grad, ctx->stream));
+  } else {
+    hipLaunchKernelGGL(lane_tail_kernel, dim3(2 * MAXD * 4), dim3(SEQ_COUNTER_WORDS), 0, ns[0], w.seq_counters, 0, w.seq_err, grad_d, (float*)nullptr);
+    KBJ_HIP(ctx, hipEventRecord(ctx->ev_actor_grad, ns[0]));
+    if (fold_actor && fold_critic && !bias_done[1]) fold_bias_terms(1, ns[1]);   // on the critic's own lane (its side lane has joined it above), beside the actor's
+    hipLaunchKernelGGL(lane_tail_kernel, dim3(2 * MAXD * 4), dim3(SEQ_COUNTER_WORDS), 0, ns[1], w.seq_counters, 1, w.seq_err, grad_d + w.nactor, (float*)nullptr);
+    // join: the lane that is NOT the caller's stream into the caller's stream. With the critic on the caller's stream (default) the wait is for an
+    // event that was recorded long ago - the actor's lane finishes first - so the tail of a minibatch crosses no queue either.
+    KBJ_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->stream2));
+    KBJ_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  }
+#ifndef KBJ_NO_TAIL_CLEAN   // A/B
+  w.counters_clean = true;
+#endif
   KBJ_CHECK_LAUNCH(ctx, "kbj_ppo_grad");
   if (sc.debug_sync) return kbj_synchronize(ctx);   // KBJ_DEBUG=1: surface a hand-off timeout at the call that caused it
   return 0;

@@ -569,17 +569,16 @@ __global__ void sumsq_kernel(const float* __restrict__ g, size_t n, float scale,
 }
 struct AdamParams { float lr, b1, b2, eps, wd, max_norm, bc1, bc2, gscale; };
 // Fail-stop: a gradient whose global norm is not finite leaves parameters and moments untouched and raises err[1]; err[0] is the
-// hand-off timeout flag of the persistent recurrences (kbj_lstm_seq.h), which also poisons the gradient (poison_grad_kernel) so that
+// hand-off timeout flag of the persistent recurrences (kbj_lstm_seq.h), which also poisons the gradient (lane_tail_kernel) so that
 // after the data-parallel all-reduce EVERY rank skips the step instead of applying a truncated gradient. Both are reported by
 // kbj_synchronize.
-// hand-off counters [phase][net][SEQ_COUNTER_WORDS words]: clear the blocks of the nets of one lane (net & 1 == lane; lane < 0: all)
-__global__ void seq_counters_clear_kernel(unsigned* __restrict__ counters, int lane) {
+// The last kernel of a lane of kbj_ppo_grad: clear the hand-off counter blocks [phase][net][words] of the lane's nets (net & 1 == lane; lane < 0:
+// all) and, when a recurrence timed out (err[0]), poison the lane's slice(s) of the gradient with a NaN marker (fail-stop, see adamw_kernel)
+__global__ void lane_tail_kernel(unsigned* __restrict__ counters, int lane, const unsigned* __restrict__ err, float* __restrict__ g0, float* __restrict__ g1) {
   const int net = blockIdx.x & 3;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && err[0]) { g0[0] = __int_as_float(0x7FC00000); if (g1) g1[0] = __int_as_float(0x7FC00000); }
   if (lane >= 0 && (net & 1) != lane) return;
   counters[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = 0u;
-}
-__global__ void poison_grad_kernel(const unsigned* __restrict__ err, float* __restrict__ g) {
-  if (err[0]) g[0] = __int_as_float(0x7FC00000);
 }
 __global__ void poison_vars_kernel(const unsigned* __restrict__ err, float* __restrict__ logp, float* __restrict__ value) {
   if (err[0]) { logp[0] = __int_as_float(0x7FC00000); value[0] = __int_as_float(0x7FC00000); }

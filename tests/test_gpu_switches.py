@@ -24,6 +24,7 @@ SWITCHES = {
     "KBJ_ROLLOUT_STEP=0": {"KBJ_ROLLOUT_STEP": "0"},
     "KBJ_DETERMINISTIC=1": {"KBJ_DETERMINISTIC": "1"},
     "KBJ_DEBUG=1": {"KBJ_DEBUG": "1"},
+    "KBJ_CRITIC_LANE=2nd": {"KBJ_CRITIC_LANE": "2nd"},   # rounds 1-5 lane assignment: critic chain on the context's second stream, actor on the caller's
     "KBJ_BWD16=0": {"KBJ_BWD16": "0"},           # backward recurrences on the 32 x 32-tile form everywhere (round 4's kernel)
     "KBJ_BWD16=0+DET": {"KBJ_BWD16": "0", "KBJ_DETERMINISTIC": "1"},
     "KBJ_GEMM_X3=1": {"KBJ_GEMM_X3": "1"},       # = kbj_config.gemm_bf16x3: the backward pass's large GEMMs through the exact three-way bf16 split
