@@ -630,7 +630,7 @@ def test_launch_loop_with_validation_and_background_checkpoints(tmp_path):
     import torch
     from kbot_joystick_amd.host.task import HumanoidWalkingTask
     run = str(tmp_path / "run_1")
-    t = HumanoidWalkingTask.launch(_small(render_length_seconds=0.4, valid_every_n_steps=3, save_every_n_seconds=0.01), num_iterations=7, run_dir=run, quiet=True)
+    t = HumanoidWalkingTask.launch(_small(render_length_seconds=0.4, valid_every_n_steps=3, save_every_n_seconds=1e-4), num_iterations=7, run_dir=run, quiet=True)   # (period far below an iteration of this small task - a few milliseconds since round 6 -: a save is due after every iteration)
     st = t.loop_stats
     assert st["iterations"] == 7 and st["validations"] == 2 and st["checkpoints"] >= 5 and st["env_steps_per_s"] > 0
     assert st["loop_seconds"] >= st["validation_seconds"] + st["checkpoint_seconds"]
