@@ -248,6 +248,54 @@ def test_deterministic_gradient_at_the_baseline_minibatch(monkeypatch):
     assert float((grads[1][0] - grads[0][0]).norm() / grads[0][0].norm()) < 1e-5
 
 
+def test_call_sequences_do_not_change_the_gradient(monkeypatch):
+    """Round 6: kbj_ppo_grad leaves the recurrences' hand-off counters cleared for the next call (each lane clears its nets' blocks behind its
+    last recurrence) and kbj_adamw_step skips its accumulator clear when the preceding kbj_ppo_grad already made it. Every other call sequence
+    must fall back to its own clears: in deterministic mode (bit-reproducible) the gradient of the same minibatch is bit-identical whatever ran
+    before it - another kbj_ppo_grad, a kbj_ppo_forward (which uses the forward counters and clears nothing at its tail), two optimizer steps in a
+    row (the second clears its accumulator itself) - and the optimizer step from the same state gives the same parameters."""
+    import torch
+    N, B, T, H = 96, 32, 9, 128
+    m, cfg, ctx = _ctx(monkeypatch, {}, N, B, T, H, deterministic=1)
+    params, tr, idx, _, _ = _problem(torch, m, cfg, ctx, N, B, T, H)
+    idx = idx.cuda()
+    P = ctx.param_count()
+    new = lambda: torch.zeros(P, device="cuda:0")
+    met = torch.zeros(10, device="cuda:0")
+    g = [new() for _ in range(4)]
+    grad = lambda out: ctx.ppo_grad(params, tr.c, idx, B, tr.adv, tr.target, out, met)
+    grad(g[0])                                                            # first call of the context: clears everything itself
+    grad(g[1])                                                            # behind a kbj_ppo_grad: counters cleared by its tail
+    lp, v = torch.zeros(T, B, device="cuda:0"), torch.zeros(T, B, device="cuda:0")
+    ctx.ppo_forward(params, tr.c, idx, B, lp, v)                          # forward-only pass: uses the counters, leaves them dirty
+    grad(g[2])
+    p1, m1, v1 = params.clone(), new(), new()
+    p2, m2, v2 = params.clone(), new(), new()
+    ctx.adamw_step(p1, m1, v1, g[2], 1, 1.0)                              # behind kbj_ppo_grad: no accumulator clear in front of it
+    ctx.adamw_step(p2, m2, v2, g[2], 1, 1.0)                              # a second step in a row: clears its accumulator itself
+    grad(g[3])                                                            # behind optimizer steps
+    ctx.synchronize()
+    assert torch.isfinite(g[0]).all() and float(g[0].abs().max()) > 0
+    assert torch.equal(g[0], g[1]) and torch.equal(g[0], g[2]) and torch.equal(g[0], g[3])
+    assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2) and not torch.equal(p1, params)
+    ctx.close()
+
+
+def test_recurrence_residency_query(monkeypatch):
+    """kbj_recurrence_residency: what a host needs to co-locate contexts on one GPU. At the BASELINE minibatch a recurrence launch is
+    (512 / 32) x (256 / 32) = 128 workgroups (forward 32 x 32 tiles; backward 16 x 64 tiles: the same count), two launches are in flight (one on the
+    one-stream schedule), and the device holds at least one workgroup of the worst-fitting recurrence kernel per CU."""
+    import torch
+    m, cfg, ctx = _ctx(monkeypatch, {}, 512, 512, 10, 256)
+    grid, conc, slots = ctx.recurrence_residency()
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    assert (grid, conc) == (128, 2) and slots >= cus and slots % cus == 0 and conc * grid <= slots
+    ctx.close()
+    m, cfg, ctx = _ctx(monkeypatch, {"KBJ_ONE_STREAM": "1"}, 64, 64, 10, 64)
+    assert ctx.recurrence_residency()[:2] == (4, 1)
+    ctx.close()
+
+
 def test_gemm_bf16x3_gradient_at_the_baseline_minibatch(monkeypatch):
     """kbj_config.gemm_bf16x3 at the BASELINE minibatch (512 envs x 100 steps, H = 256): every large backward GEMM (input gradient
     51200 x 256 x 1024, paired weight gradients 1024 x 512 x 51200 and the folded layer-0 pairs with their ragged second problem) runs
