@@ -43,7 +43,6 @@ __global__ __launch_bounds__(BWD16_NTH) void lstm_seq_bwd16_kernel(SeqBwdArgs a)
   const int ug = lid % NUG, rg = lid / NUG;
   const int r0 = rg * ROWS, u0 = ug * UNITS;
   const int B = a.B, T = a.T;
-  const bool full = r0 + ROWS <= B;
   if (seq_aborted(a.err, &flag)) return;
   // B operands. Chunk j of this workgroup = partner (ug + j) % NUG (own chunk first); k-step s of the wave's half: local k = KHALF kh + KK::kidx(s, g),
   // i.e. gate = local k / 64, unit = local k % 64 of that partner; column = this wave's unit tile.
@@ -65,19 +64,25 @@ __global__ __launch_bounds__(BWD16_NTH) void lstm_seq_bwd16_kernel(SeqBwdArgs a)
   float bsum[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   // everything the cell derivative of a step needs (produced by earlier kernels) is fetched ONE STEP AHEAD
   float actn[2][4], tcn[2], cprevn[2], dhan[2], kpn[2];
+  // NO SELECTS (round 6): a row beyond B or a step before 0 is fetched from a clamped address and its values are never used - rows are independent in
+  // the contraction, every global store and bias sum below is guarded by r < B. A select per fetched value (and per staged chunk piece) was 63 of the
+  // loop's 169 vector instructions per step, and fp32 MFMA shares the issue port with them: -0.55 % per iteration in A/B (profiles/r06q_*). The same
+  // loads as buffer instructions on a scalar per-step offset (67 instructions) LOST that gain again: plain global loads / stores it stays.
+  int rcl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int r = r0 + erow[i]; rcl[i] = r < B ? r : 0; }
   auto fetch_inputs = [&](int tt) {
+    const int tq = tt < 0 ? 0 : tt;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int r = r0 + erow[i];
-      const bool ok = r < B && tt >= 0;
-      const size_t o1 = ((size_t)(ok ? tt : 0) * B + (ok ? r : 0)) * H + u0 + eunit[i];
-      const float* g = a.Gact + ((size_t)(ok ? tt : 0) * B + (ok ? r : 0)) * 4 * H + u0 + eunit[i];
+      const size_t o1 = ((size_t)tq * B + rcl[i]) * H + u0 + eunit[i];
+      const float* g = a.Gact + ((size_t)tq * B + rcl[i]) * 4 * H + u0 + eunit[i];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) actn[i][k] = ok ? g[k * H] : 0.0f;
-      tcn[i] = ok ? a.TanhC[o1] : 0.0f;
-      cprevn[i] = ok ? a.Cm[o1] : 0.0f;
-      dhan[i] = ok ? a.dHabove[o1] : 0.0f;
-      kpn[i] = ok ? a.keep[(size_t)tt * B + r] : 0.0f;
+      for (int k = 0; k < 4; ++k) actn[i][k] = g[k * H];
+      tcn[i] = a.TanhC[o1];
+      cprevn[i] = a.Cm[o1];
+      dhan[i] = a.dHabove[o1];
+      kpn[i] = a.keep[(size_t)tq * B + rcl[i]];
     }
   };
   fetch_inputs(T - 1);
@@ -96,7 +101,7 @@ __global__ __launch_bounds__(BWD16_NTH) void lstm_seq_bwd16_kernel(SeqBwdArgs a)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int q = tid + NTH * i, row = q >> 6, seg = q & 63;
-      *reinterpret_cast<f32x4m*>(buf + row * LDC + UNITS * (seg >> 4) + 4 * (seg & 15)) = (full || r0 + row < B) ? c.v[i] : f32x4m{0, 0, 0, 0};
+      *reinterpret_cast<f32x4m*>(buf + row * LDC + UNITS * (seg >> 4) + 4 * (seg & 15)) = c.v[i];   // (rows beyond B hold a clamped row's values: harmless, see fetch_inputs)
     }
   };
   // acc += A[16 rows][k of blocks jb..je) of this wave's half] * w  (two accumulators: two independent MFMA chains)
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(BWD16_NTH) void lstm_seq_bwd16_kernel(SeqBwdArgs a)
       const float dh = dha[i] + kp[i] * dhm[i];
       const float dc = kp[i] * dcm[i] + dh * og * (1 - tc[i] * tc[i]);
       const float d0 = dc * gg * ig * (1 - ig), d1 = dc * cprev[i] * fg * (1 - fg), d2 = dc * ig * (1 - gg * gg), d3 = dh * tc[i] * og * (1 - og);
-      float* own = cbuf[0] + erow[i] * LDC + eunit[i];      // rows beyond B carry zero inputs, hence zeros
+      float* own = cbuf[0] + erow[i] * LDC + eunit[i];      // (rows beyond B carry a clamped row's values: harmless, rows are independent)
       own[0] = d0; own[UNITS] = d1; own[2 * UNITS] = d2; own[3 * UNITS] = d3;
       if (r < B) {
         float* dg = a.dG + ((size_t)t * B + r) * 4 * H + u0 + eunit[i];

@@ -307,15 +307,24 @@ __global__ __launch_bounds__(256 * UW) void lstm_seq_fwd_kernel(SeqFwdArgs a) {
   // own inputs (input projection pre-activations, keep flags) are fetched ONE STEP AHEAD: their HBM latency hides behind
   // a whole step instead of stalling the cell
   float gxn[2][4], kpn[2];
+  // (no selects: a row beyond B or the step behind the last is fetched from a clamped address and never used - rows are independent, every
+  // store below is guarded by r < B; kbj_lstm_bwd16.h has the measurement)
+  int rcl[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) { const int r = r0 + erow[i]; rcl[i] = r < B ? r : 0; }
   auto fetch_inputs = [&](int tt) {
+    const int tq = tt < T ? tt : T - 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int r = r0 + erow[i];
-      bool ok = r < B && tt < T;
-      const float* g = a.G + ((size_t)(ok ? tt : 0) * B + (ok ? r : 0)) * 4 * H + u0 + eunit[i];
+      if (!FUSE) {
+        const float* g = a.G + ((size_t)tq * B + rcl[i]) * 4 * H + u0 + eunit[i];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) gxn[i][k] = (ok && !FUSE) ? g[k * H] : 0.0f;
-      kpn[i] = ok ? a.keep[(size_t)tt * B + r] : 0.0f;
+        for (int k = 0; k < 4; ++k) gxn[i][k] = g[k * H];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) gxn[i][k] = 0.0f;
+      }
+      kpn[i] = a.keep[(size_t)tq * B + rcl[i]];
     }
   };
   fetch_inputs(0);
