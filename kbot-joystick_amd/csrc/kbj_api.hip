@@ -215,7 +215,7 @@ int kbj_profile_end(kbj_ctx* ctx, float* env_step_ms, int* env_step_launches, fl
       // gemm_x3_kernel<TM, A_KC, B_KC, GEN> as rocprofv3 prints the instantiations the launcher uses (kbj_ctx.h kbj_kind_gemm_x3)
       "kbj::gemm_x3_kernel<2, false, false, false>", "kbj::gemm_x3_kernel<2, false, true, false>", "kbj::gemm_x3_kernel<2, true, false, false>",
       "kbj::gemm_x3_kernel<2, true, true, false>", "kbj::gemm_x3_kernel<2, true, true, true>", "kbj::gemm_x3_kernel<1, true, true, false>",
-      "kbj::gemm_x3_kernel<1, true, true, true>", "kbj::lstm_seq_bwd16_kernel"};
+      "kbj::gemm_x3_kernel<1, true, true, true>", "kbj::lstm_seq_bwd16_kernel", "kbj::gemm_f32_kernel<1, 1, true, true, 2, 4>", "kbj::gemm_f32_kernel<1, 1, true, false, 2, 4>"};
   for (int k = 0; k < KBJ_KIND_COUNT; ++k) {
     kbj_kernel_stat& st = ctx->kstats[k];
     const int uw = 2;   // wavefront pairs per recurrence workgroup (kbj_nn.hip SEQ_UW), as rocprofv3 prints the template argument

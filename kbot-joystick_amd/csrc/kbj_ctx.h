@@ -12,7 +12,8 @@ enum { KBJ_KIND_GEMM = 0 /* +4 small tile, +2 A k-contiguous, +1 B k-contiguous 
        // gemm_x3_kernel<TM, A_KC, B_KC, GEN> (kbj_config.gemm_bf16x3), one kind per instantiation the launcher uses: 15..18 = <2, A_KC, B_KC, false>
        // (+2 A k-contiguous, +1 B k-contiguous), 19 = <2, true, true, true>, 20 = <1, true, true, false>, 21 = <1, true, true, true>
        KBJ_KIND_GEMM_X3 = 15, KBJ_KIND_GEMM_X3_GEN = 19, KBJ_KIND_GEMM_X3_SMALL = 20, KBJ_KIND_GEMM_X3_SMALL_GEN = 21,
-       KBJ_KIND_SEQ_BWD16 = 22 /* lstm_seq_bwd16_kernel<H> */, KBJ_KIND_COUNT = 23 };
+       KBJ_KIND_SEQ_BWD16 = 22 /* lstm_seq_bwd16_kernel<H> */, KBJ_KIND_GEMM_64x128 = 23 /* gemm_f32_kernel<1, 1, true, true, 2, 4>: the critic's input projection; 24 = <1, 1, true, false, 2, 4>: the input gradients */,
+       KBJ_KIND_COUNT = 25 };
 inline int kbj_kind_gemm_x3(int tm, bool a_kc, bool b_kc, bool gen) {
   if (tm == 2) return gen ? KBJ_KIND_GEMM_X3_GEN : KBJ_KIND_GEMM_X3 + (a_kc ? 2 : 0) + (b_kc ? 1 : 0);
   return gen ? KBJ_KIND_GEMM_X3_SMALL_GEN : KBJ_KIND_GEMM_X3_SMALL;

@@ -542,6 +542,18 @@ inline void gemm_launch(hipStream_t s, const GemmArgs& g_in, int force_big = -1)
     } else gemm_x3_launch_tile<2, A_KC, B_KC, false>(s, g, sk);
     return;
   }
+  // force_big == 2 (A k-contiguous, no split-K): 64 x 128 tiles on 8 wavefronts (2 x 4, each 32 x 32; 55 KB of LDS, two workgroups per CU).
+  // For a product with FEW 128 x 128 tiles - the critic's input projection R x 256 x 476 and the input gradients R x 256 x 1024 are 800 tiles on 512
+  // workgroup slots, 1.56 rounds paid as 2 - the 1600 half-height tiles fill 3.1 rounds: 118 instead of 132-146 us and 225 instead of 254 us alone
+  // (tools/gemm_bench 12, profiles/r06t_*), on the chain a minibatch waits for.
+  if constexpr (A_KC) {
+    if (force_big == 2 && sk == 1) {
+      KbjKernelTimer timer(s, KBJ_KIND_GEMM_64x128 + (B_KC ? 0 : 1), 2.0 * g.M * g.N * g.K);
+      const long it = (long)((g.M + 63) / 64) * ((g.N + 127) / 128);
+      gemm_launch_tile<1, 1, true, B_KC, 2, 4>(s, g, (int)((it + 7) / 8 * 8));
+      return;
+    }
+  }
   KbjKernelTimer timer(s, KBJ_KIND_GEMM + (big ? 0 : 4) + (A_KC ? 2 : 0) + (B_KC ? 1 : 0), 2.0 * g.M * g.N * g.K);
 #ifdef KBJ_GEMM_W4   // 128x128 tile on 4 wavefronts (2 x 2, each 64x64, 207 registers): 2-4 % faster only at K >= 4096
   if (big) gemm_launch_tile<2, 2, A_KC, B_KC>(s, g, wgs);

@@ -210,10 +210,10 @@ void linear_fwd(hipStream_t s, const float* x, int lda, const float* W, int ldw,
   gemm_launch<true, true>(s, g);
 }
 // dx = dy W   (dy [M][K=nout] , W [K][N])
-void linear_bwd_input(hipStream_t s, const float* dy, int lddy, const float* W, int ldw, float* dx, int lddx, int M, int N, int K, int beta) {
+void linear_bwd_input(hipStream_t s, const float* dy, int lddy, const float* W, int ldw, float* dx, int lddx, int M, int N, int K, int beta, int tile = -1) {
   GemmArgs g{dy, W, dx, nullptr, M, N, K, lddy, ldw, lddx, beta, 1, nullptr};
   g.x3 = g_gemm_x3;
-  gemm_launch<true, false>(s, g);
+  gemm_launch<true, false>(s, g, g_gemm_x3 ? -1 : tile);   // tile = 2: 64 x 128 tiles (kbj_gemm.h: few 128 x 128 tiles quantise badly)
 }
 // dW[Nout][Nin] += dy^T x  (dy [R][Nout], x [R][Nin]); split-K over the R samples with atomics (dW pre-zeroed by the caller)
 void linear_bwd_weight(kbj_ctx* ctx, hipStream_t s, const float* dy, int lddy, const float* x, int ldx, float* dW, int lddw, int Nout, int Nin, int R) {
@@ -1116,7 +1116,7 @@ int ppo_forward_nets(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, co
       GemmArgs g{tr->critic_obs_d, w.WinP[1], w.tb[1].X0, params_d + o.b_in, R, H, o.ld_obs, o.ld_obs, o.ld_obs, H, 0, 1, nullptr};
       g.a_idx = idx; g.a_B = B; g.a_N = N;
       g.x3 = sc.gemm_x3 ? 1 : 0;
-      gemm_launch<true, true>(ns[1], g);
+      gemm_launch<true, true>(ns[1], g, sc.gemm_x3 ? -1 : 2);   // 64 x 128 tiles (kbj_gemm.h: 800 tiles of 128 x 128 are 1.56 rounds paid as 2)
       // the copy under the recurrences, on the critic's side lane. It starts behind the ACTOR lane's head (ev_join: the folded-weight preparation
       // and, without a prefetch hint, the head gathers - about when the projection ends; beside it the two would share HBM: 175 instead of 144 us
       // for the GEMM) and behind the side-lane gathers (ev_small), so that ev_obs implies both and the critic's lane - the chain a minibatch
@@ -1399,7 +1399,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
         continue;
       }
       // the input gradient as ONE product on the net's own lane, behind the recurrence (it is the next layer's input)
-      linear_bwd_input(s, t.dGl[l], 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0);
+      linear_bwd_input(s, t.dGl[l], 4 * H, params_d + o.w_ih[l], H, dx_out[n], H, R, H, 4 * H, 0, H <= 256 ? 2 : -1);
       if (l > 0) pending_dw.push_back(PendingDW{n, l});   // issued in the next pass of the layer loop, behind layer l - 1's recurrence
       else {
         fork_side(n);   // the weight gradients start behind the input gradient

@@ -262,6 +262,24 @@ double tail4(const char* name, const TailProblem (&pr)[4], hipStream_t (&st)[4],
   return us;
 }
 
+
+// ---- mode 12: one k-contiguous product (the critic's input projection R x H x 476 at the head of a minibatch's critical chain) by tile configuration ----
+template <int MT, int NT, int WM, int WN, bool B_KC = true>
+void one_kc(const char* name, int M, int N, int K, float* A, float* B, float* C) {
+  constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+  GemmArgs g{A, B, C, nullptr, M, N, K, K, B_KC ? K : N, N, 0, 1, nullptr};
+  const int wgs = (((M + BM - 1) / BM) * ((N + BN - 1) / BN) + 7) / 8 * 8;
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  gemm_launch_tile<MT, NT, true, B_KC, WM, WN>(0, g, wgs);
+  CK(hipDeviceSynchronize());
+  const int reps = 20;
+  CK(hipEventRecord(e0, 0));
+  for (int r = 0; r < reps; ++r) gemm_launch_tile<MT, NT, true, B_KC, WM, WN>(0, g, wgs);
+  CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("%-36s tile %3d x %3d, %d waves, %5d wgs  M=%d N=%d K=%d  %8.1f us  %6.1f TF\n", name, BM, BN, WM * WN, wgs, M, N, K, ms * 1e3 / reps, 2.0 * M * N * K / (ms * 1e-3 / reps) / 1e12);
+}
+
 int main(int argc, char** argv) {
   const int only = argc > 1 ? atoi(argv[1]) : 0;   // 1..4: that shape alone, without the checks (for counter passes)
   size_t big = (size_t)51200 * 1024;
@@ -348,6 +366,24 @@ int main(int argc, char** argv) {
       for (int tgt : {256, 384, 512, 768}) tail4<2, 2, 4, 2>("256x128 on 8 waves (64x64 each)", pr, st, tgt, reps);
       for (int tgt : {256, 384, 512, 768}) tail4<2, 2, 2, 4>("128x256 on 8 waves (64x64 each)", pr, st, tgt, reps);
       for (int tgt : {256, 384, 512, 768}) tail4<4, 1, 2, 4>("256x128 on 8 waves (128x32 each)", pr, st, tgt, reps);
+      for (int tgt : {512, 768, 1024, 1536}) tail4<1, 1, 2, 4>("64x128 on 8 waves (32x32 each)", pr, st, tgt, reps);
+    }
+    return 0;
+  }
+  if (only == 12) {
+    for (int pass = 0; pass < 2; ++pass) {
+      one_kc<2, 1, 2, 4>("in-proj: 128x128 / 8 waves (product)", 51200, 256, 476, A, B, C);
+      one_kc<2, 2, 2, 2>("in-proj: 128x128 / 4 waves", 51200, 256, 476, A, B, C);
+      one_kc<2, 2, 4, 2>("in-proj: 256x128 / 8 waves", 51200, 256, 476, A, B, C);
+      one_kc<2, 2, 2, 4>("in-proj: 128x256 / 8 waves", 51200, 256, 476, A, B, C);
+      one_kc<1, 1, 2, 2>("in-proj: 64x64 / 4 waves", 51200, 256, 476, A, B, C);
+      one_kc<1, 2, 2, 2>("in-proj: 64x128 / 4 waves", 51200, 256, 476, A, B, C);
+      one_kc<1, 1, 2, 4>("in-proj: 64x128 / 8 waves", 51200, 256, 476, A, B, C);
+      one_kc<2, 1, 2, 4>("dX-like fwd ih: 128x128 / 8", 51200, 1024, 256, A, B, C);
+      one_kc<2, 2, 4, 2>("dX-like fwd ih: 256x128 / 8", 51200, 1024, 256, A, B, C);
+      one_kc<2, 1, 2, 4, false>("dX (R x H x 4H): 128x128 / 8 (product)", 51200, 256, 1024, A, B, C);
+      one_kc<1, 1, 2, 4, false>("dX (R x H x 4H): 64x128 / 8", 51200, 256, 1024, A, B, C);
+      one_kc<1, 1, 2, 2, false>("dX (R x H x 4H): 64x64 / 4", 51200, 256, 1024, A, B, C);
     }
     return 0;
   }
