@@ -667,7 +667,21 @@ const float* fold_actor_weights(kbj_ctx* ctx, hipStream_t s, const float* params
   return w.Weff;
 }
 
+// Rollout-time input projections read W_in [H][nin] with nin = 65 / 475 floats per row: no 16-byte alignment, which puts the GEMM on its element-wise
+// load path for that operand (the critic's 8192 x 256 x 475 product ran at 27 TFLOP/s, with four times the load instructions - beside an env kernel
+// that is bound by vector issue). As in the update (ppo_forward_nets): a re-pitched copy with the observation rows' stride, zeros behind column nin,
+// made once per rollout / policy step; the contraction then runs over the padded width (the rows' padding columns hold zeros: host/buffers.py).
+void repitch_input_weights(kbj_ctx* ctx, hipStream_t s, const float* params_d) {
+  NnWs& w = *ws_of(ctx);
+  for (int k = 0; k < 2; ++k) {
+    const NetOff& o = w.net[k];
+    if (o.nin == o.ld_obs) continue;
+    hipLaunchKernelGGL(repitch_rows_kernel, g1((size_t)w.H * o.ld_obs), dim3(256), 0, s, params_d + o.w_in, w.H, o.nin, o.ld_obs, w.WinP[k]);
+  }
+}
+
 // weff: the folded actor input weights (W_ih0 W_in, bias in w.beff) when the caller has prepared them for these parameters, else null
+// (the caller has also run repitch_input_weights for these parameters)
 int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, int net_hi, int n0, int cnt, const float* actor_obs_d, const float* critic_obs_d,
                 kbj_carry* carry, uint32_t seed, uint32_t step_index, int argmax, float* action_d, float* logp_d, float* value_d, int parity, const float* weff) {
   NnWs& w = *ws_of(ctx);
@@ -692,7 +706,10 @@ int policy_nets(kbj_ctx* ctx, hipStream_t s, const float* params_d, int net_lo, 
     }
     const bool fused = fused_any && net_uses_step_kernel(w, n);
     const bool folded = fused && weff && k == 0 && o.ld_obs == KBJ_LD_ACTOR;   // actor-type net: layer-0 gates straight from the observation row
-    if (!folded) linear_fwd(s, obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, X, H, cnt, H, o.nin, 0);
+    if (!folded) {
+      if (o.nin != o.ld_obs) linear_fwd(s, obs, o.ld_obs, w.WinP[k], o.ld_obs, params_d + o.b_in, X, H, cnt, H, o.ld_obs, 0);   // aligned copy of W_in (repitch_input_weights)
+      else linear_fwd(s, obs, o.ld_obs, params_d + o.w_in, o.nin, params_d + o.b_in, X, H, cnt, H, o.nin, 0);
+    }
     const float* x = X;
     for (int l = 0; l < w.D; ++l) {
       float* cc = hc[n] + (size_t)(2 * l + 1) * N * H + (size_t)n0 * H;
@@ -859,6 +876,7 @@ int kbj_policy_step(kbj_ctx* ctx, const float* params_d, const float* actor_obs_
   }
   kbj_nn_drop_prefetch(ctx);   // action / logp / value may be trajectory rows
   KbjTimed timed(ctx, true);
+  repitch_input_weights(ctx, ctx->stream, params_d);
   if (policy_nets(ctx, ctx->stream, params_d, 0, w.nnets, 0, w.N, actor_obs_d, critic_obs_d, carry, seed, step_index, argmax, action_d, logp_d, value_d, 0,
                   fold_actor_weights(ctx, ctx->stream, params_d))) return -1;
   if (w.sched.rollout_step && carry_h_home(ctx, ctx->stream, 0, w.nnets, carry)) return -1;   // the new h sits in the partners: bring it home
@@ -932,6 +950,7 @@ int kbj_rollout(kbj_ctx* ctx, const float* params_d, kbj_carry* carry, uint32_t 
   const bool serial = pipe_env && atoi(pipe_env) == 0;
   hipStream_t cs = serial ? s : ctx->side[0];                 // critic + mirror branches
   const float* weff = fold_actor_weights(ctx, s, params_d);   // once: the parameters are fixed for the whole rollout
+  repitch_input_weights(ctx, s, params_d);                    // (ahead of the fork: the side lane's critic reads the copy)
   if (!serial) {
     KBJ_HIP(ctx, hipEventRecord(ctx->ev_fork, s));
     KBJ_HIP(ctx, hipStreamWaitEvent(cs, ctx->ev_fork, 0));
