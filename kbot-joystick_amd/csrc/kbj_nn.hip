@@ -1294,15 +1294,14 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
     hipLaunchKernelGGL(mirror_loss_kernel, g1(R), dim3(256), 0, ns[1], w.y, w.y_m, w.value, w.value_m, c.actor_mirror_loss_scale, c.critic_mirror_loss_scale, R, w.dy, w.dy_m,
                        w.dvalue, w.dvalue_m, w.stats + 2, one_stream ? 3 : 2);
   }
-  // the metrics line is nobody's input: a side lane computes it once both halves of the loss are in (it joins the caller's stream at the end)
+  // The metrics line is nobody's input. It used to be a one-thread launch on a side lane right here - where every CU is about to be taken by the
+  // backward recurrences (250 registers x 2 wavefronts per SIMD), so in most minibatches it sat dispatched-but-unplaced for ~450 us (2.9 % of the
+  // summed kernel time in a rocprofv3 summary, and the side lane's next launch queued behind it): the same "waiting for a wave slot" artefact as the
+  // pause kernel of rounds 4-5. It now runs at the END of the actor's lane (below), behind an event of the critic's loss half.
   // (the critic lane's record doubles as the fork of its side lane below when nothing is launched on it in between - the fused head: one packet)
   const bool critic_fork_recorded = !one_stream && fused_critic_head;
-  if (!one_stream) {
-    hipEvent_t ea = ctx->ev_pool[ctx->ev_next++ & 31], eb = critic_fork_recorded ? ctx->ev_side[1] : ctx->ev_pool[ctx->ev_next++ & 31];
-    hipEventRecord(ea, ns[0]); hipEventRecord(eb, ns[1]);
-    hipStreamWaitEvent(ctx->side[0], ea, 0); hipStreamWaitEvent(ctx->side[0], eb, 0);
-  }
-  hipLaunchKernelGGL(ppo_metrics_kernel, dim3(1), dim3(1), 0, one_stream ? s : ctx->side[0], w.stats + 2, w.stats, pp, R, metrics_d);
+  hipEvent_t ev_critic_loss = critic_fork_recorded ? ctx->ev_side[1] : ctx->ev_pool[ctx->ev_next++ & 31];
+  if (!one_stream) hipEventRecord(ev_critic_loss, ns[1]);
   // ---- backward ---- (dOut needs no clearing: the actor head writes all 40 columns, the critic's GEMMs read column 0 only)
   hipLaunchKernelGGL(actor_head_bwd_pre_kernel, g1((size_t)R * KBJ_NU), dim3(256), 0, s, w.tb[0].Out, w.y, w.sd, w.act, w.dlogp,
                      w.mirror ? w.dy : (const float*)nullptr, -c.entropy_coef / (float)R, hp, R, w.tb[0].dOut);
@@ -1452,6 +1451,8 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
   // The actor's slice grad[0, nactor) is final here, ~0.4 ms before the critic's (shorter chain: folded layer 0, no 475-wide projection).
   // A data-parallel host may start its all-reduce now, under the critic's tail (kbj_stream_wait_actor_grad).
   if (fold_actor && !bias_done[0]) fold_bias_terms(0, ns[0]);
+  if (!one_stream) hipStreamWaitEvent(ns[0], ev_critic_loss, 0);   // (fired ~3 ms ago)
+  hipLaunchKernelGGL(ppo_metrics_kernel, dim3(1), dim3(1), 0, ns[0], w.stats + 2, w.stats, pp, R, metrics_d);
   if (one_stream) {
     if (fold_actor && fold_critic && !bias_done[1]) fold_bias_terms(1, ns[1]);
     hipLaunchKernelGGL(lane_tail_kernel, dim3(2 * MAXD * 4), dim3(SEQ_COUNTER_WORDS), 0, ctx->stream, w.seq_counters, -1, w.seq_err, grad_d, grad_d + w.nactor);
