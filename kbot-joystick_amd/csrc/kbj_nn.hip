@@ -11,7 +11,6 @@
 #include "kbj_nn_kernels.h"
 #include "kbj_lstm_seq.h"
 #include "kbj_lstm_bwd16.h"
-#include "kbj_lstm_bwd16x2.h"
 
 using namespace kbj;
 
@@ -43,7 +42,6 @@ struct Sched {
   bool deterministic = false;      // fixed-order reductions instead of fp32 / fp64 atomics (bit-reproducible update)
   bool bwd16 = true;               // KBJ_BWD16=0: backward recurrences on the 32-row x 32-unit form of rounds 1-4 (lstm_seq_bwd_kernel) instead of 16-row x 64-unit
                                    // tiles with the partner-major contraction (kbj_lstm_bwd16.h: 620 instead of 907 us per launch in situ)
-  bool bwd16x2 = false;            // KBJ_BWD16X2=1 (experiment): two interleaved 16-row groups per backward-recurrence workgroup (kbj_lstm_bwd16x2.h; H = 256, batch a multiple of 32)
   bool critic_on_caller = true;    // KBJ_CRITIC_LANE=2nd: the critic's chain on the context's SECOND stream (rounds 1-5). Default (round 6): the critic - the longer
                                    // chain, the one a minibatch waits for - runs on the caller's stream, so that nothing between the optimizer step and the
                                    // critic's first kernel, nor between its last kernel and the next optimizer step, crosses a queue (a cross-queue event wait
@@ -312,20 +310,10 @@ template <int H> void seq_bwd16_launch(hipStream_t s, const SeqBwdArgs& a0) {
   if (g_seq_drop_bwd > 0 && grid > 1 && H > BWD16_UNITS) { --g_seq_drop_bwd; --grid; }   // fault injection (a launch without partners has nobody to time out)
   hipLaunchKernelGGL((lstm_seq_bwd16_kernel<H>), dim3(grid), dim3(BWD16_NTH), 0, s, a);
 }
-template <int H> void seq_bwd16x2_launch(hipStream_t s, const SeqBwdArgs& a0) {
-  SeqBwdArgs a = a0;
-  a.timeout_ticks = g_seq_timeout_ticks;
-  constexpr size_t bytes = bwdx2_lds_bytes<H>();
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&lstm_seq_bwd16x2_kernel<H>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-  (void)attr;
-  const int grid = (H / BWDX2_UNITS) * (a.B / (2 * BWDX2_ROWS));
-  hipLaunchKernelGGL((lstm_seq_bwd16x2_kernel<H>), dim3(grid), dim3(BWDX2_NTH), bytes, s, a);
-}
 // row groups of a backward-recurrence launch (deterministic mode: rows of its per-row-group bias partials)
 int seq_bwd_row_groups(int B, bool tiles16) { return tiles16 ? (B + BWD16_ROWS - 1) / BWD16_ROWS : (B + SEQ_ROWS - 1) / SEQ_ROWS; }
-int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a, bool tiles16 = false, bool x2 = false) {   // a.counters: zeroed by the caller
+int seq_bwd(kbj_ctx* ctx, hipStream_t st, int H, const SeqBwdArgs& a, bool tiles16 = false) {   // a.counters: zeroed by the caller
   KbjKernelTimer timer(st, tiles16 ? KBJ_KIND_SEQ_BWD16 : KBJ_KIND_SEQ_BWD, 2.0 * a.T * a.B * 4.0 * H * H);
-  if (tiles16 && x2 && H == 256 && a.B % (2 * BWDX2_ROWS) == 0) { seq_bwd16x2_launch<256>(st, a); return 0; }
   if (tiles16) {
     switch (H) {
       case 64: seq_bwd16_launch<64>(st, a); break;
@@ -574,7 +562,6 @@ int kbj_nn_create(kbj_ctx* ctx) {
     sc.deterministic = c.deterministic != 0 || env_flag("KBJ_DETERMINISTIC", false);
     { const char* cl = getenv("KBJ_CRITIC_LANE"); sc.critic_on_caller = !(cl && std::string(cl) == "2nd"); }
     sc.bwd16 = env_flag("KBJ_BWD16", true) && H <= (size_t)SEQ_FUSED_MAX_H;   // wide layers keep lstm_seq_bwd_wide_kernel
-    sc.bwd16x2 = sc.bwd16 && env_flag("KBJ_BWD16X2", false) && H == 256;
     sc.gemm_x3 = (c.gemm_bf16x3 != 0 || env_flag("KBJ_GEMM_X3", false)) && !sc.deterministic;   // (the deterministic split-K slabs stay on the exact kernel)
     if (H > (size_t)SEQ_FUSED_MAX_H) sc.fuse_ih = sc.fuse_obs = sc.rollout_step = false;   // wide layers (SEQ_FUSED_MAX_H above)
     if (sc.deterministic) {
@@ -1380,7 +1367,7 @@ int kbj_ppo_grad(kbj_ctx* ctx, const float* params_d, const kbj_traj* tr, const 
       ba.db_part = det_partials(ctx, ns[n & 1]);   // deterministic mode: per-row-group bias sums, added in order below
       if (w.seq_bstamps && bstamp_sel == 1 + n + 2 * l) ba.stamps = w.seq_bstamps;
       const bool tiles16 = sc.bwd16;
-      if (seq_bwd(ctx, ns[n & 1], H, ba, tiles16, sc.bwd16x2)) return -1;
+      if (seq_bwd(ctx, ns[n & 1], H, ba, tiles16)) return -1;
       if (ba.db_part) hipLaunchKernelGGL(reduce_rows_kernel, dim3((4 * H + 255) / 256), dim3(256), 0, ns[n & 1], ba.db_part, seq_bwd_row_groups(B, tiles16), 4 * H, grad_d + o.b[l]);
     }
     // the layer above's weight gradients, behind THIS layer's recurrence of the same net
